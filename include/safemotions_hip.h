@@ -1,0 +1,126 @@
+/*
+ * safemotions_hip.h - C ABI of libsmr_hip.so: the batched, MI355X-native replacement for the
+ * per-RL-step hot path of translearn/safeMotionsRisk.
+ *
+ * The reference has no native boundary on this path: its boundary is the Python gym surface
+ *     Env(**env_config)                         train.py:620, base.py:85-207
+ *     obs = env.reset()                         observations.py:144-187  -> base.py:913-1022
+ *     obs, reward, done, info = env.step(a)     base.py:1043-1227
+ * one environment per process.  This library is what a maintainer binds underneath that surface to
+ * run B environments per call on one GPU (one environment per wavefront lane); the ctypes stub is
+ * safemotionsrisk_amd/lib.py and the gym-style shim is safemotionsrisk_amd/env.py.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a negative SMR_E_* code on failure; nothing throws
+ *    across the ABI; smr_last_error() returns the message of the last failure on that handle
+ *    (handle == NULL: the last smr_create failure of the calling thread).
+ *  - "dev" pointers are device pointers on the handle's GPU, owned by the caller (e.g. torch tensors);
+ *    "host" pointers are ordinary host memory.  The library owns all persistent env state.
+ *  - all kernels of a handle are enqueued on the hipStream_t given to smr_create (NULL = the legacy
+ *    default stream); calls return without synchronising unless documented otherwise.
+ *  - a handle is not re-entrant: one call at a time per handle.
+ */
+#ifndef SAFEMOTIONS_HIP_H
+#define SAFEMOTIONS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "smr_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMR_ABI_VERSION 1
+
+#define SMR_OK 0
+#define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
+#define SMR_E_HIP (-2)          /* a HIP runtime call failed                   */
+#define SMR_E_NO_DEVICE (-3)    /* no usable GPU (the library has no CPU path) */
+
+/* columns of the optional per-step info matrix (float32 [B][SMR_INFO_N]); the Python shim turns
+ * them into the reference's info dict (base.py:1350-1386, rewards.py:490-498) */
+#define SMR_INFO_D_STATIC 0           /* minimum_distance_to_static_obstacles after the 0.001 clamp, rewards.py:115-117 */
+#define SMR_INFO_D_SELF 1             /* minimum_distance_self_collision,          rewards.py:119-121 */
+#define SMR_INFO_D_MOVING 2           /* minimum_distance_to_moving_obstacles,     rewards.py:147-155 */
+#define SMR_INFO_ACTION_PUNISHMENT 3  /* rewards.py:164-169 */
+#define SMR_INFO_R_SELF 4             /* self_collision_reward,                     rewards.py:123-126 */
+#define SMR_INFO_R_STATIC 5           /* static_obstacles_collision_reward,         rewards.py:128-131 */
+#define SMR_INFO_R_MOVING 6           /* moving_obstacles_collision_reward,         rewards.py:157-159 */
+#define SMR_INFO_EPISODE_LENGTH 7     /* _episode_length of the step just taken,    base.py:1044,1374 */
+#define SMR_INFO_N 8
+
+/* kernels timed by smr_get_profile */
+#define SMR_K_PLAN 0      /* A2/A4: safe acceleration range + action mapping            */
+#define SMR_K_COLLIDE 1   /* A3/A6/A7/A8/A11: cubic sample, FK, GJK distances, contacts  */
+#define SMR_K_FINISH 2    /* A1/A12/A13/A15/A16: state update, reward, termination, obs  */
+#define SMR_K_RESET 3     /* A17/A9: start-state and planet-phase sampling               */
+#define SMR_K_COUNT 4
+
+typedef struct smr_env smr_env_t;   /* opaque */
+
+/* Host-side snapshot of the persistent env state (get/set: parity injection and checkpointing; the
+ * reference's counterpart is the attribute copy of base.py:1801-1891).  Any pointer may be NULL. */
+typedef struct smr_host_state {
+    float *q;              /* [B][7] joint position setpoint (_start_position, base.py:1179)     */
+    float *v;              /* [B][7] joint velocity setpoint (_start_velocity, base.py:1180)     */
+    float *a;              /* [B][7] joint acceleration      (_start_acceleration, base.py:1181) */
+    int32_t *planet_idx;   /* [B][2] Planet._current_time_step_index, ctlp.py:4504               */
+    int32_t *step_count;   /* [B]    _episode_length, base.py:1044                               */
+    int32_t *moving_hit;   /* [B]    latched Planet._collision_detected, ctlp.py:4570-4579       */
+    uint32_t *rng_draws;   /* [B]    per-env Philox draw counter                                */
+} smr_host_state_t;
+
+int smr_abi_version(void);
+size_t smr_scene_sizeof(void);          /* sizeof(smr_scene_t) as compiled into the library */
+
+/* Env(**env_config) x B.  device: HIP device ordinal.  stream: hipStream_t or NULL. */
+int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint64_t seed, void *stream,
+               smr_env_t **out);
+int smr_destroy(smr_env_t *env);
+const char *smr_last_error(const smr_env_t *env);
+
+int32_t smr_num_envs(const smr_env_t *env);
+int32_t smr_obs_size(const smr_env_t *env);
+
+/* env.reset() for the envs whose mask byte is non-zero (mask_dev == NULL: all).  obs_dev float32
+ * [B][obs_size] receives the observation of the reset envs (other rows untouched); may be NULL. */
+int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev);
+
+/* env.step(action) for all B envs.  actions_dev float32 [B][7] in [-1,1] (base.py:1051);
+ * obs_dev float32 [B][obs_size]; reward_dev float32 [B]; done_dev uint8 [B];
+ * reason_dev int8 [B] = SMR_TERMINATION_* (-1 while running); info_dev float32 [B][SMR_INFO_N] or NULL.
+ * With scene.auto_reset a finished env is re-sampled before the call returns and obs_dev holds the
+ * first observation of its next episode (done/reward/reason/info describe the finished step). */
+int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev,
+             int8_t *reason_dev, float *info_dev);
+
+/* current observation of every env (obs.py:313-351) without stepping */
+int smr_observe(smr_env_t *env, float *obs_dev);
+
+int smr_get_state(smr_env_t *env, const smr_host_state_t *host_out);   /* synchronises */
+int smr_set_state(smr_env_t *env, const smr_host_state_t *host_in);    /* synchronises */
+int smr_synchronize(smr_env_t *env);
+
+/* Per-kernel HIP-event timing (events are recorded on the handle's stream around every launch while
+ * enabled; smr_get_profile synchronises, returns accumulated milliseconds and launch counts per
+ * SMR_K_* kernel since the last call and clears them). */
+int smr_set_profiling(smr_env_t *env, int32_t enable);
+int smr_get_profile(smr_env_t *env, double ms_out[SMR_K_COUNT], int64_t launches_out[SMR_K_COUNT]);
+
+/* ---- component entry points (parity tests): each runs the same device functions the step kernels
+ * use on n host-provided inputs and copies the results back; all synchronise ---- */
+/* A6: link frames of iiwa_link_0..7; pos_out [n][8][3], rot_out [n][8][9] row-major */
+int smr_test_fk(smr_env_t *env, const float *q_host, int32_t n, float *pos_out, float *rot_out);
+/* A4: per joint [lo, hi] and violation code; p/v/a/lo/hi [n][7], code [n][7] */
+int smr_test_safe_acc_range(smr_env_t *env, const float *p_host, const float *v_host, const float *a_host,
+                            int32_t n, float *lo_out, float *hi_out, int32_t *code_out);
+/* A7/A8/A11: out [n][4] = d_static, d_self, d_moving (no latch), contact flag; planet_idx [n][2] */
+int smr_test_distances(smr_env_t *env, const float *q_host, const int32_t *planet_idx_host, int32_t n,
+                       float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAFEMOTIONS_HIP_H */

@@ -1,0 +1,889 @@
+/*
+ * smr_oracle.cpp - CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A scalar float64 restatement of the per-RL-step hot path of translearn/safeMotionsRisk
+ * (SafeMotionsEnvCollisionAvoidance.reset()/step()).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (safemotionsrisk_amd/) never does.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in two third-party packages that are not part
+ * of /root/reference and are not installable here - pybullet==3.1.6 (FK, GJK closest points,
+ * contacts) and klimits==1.1.3 (safe acceleration range) - and the reference ships no tests, golden
+ * vectors or fixtures for it.  This file restates the published algorithms (Bullet's convex-hull +
+ * margin distance model; Kiemel & Kroeger, ICRA 2021 for the acceleration range) and follows the
+ * reference's own call sites line by line for everything else.  It is pinned only by analytic
+ * known answers (tests/test_oracle_*.py).
+ *
+ * Reference short names: base.py = safemotions/envs/safe_motions_base.py, actions.py / obs.py /
+ * rewards.py = safemotions/envs/decorators/<name>.py, ctlp.py =
+ * safemotions/robot_scene/collision_torque_limit_prevention.py, scene.py =
+ * safemotions/robot_scene/robot_scene_base.py, tm.py = safemotions/utils/trajectory_manager.py.
+ */
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../include/smr_scene.h"
+
+namespace {
+
+struct V3 { double x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 neg(V3 a) { return {-a.x, -a.y, -a.z}; }
+
+struct Xf {            // rigid transform world <- body: x_w = R x_b + t, R row-major
+    double R[9];
+    V3 t;
+};
+inline V3 rot(const Xf &X, V3 v) {
+    return {X.R[0] * v.x + X.R[1] * v.y + X.R[2] * v.z, X.R[3] * v.x + X.R[4] * v.y + X.R[5] * v.z,
+            X.R[6] * v.x + X.R[7] * v.y + X.R[8] * v.z};
+}
+inline V3 rot_t(const Xf &X, V3 v) {
+    return {X.R[0] * v.x + X.R[3] * v.y + X.R[6] * v.z, X.R[1] * v.x + X.R[4] * v.y + X.R[7] * v.z,
+            X.R[2] * v.x + X.R[5] * v.y + X.R[8] * v.z};
+}
+inline V3 apply(const Xf &X, V3 v) { return rot(X, v) + X.t; }
+inline Xf identity_xf() { return {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}}; }
+
+/* quaternion (x,y,z,w) -> rotation matrix */
+inline void quat_to_R(const double q[4], double R[9]) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double n = x * x + y * y + z * z + w * w;
+    double s = n > 0 ? 2.0 / n : 0.0;
+    R[0] = 1 - s * (y * y + z * z); R[1] = s * (x * y - z * w);     R[2] = s * (x * z + y * w);
+    R[3] = s * (x * y + z * w);     R[4] = 1 - s * (x * x + z * z); R[5] = s * (y * z - x * w);
+    R[6] = s * (x * z - y * w);     R[7] = s * (y * z + x * w);     R[8] = 1 - s * (x * x + y * y);
+}
+
+/* ------------------------------------------------------------------------------------------- *
+ * RNG: Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (block, env, stream, 0).
+ * Draw d of env e is word d&3 of block d>>2.  uniform01 keeps 24 bits, so the same draw is exact
+ * in float32 and float64.  The reference uses numpy's global Mersenne Twister with data-dependent
+ * draw counts (base.py:1704-1710, ctlp.py:2030-2138); reset parity is therefore property based.
+ * ------------------------------------------------------------------------------------------- */
+inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+struct Rng {
+    uint64_t seed;
+    uint32_t env;
+    uint32_t draws;     // persistent per-env draw counter (part of the env state)
+    uint32_t next_u32() {
+        uint32_t c[4] = {draws >> 2, env, 0u, 0u};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        uint32_t w = c[draws & 3u];
+        ++draws;
+        return w;
+    }
+    double uniform01() { return (double)(next_u32() >> 8) * (1.0 / 16777216.0); }
+    double uniform(double lo, double hi) { return lo + uniform01() * (hi - lo); }
+    int randint(int n) {                 // [0, n)
+        int k = (int)(uniform01() * n);
+        return k < n ? k : n - 1;
+    }
+};
+
+/* ------------------------------------------------------------------------------------------- *
+ * A3: constant-jerk segment, actions.py:468-487 (= ctlp.py:3509-3530, klimits interpolate_*).
+ * ------------------------------------------------------------------------------------------- */
+inline double interp_pos(double p0, double v0, double a0, double a1, double t, double dt) {
+    return p0 + v0 * t + 0.5 * a0 * t * t + (1.0 / 6.0) * ((a1 - a0) / dt) * t * t * t;
+}
+inline double interp_vel(double v0, double a0, double a1, double t, double dt) {
+    return v0 + a0 * t + 0.5 * ((a1 - a0) / dt) * t * t;
+}
+
+/* ------------------------------------------------------------------------------------------- *
+ * A4: range of end-of-step accelerations a1 from which pos/vel/acc/jerk limits remain satisfiable
+ * forever (call sites actions.py:97-106,206-211; klimits.PosVelJerkLimitation, source absent).
+ * Restated from Kiemel & Kroeger, "Learning Robot Trajectories subject to Kinematic Joint
+ * Constraints" (ICRA 2021), Sec. IV, as an exact discrete-time viability test per constraint:
+ *   a1 is admissible for the upper velocity (position) limit iff, after the segment a0->a1, the
+ *   profile that lowers the acceleration by jerk_max*dt per step (floored at -acc_max) never
+ *   exceeds vel_max (pos_hi) before the velocity stops increasing (the joint stops moving up).
+ * That braking profile minimises a(t), hence v(t), hence p(t) pointwise, so the test is exact for
+ * piecewise-linear accelerations with knots every dt.  The admissible set is an interval; its end
+ * is found by bisection.  Lower limits use the mirrored state.
+ * violation code bits: 1 velocity, 2 position, 4 empty intersection.
+ * ------------------------------------------------------------------------------------------- */
+struct JointLim { double plo, phi, V, A, J, dt; };
+
+const double kVelTolRel = 1e-5;   /* slack on the limits so that a state that sits on a limit */
+const double kPosTolRel = 1e-6;   /* up to rounding is still "feasible"                        */
+const int kBrakeMaxSteps = 4096;
+
+inline double seg_vmax(double v0, double a0, double a1, double dt) {
+    double m = v0 + 0.5 * (a0 + a1) * dt;
+    if (a0 > 0 && a1 < 0) {
+        double tau = dt * a0 / (a0 - a1);
+        m = std::max(m, v0 + 0.5 * a0 * tau);
+    }
+    return m;
+}
+
+inline double seg_pmax(double p0, double v0, double a0, double a1, double dt) {
+    double m = interp_pos(p0, v0, a0, a1, dt, dt);
+    double j = (a1 - a0) / dt;
+    /* stationary points of p: 0.5 j t^2 + a0 t + v0 = 0, t in (0, dt) */
+    double disc = a0 * a0 - 2.0 * j * v0;
+    if (disc >= 0) {
+        double sq = std::sqrt(disc);
+        double q = -(a0 + (a0 >= 0 ? sq : -sq));
+        double r[2];
+        int n = 0;
+        if (j != 0 && std::isfinite(q / j)) r[n++] = q / j;
+        if (q != 0) r[n++] = 2.0 * v0 / q;
+        for (int i = 0; i < n; ++i)
+            if (r[i] > 0 && r[i] < dt) m = std::max(m, interp_pos(p0, v0, a0, a1, r[i], dt));
+    }
+    return m;
+}
+
+bool vel_upper_ok(double v0, double a0, double a1, double Vlim, const JointLim &L) {
+    if (seg_vmax(v0, a0, a1, L.dt) > Vlim) return false;
+    double v = v0 + 0.5 * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
+    for (int it = 0; it < kBrakeMaxSteps; ++it) {
+        if (a <= 0) return true;
+        double an = std::max(a - D, -L.A);
+        if (seg_vmax(v, a, an, L.dt) > Vlim) return false;
+        v += 0.5 * (a + an) * L.dt;
+        a = an;
+    }
+    return false;
+}
+
+bool pos_upper_ok(double p0, double v0, double a0, double a1, double Plim, const JointLim &L) {
+    if (seg_pmax(p0, v0, a0, a1, L.dt) > Plim) return false;
+    double p = interp_pos(p0, v0, a0, a1, L.dt, L.dt);
+    double v = v0 + 0.5 * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
+    for (int it = 0; it < kBrakeMaxSteps; ++it) {
+        if (v <= 0 && a <= 0) return true;
+        double an = std::max(a - D, -L.A);
+        if (seg_pmax(p, v, a, an, L.dt) > Plim) return false;
+        p = interp_pos(p, v, a, an, L.dt, L.dt);
+        v += 0.5 * (a + an) * L.dt;
+        a = an;
+    }
+    return false;
+}
+
+template <class Pred>
+double upper_end(Pred ok, double lo, double hi, bool &violated) {
+    violated = false;
+    if (ok(hi)) return hi;
+    if (!ok(lo)) { violated = true; return lo; }
+    for (int it = 0; it < 60; ++it) {
+        double mid = 0.5 * (lo + hi);
+        if (ok(mid)) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+void safe_acc_range_joint(const JointLim &L, double p, double v, double a, double &lo, double &hi, int &code) {
+    double D = L.J * L.dt;
+    double blo = std::max(-L.A, a - D), bhi = std::min(L.A, a + D);
+    if (blo > bhi) { blo = bhi = std::min(std::max(a, -L.A), L.A); }
+    double Vlim = L.V * (1.0 + kVelTolRel);
+    double ptol = kPosTolRel * (L.phi - L.plo);
+    bool viol;
+    code = 0;
+    double uv = upper_end([&](double a1) { return vel_upper_ok(v, a, a1, Vlim, L); }, blo, bhi, viol);
+    if (viol) code |= 1;
+    double up = upper_end([&](double a1) { return pos_upper_ok(p, v, a, a1, L.phi + ptol, L); }, blo, bhi, viol);
+    if (viol) code |= 2;
+    double lv = -upper_end([&](double a1) { return vel_upper_ok(-v, -a, a1, Vlim, L); }, -bhi, -blo, viol);
+    if (viol) code |= 1;
+    double lp = -upper_end([&](double a1) { return pos_upper_ok(-p, -v, -a, a1, -L.plo + ptol, L); }, -bhi, -blo, viol);
+    if (viol) code |= 2;
+    hi = std::min(uv, up);
+    lo = std::max(lv, lp);
+    if (lo > hi) {
+        code |= 4;
+        double mid = 0.5 * (lo + hi);
+        lo = hi = std::min(std::max(mid, blo), bhi);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- *
+ * A6: forward kinematics = pybullet getLinkState(...)[4],[5] (URDF link frames) of iiwa_link_0..7
+ * for joint vector q (ctlp.py:2940-2985, 5163-5195; chain from description/urdf/robot.urdf).
+ * ------------------------------------------------------------------------------------------- */
+void forward_kinematics(const smr_scene_t &S, const double q[SMR_NJ], Xf out[SMR_NLINK]) {
+    Xf T = identity_xf();
+    T.t = {S.base_xyz[0], S.base_xyz[1], S.base_xyz[2]};
+    out[0] = T;
+    for (int k = 0; k < SMR_NJ; ++k) {
+        V3 o = {S.joint_xyz[k][0], S.joint_xyz[k][1], S.joint_xyz[k][2]};
+        T.t = apply(T, o);
+        double ax = S.joint_axis[k][0], ay = S.joint_axis[k][1], az = S.joint_axis[k][2];
+        double c = std::cos(q[k]), s = std::sin(q[k]), C = 1 - c;
+        double Rj[9] = {c + ax * ax * C,      ax * ay * C - az * s, ax * az * C + ay * s,
+                        ay * ax * C + az * s, c + ay * ay * C,      ay * az * C - ax * s,
+                        az * ax * C - ay * s, az * ay * C + ax * s, c + az * az * C};
+        double Rn[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                Rn[3 * i + j] = T.R[3 * i] * Rj[j] + T.R[3 * i + 1] * Rj[3 + j] + T.R[3 * i + 2] * Rj[6 + j];
+        std::memcpy(T.R, Rn, sizeof Rn);
+        out[k + 1] = T;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- *
+ * GJK distance between two convex vertex sets (Gilbert, Johnson, Keerthi 1988) - the published
+ * algorithm behind pybullet.getClosestPoints for convex hull shapes (btGjkPairDetector); the
+ * reported distance is dist(hull_A, hull_B) - margin_A - margin_B (Bullet's margin model).
+ * The closest point of the current simplex to the origin is found by brute force over all of its
+ * sub-simplices (Johnson's sub-algorithm without the recursive shortcuts).
+ * ------------------------------------------------------------------------------------------- */
+struct Hull { const double *v; int n; Xf X; };
+
+long g_support_calls = 0;   /* work counter for the flop model, not thread safe by design */
+bool g_count_work = false;
+
+inline V3 support(const Hull &H, V3 d) {
+    V3 dl = rot_t(H.X, d);
+    int best = 0;
+    double bd = -1e300;
+    for (int i = 0; i < H.n; ++i) {
+        double s = H.v[3 * i] * dl.x + H.v[3 * i + 1] * dl.y + H.v[3 * i + 2] * dl.z;
+        if (s > bd) { bd = s; best = i; }
+    }
+    if (g_count_work) g_support_calls += H.n;
+    return apply(H.X, {H.v[3 * best], H.v[3 * best + 1], H.v[3 * best + 2]});
+}
+
+/* closest point to the origin on conv{w[0..n)}; keeps only the supporting vertices */
+static V3 simplex_closest(V3 w[4], int &n) {
+    double bestd = 1e300;
+    V3 bestp = w[0];
+    int bestmask = 1;
+    for (int mask = 1; mask < (1 << n); ++mask) {
+        int idx[4], k = 0;
+        for (int i = 0; i < n; ++i) if (mask & (1 << i)) idx[k++] = i;
+        /* minimise |sum l_i w_i|^2 s.t. sum l_i = 1: eliminate l_0, solve (k-1)x(k-1) normal equations */
+        double lam[4];
+        if (k == 1) {
+            lam[0] = 1;
+        } else {
+            int m = k - 1;
+            double M[3][4];
+            V3 e[3];
+            for (int i = 0; i < m; ++i) e[i] = w[idx[i + 1]] - w[idx[0]];
+            for (int i = 0; i < m; ++i) {
+                for (int j = 0; j < m; ++j) M[i][j] = dot(e[i], e[j]);
+                M[i][m] = -dot(e[i], w[idx[0]]);
+            }
+            bool singular = false;
+            for (int c = 0; c < m && !singular; ++c) {           /* Gauss-Jordan with partial pivoting */
+                int piv = c;
+                for (int r = c + 1; r < m; ++r) if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+                double scale = 0;
+                for (int j = 0; j < m; ++j) scale = std::max(scale, std::fabs(M[c][j]));
+                if (std::fabs(M[piv][c]) <= 1e-14 * std::max(scale, 1e-300)) { singular = true; break; }
+                if (piv != c) for (int j = 0; j <= m; ++j) std::swap(M[piv][j], M[c][j]);
+                for (int r = 0; r < m; ++r) {
+                    if (r == c) continue;
+                    double f = M[r][c] / M[c][c];
+                    for (int j = c; j <= m; ++j) M[r][j] -= f * M[c][j];
+                }
+            }
+            if (singular) continue;
+            double s = 0;
+            for (int i = 0; i < m; ++i) { lam[i + 1] = M[i][m] / M[i][i]; s += lam[i + 1]; }
+            lam[0] = 1 - s;
+        }
+        bool inside = true;
+        for (int i = 0; i < k; ++i) if (lam[i] < -1e-12) inside = false;
+        if (!inside) continue;
+        V3 pnt = {0, 0, 0};
+        for (int i = 0; i < k; ++i) pnt = pnt + std::max(lam[i], 0.0) * w[idx[i]];
+        double d2 = dot(pnt, pnt);
+        if (d2 < bestd) { bestd = d2; bestp = pnt; bestmask = mask; }
+    }
+    V3 nw[4];
+    int k = 0;
+    for (int i = 0; i < n; ++i) if (bestmask & (1 << i)) nw[k++] = w[i];
+    for (int i = 0; i < k; ++i) w[i] = nw[i];
+    n = k;
+    return bestp;
+}
+
+/* Distance between the two hulls (without margins).  If it can be proven to exceed `cutoff`
+ * the search stops and a lower bound > cutoff is returned. */
+double gjk_distance(const Hull &A, const Hull &B, double cutoff) {
+    V3 w[4];
+    int n = 0;
+    V3 v = apply(A.X, {A.v[0], A.v[1], A.v[2]}) - apply(B.X, {B.v[0], B.v[1], B.v[2]});
+    double vv = dot(v, v);
+    for (int it = 0; it < 128; ++it) {
+        if (vv < 1e-24) return 0.0;
+        V3 wn = support(A, neg(v)) - support(B, v);
+        double vw = dot(v, wn);
+        if (vw > 0) {
+            double lb = vw / std::sqrt(vv);
+            if (lb > cutoff) return lb;
+        }
+        if (vv - vw <= 1e-12 * vv) break;                 /* v is (numerically) the closest point */
+        bool dup = false;
+        for (int i = 0; i < n; ++i) {
+            V3 d = w[i] - wn;
+            if (dot(d, d) == 0) dup = true;
+        }
+        if (dup) break;
+        w[n++] = wn;
+        V3 vn = simplex_closest(w, n);
+        double vvn = dot(vn, vn);
+        if (n == 4) return 0.0;                           /* origin inside a tetrahedron */
+        if (vvn >= vv) break;                             /* no progress (rounding) */
+        v = vn;
+        vv = vvn;
+    }
+    return std::sqrt(vv);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+struct EnvState {
+    double q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
+    int32_t planet_idx[SMR_MAX_PLANETS];
+    int32_t step_count;
+    int32_t moving_hit;        /* latched Planet._collision_detected / ball hit_robot */
+    uint32_t rng_draws;
+};
+
+struct Oracle {
+    smr_scene_t S;
+    std::vector<double> verts;
+    std::vector<smr_piece_t> pieces;
+    std::vector<double> orbit_pose[SMR_MAX_PLANETS], orbit_local[SMR_MAX_PLANETS];
+    int B;
+    uint64_t seed;
+    std::vector<EnvState> st;
+    std::string err;
+    int num_threads;
+};
+
+inline Hull piece_hull(const Oracle &O, int piece, const Xf &X) {
+    const smr_piece_t &P = O.pieces[piece];
+    return {&O.verts[3 * (size_t)P.vert_begin], P.vert_count, X};
+}
+
+/* signed distance (margins subtracted) between two pieces; values above `cutoff` only mean
+ * "farther than cutoff" (getClosestPoints(distance=cutoff) returns nothing, ctlp.py:2915-2931) */
+double piece_distance(const Oracle &O, int pa, const Xf &Xa, int pb, const Xf &Xb, double cutoff) {
+    const smr_piece_t &A = O.pieces[pa], &B = O.pieces[pb];
+    double margins = A.margin + B.margin;
+    V3 ca = apply(Xa, {A.center[0], A.center[1], A.center[2]});
+    V3 cb = apply(Xb, {B.center[0], B.center[1], B.center[2]});
+    V3 d = ca - cb;
+    double sphere_lb = std::sqrt(dot(d, d)) - A.radius - B.radius - margins;
+    if (sphere_lb > cutoff) return sphere_lb;
+    return gjk_distance(piece_hull(O, pa, Xa), piece_hull(O, pb, Xb), cutoff + margins) - margins;
+}
+
+Xf planet_pose(const Oracle &O, int p, int idx) {
+    const double *row = &O.orbit_pose[p][7 * (size_t)idx];
+    Xf X;
+    quat_to_R(row + 3, X.R);
+    X.t = {row[0], row[1], row[2]};
+    return X;
+}
+
+/* A7: get_minimum_distance(check_safety_distance=False), ctlp.py:3282-3374 -> (static, self). */
+void min_distance_static_self(const Oracle &O, const Xf link[SMR_NLINK], double &d_static, double &d_self) {
+    const smr_scene_t &S = O.S;
+    d_static = S.static_max_distance;
+    d_self = S.static_max_distance;      /* no self-collision pairs for one iiwa, ctlp.py:1409-1459 */
+    Xf I = identity_xf();
+    for (int s = 0; s < S.n_static; ++s)
+        for (int k = 0; k < SMR_NLINK; ++k) {
+            if (!(S.static_link_mask & (1u << k))) continue;
+            double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], S.static_max_distance);
+            if (d <= S.static_max_distance && d < d_static) d_static = d;
+        }
+}
+
+/* A8: _get_minimum_distance_to_obstacles, ctlp.py:3258-3280 (planets). */
+double min_distance_moving(const Oracle &O, const Xf link[SMR_NLINK], const int32_t planet_idx[]) {
+    const smr_scene_t &S = O.S;
+    double dmin = S.moving_max_distance + 0.002;
+    for (int p = 0; p < S.n_planets; ++p) {
+        Xf Xp = planet_pose(O, p, planet_idx[p]);
+        for (int k = 0; k < SMR_NLINK; ++k) {
+            if (!(S.moving_link_mask & (1u << k))) continue;
+            for (int c = 0; c < S.planet[p].piece_count; ++c) {
+                double d = piece_distance(O, S.planet[p].piece_begin + c, Xp, S.link_piece[k], link[k],
+                                          S.moving_max_distance);
+                if (d <= S.moving_max_distance && d < dmin) {
+                    dmin = d;
+                    if (dmin <= 0.0) return 0.0;
+                }
+            }
+        }
+    }
+    return dmin;
+}
+
+/* A11: Planet.check_if_object_is_colliding, ctlp.py:4570-4579 = "Bullet holds a contact point
+ * between the planet and any robot link", i.e. separation <= contact breaking threshold. */
+bool moving_contact(const Oracle &O, const Xf link[SMR_NLINK], const int32_t planet_idx[]) {
+    const smr_scene_t &S = O.S;
+    for (int p = 0; p < S.n_planets; ++p) {
+        Xf Xp = planet_pose(O, p, planet_idx[p]);
+        for (int k = 0; k < SMR_NLINK; ++k) {
+            if (!(S.contact_link_mask & (1u << k))) continue;
+            for (int c = 0; c < S.planet[p].piece_count; ++c) {
+                double d = piece_distance(O, S.planet[p].piece_begin + c, Xp, S.link_piece[k], link[k],
+                                          S.contact_distance);
+                if (d <= S.contact_distance) return true;
+            }
+        }
+    }
+    return false;
+}
+
+JointLim joint_lim(const smr_scene_t &S, int j) {
+    return {S.pos_lo[j], S.pos_hi[j], S.vel_max[j], S.acc_max[j], S.jerk_max[j], S.dt};
+}
+
+/* A15: _get_observation, obs.py:313-351 (+ :17-32, :233-242, :262-292). */
+void observation(const Oracle &O, const EnvState &e, float *obs) {
+    const smr_scene_t &S = O.S;
+    int o = 0;
+    for (int j = 0; j < SMR_NJ; ++j) obs[o++] = (float)(-1 + 2 * (e.q[j] - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j]));
+    for (int j = 0; j < SMR_NJ; ++j) obs[o++] = (float)(e.v[j] / S.vel_max[j]);
+    for (int j = 0; j < SMR_NJ; ++j) obs[o++] = (float)(e.a[j] / S.acc_max[j]);
+    for (int p = 0; p < S.obs_num_planets; ++p) {
+        int idx = e.planet_idx[p];
+        if (S.obs_planet_size_per_planet == 1) {
+            obs[o++] = (float)(-1 + 2 * ((double)idx - 0) / ((double)S.planet[p].n_orbit - 0));
+        } else if (S.obs_planet_size_per_planet == 2) {
+            for (int c = 0; c < 2; ++c) {
+                double lo = -1.05 * S.planet[p].radius_xy[c], hi = 1.05 * S.planet[p].radius_xy[c];
+                obs[o++] = (float)(-1 + 2 * (O.orbit_local[p][2 * (size_t)idx + c] - lo) / (hi - lo));
+            }
+        } else {
+            for (int c = 0; c < 3; ++c) {
+                double lo = S.planet_obs_pos_min[c], hi = S.planet_obs_pos_max[c];
+                obs[o++] = (float)(-1 + 2 * (O.orbit_pose[p][7 * (size_t)idx + c] - lo) / (hi - lo));
+            }
+        }
+    }
+    for (int i = 0; i < o; ++i) obs[i] = std::min(1.0f, std::max(-1.0f, obs[i]));
+}
+
+/* A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138 (gravity-torque check via one
+ * physics step omitted: kinematic restatement). */
+bool position_is_valid(const Oracle &O, const double q[SMR_NJ]) {
+    const smr_scene_t &S = O.S;
+    Xf link[SMR_NLINK];
+    forward_kinematics(S, q, link);
+    V3 ee = apply(link[SMR_NLINK - 1], {S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
+    double e[3] = {ee.x, ee.y, ee.z};
+    for (int c = 0; c < 3; ++c)
+        if (e[c] < S.start_box[c][0] || e[c] > S.start_box[c][1]) return false;          /* ctlp.py:2054-2061 */
+    Xf I = identity_xf();
+    for (int s = 0; s < S.n_static; ++s)                                                    /* ctlp.py:2140-2168 */
+        for (int k = 0; k < SMR_NLINK; ++k) {
+            if (!(S.static_link_mask & (1u << k))) continue;
+            double thr = S.start_min_dist_static;
+            double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], thr + 0.005);
+            if (d <= thr + 0.005 && d < thr) return false;
+        }
+    return true;
+}
+
+void sample_position(const Oracle &O, Rng &rng, double q[SMR_NJ]) {
+    for (int attempt = 0; attempt < 100000; ++attempt) {
+        for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(O.S.pos_lo[j], O.S.pos_hi[j]);   /* ctlp.py:2035-2037 */
+        if (position_is_valid(O, q)) return;
+    }
+}
+
+void reset_env(Oracle &O, int e) {
+    const smr_scene_t &S = O.S;
+    EnvState &st = O.st[e];
+    Rng rng = {O.seed, (uint32_t)e, st.rng_draws};
+    double q[SMR_NJ], v[SMR_NJ] = {0}, a[SMR_NJ] = {0};
+    sample_position(O, rng, q);
+    /* A17 part 2: get_starting_point_joint_pos_vel_acc, ctlp.py:1490-1654 */
+    if (S.kinematic_state_sampling_mode && rng.uniform01() < S.kinematic_state_sampling_probability) {
+        for (;;) {                                                                           /* ctlp.py:1499-1556 */
+            bool all_found = true;
+            for (int j = 0; j < SMR_NJ && all_found; ++j) {
+                bool found = false;
+                JointLim L = joint_lim(S, j);
+                for (int tv = 0; tv < 5 && !found; ++tv) {
+                    double vj = rng.uniform(-S.vel_max[j], S.vel_max[j]);
+                    for (int ta = 0; ta < 10 && !found; ++ta) {
+                        double aj = rng.uniform(-S.acc_max[j], S.acc_max[j]);
+                        double lo, hi;
+                        int code;
+                        safe_acc_range_joint(L, q[j], vj, aj, lo, hi, code);
+                        if (code == 0) { found = true; v[j] = vj; a[j] = aj; }
+                    }
+                }
+                if (!found) all_found = false;
+            }
+            if (all_found) break;
+            sample_position(O, rng, q);
+        }
+    } else {                                                                                  /* ctlp.py:1558-1654 */
+        double hq[3][SMR_NJ], hv[3][SMR_NJ], ha[3][SMR_NJ];   /* ring of the three latest states */
+        int count = 1;
+        std::memcpy(hq[0], q, sizeof q); std::memcpy(hv[0], v, sizeof v); std::memcpy(ha[0], a, sizeof a);
+        for (int walk = 0; walk < 64; ++walk) {
+            if (rng.uniform01() < S.stay_in_state_probability) break;
+            const double *cq = hq[(count - 1) % 3], *cv = hv[(count - 1) % 3], *ca = ha[(count - 1) % 3];
+            double nq[SMR_NJ], nv[SMR_NJ], na[SMR_NJ];
+            double lo[SMR_NJ], hi[SMR_NJ];
+            for (int j = 0; j < SMR_NJ; ++j) {
+                int code;
+                safe_acc_range_joint(joint_lim(S, j), cq[j], cv[j], ca[j], lo[j], hi[j], code);
+            }
+            for (int j = 0; j < SMR_NJ; ++j) {
+                double u = rng.uniform(-1.0, 1.0);
+                na[j] = lo[j] + 0.5 * (u + 1) * (hi[j] - lo[j]);
+                nv[j] = interp_vel(cv[j], ca[j], na[j], S.dt, S.dt);
+                nq[j] = interp_pos(cq[j], cv[j], ca[j], na[j], S.dt, S.dt);
+            }
+            /* end position collision free? (table + self only, ctlp.py:1605-1619) */
+            Xf link[SMR_NLINK];
+            forward_kinematics(S, nq, link);
+            bool free_pos = true;
+            Xf I = identity_xf();
+            for (int s = 0; s < S.n_static && free_pos; ++s)
+                for (int k = 0; k < SMR_NLINK; ++k) {
+                    if (!(S.static_link_mask & (1u << k))) continue;
+                    double thr = S.start_min_dist_static;
+                    double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], thr + 0.005);
+                    if (d <= thr + 0.005 && d < thr) { free_pos = false; break; }
+                }
+            if (free_pos) {
+                std::memcpy(hq[count % 3], nq, sizeof nq); std::memcpy(hv[count % 3], nv, sizeof nv);
+                std::memcpy(ha[count % 3], na, sizeof na);
+                ++count;
+            } else {
+                int sel = 1 + rng.randint(std::min(count, 3));       /* ctlp.py:1641-1646 */
+                count = count - sel + 1;
+                break;
+            }
+        }
+        std::memcpy(q, hq[(count - 1) % 3], sizeof q); std::memcpy(v, hv[(count - 1) % 3], sizeof v);
+        std::memcpy(a, ha[(count - 1) % 3], sizeof a);
+    }
+    std::memcpy(st.q, q, sizeof q); std::memcpy(st.v, v, sizeof v); std::memcpy(st.a, a, sizeof a);
+    st.step_count = 0;
+    st.moving_hit = 0;
+    st.planet_idx[0] = st.planet_idx[1] = 0;
+    if (S.n_planets > 0) {
+        /* Planet.reset: random phase until contact free, ctlp.py:4470-4501 */
+        Xf link[SMR_NLINK];
+        forward_kinematics(S, q, link);
+        int32_t idx[SMR_MAX_PLANETS] = {0, 0};
+        for (int attempt = 0; attempt < 100000; ++attempt) {
+            for (int p = 0; p < S.n_planets; ++p) {
+                if (S.planet[p].coupled) {
+                    int n = S.planet[p].n_orbit;
+                    idx[p] = ((idx[0] + S.planet[p].index_shift) % n + n) % n;
+                } else {
+                    idx[p] = rng.randint(S.planet[p].n_orbit);
+                }
+            }
+            if (!moving_contact(O, link, idx)) break;
+        }
+        /* obstacle_wrapper.update(update_after_reset=True): planets advance once and are checked,
+         * base.py:980-985, ctlp.py:2626-2637 */
+        for (int p = 0; p < S.n_planets; ++p) idx[p] = (idx[p] + 1) % S.planet[p].n_orbit;
+        if (S.terminate_on_moving_collision && moving_contact(O, link, idx)) st.moving_hit = 1;
+        for (int p = 0; p < S.n_planets; ++p) st.planet_idx[p] = idx[p];
+    }
+    st.rng_draws = rng.draws;
+}
+
+/* info columns written by step (mirrors the product's SMR_INFO_* layout) */
+enum { INFO_D_STATIC = 0, INFO_D_SELF, INFO_D_MOVING, INFO_ACTION_PUNISHMENT, INFO_R_SELF, INFO_R_STATIC,
+       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_N };
+
+/* A1/A2/A3/A11/A12/A13/A16: SafeMotionsBase.step + process_step_outcome for one env. */
+void step_env(Oracle &O, int e, const double *action, float *obs, double *reward, uint8_t *done,
+              int8_t *reason, double *info) {
+    const smr_scene_t &S = O.S;
+    EnvState &st = O.st[e];
+    st.step_count += 1;                                                     /* base.py:1044 */
+
+    /* A4 + A2: acceleration range of the current state, action -> end acceleration, actions.py:206-211,268-280 */
+    double a1[SMR_NJ];
+    for (int j = 0; j < SMR_NJ; ++j) {
+        double lo, hi;
+        int code;
+        safe_acc_range_joint(joint_lim(S, j), st.q[j], st.v[j], st.a[j], lo, hi, code);
+        a1[j] = lo + 0.5 * (action[j] + 1.0) * (hi - lo);
+    }
+
+    /* A11: moving-obstacle contact latch along the segment, ctlp.py:2626-2637 (N samples per step) */
+    int N = S.collision_checks_per_step;
+    int upd = S.updates_per_step / N;
+    Xf link[SMR_NLINK];
+    for (int k = 1; k <= N; ++k) {
+        double t = S.dt * k / N, qk[SMR_NJ];
+        for (int j = 0; j < SMR_NJ; ++j) qk[j] = interp_pos(st.q[j], st.v[j], st.a[j], a1[j], t, S.dt);
+        int32_t idx[SMR_MAX_PLANETS];
+        for (int p = 0; p < S.n_planets; ++p) idx[p] = (st.planet_idx[p] + k * upd) % S.planet[p].n_orbit;
+        if (k < N && (st.moving_hit || !S.terminate_on_moving_collision || S.n_planets == 0)) continue;
+        forward_kinematics(S, qk, link);
+        if (S.terminate_on_moving_collision && S.n_planets > 0 && !st.moving_hit && moving_contact(O, link, idx))
+            st.moving_hit = 1;
+    }
+
+    /* process_step_outcome: new start state = last setpoint, base.py:1179-1181 */
+    for (int j = 0; j < SMR_NJ; ++j) {
+        double p1 = interp_pos(st.q[j], st.v[j], st.a[j], a1[j], S.dt, S.dt);
+        double v1 = interp_vel(st.v[j], st.a[j], a1[j], S.dt, S.dt);
+        st.q[j] = p1; st.v[j] = v1; st.a[j] = a1[j];
+    }
+    for (int p = 0; p < S.n_planets; ++p)
+        st.planet_idx[p] = (st.planet_idx[p] + S.updates_per_step) % S.planet[p].n_orbit;
+
+    /* A12: _compute_collision_avoidance_reward, rewards.py:95-162 (link[] holds FK of the end setpoint) */
+    double d_static, d_self;
+    min_distance_static_self(O, link, d_static, d_self);
+    bool col_static = false, col_self = false, col_moving = false;
+    if (d_static < S.collision_distance) { d_static = 0; col_static = true; }
+    if (d_self < S.collision_distance) { d_self = 0; col_self = true; }
+    double r_self = 0, r_static = 0, r_moving = 0;
+    if (S.self_max_reward != 0) { double r = std::min(1.0, d_self / S.self_max_reward_distance); r_self = r * r; }
+    if (S.static_max_reward != 0) { double r = std::min(1.0, d_static / S.static_max_reward_distance); r_static = r * r; }
+    double d_moving;
+    if (st.moving_hit) d_moving = 0.0;                                       /* ctlp.py:3229-3234 */
+    else d_moving = (S.n_planets > 0) ? min_distance_moving(O, link, st.planet_idx) : S.moving_max_distance + 0.002;
+    if (d_moving < S.collision_distance) { d_moving = 0; col_moving = true; }
+    { double r = std::min(1.0, d_moving / S.moving_max_reward_distance); r_moving = r * r; }
+
+    /* A13: CollisionAvoidanceReward._get_reward, rewards.py:432-502 */
+    double action_punishment = 1.0;
+    if (S.punish_action) {                                                   /* rewards.py:18-21,164-169 */
+        double m = 0;
+        for (int j = 0; j < SMR_NJ; ++j) m = std::max(m, std::fabs(action[j]));
+        double pun = (m - S.action_punishment_min_threshold) / (1 - S.action_punishment_min_threshold);
+        pun = std::max(std::min(pun, 1.0), 0.0);
+        action_punishment = pun * pun;
+    }
+    double low_acc_reward = 0, low_vel_reward = 0;
+    if (S.low_acc_max_reward != 0) {
+        double m = 0;
+        for (int j = 0; j < SMR_NJ; ++j) m = std::max(m, std::fabs(st.a[j] / S.acc_max[j]));
+        double r = std::min(1.0, m / S.low_acc_threshold);
+        low_acc_reward = (r - 1) * (r - 1);
+    }
+    if (S.low_vel_max_reward != 0) {
+        double m = 0;
+        for (int j = 0; j < SMR_NJ; ++j) m = std::max(m, std::fabs(st.v[j] / S.vel_max[j]));
+        double r = std::min(1.0, m / S.low_vel_threshold);
+        low_vel_reward = (r - 1) * (r - 1);
+    }
+    bool terminating_collision = (S.terminate_on_self_collision && col_self) ||
+                                 (S.terminate_on_static_collision && col_static) ||
+                                 (S.terminate_on_moving_collision && col_moving);
+    bool finished = st.step_count >= S.episode_steps;                        /* tm.py:187-192 */
+    double bonus = (finished && !terminating_collision) ? S.termination_bonus : 0.0;
+    double punishment = terminating_collision ? S.early_termination_punishment : 0.0;
+    *reward = (1 - action_punishment) * S.action_max_punishment + r_self * S.self_max_reward +
+              r_static * S.static_max_reward + r_moving * S.moving_max_reward +
+              low_acc_reward * S.low_acc_max_reward + low_vel_reward * S.low_vel_max_reward + bonus + punishment;
+
+    /* A16: _check_termination, base.py:1775-1799 */
+    int r = SMR_TERMINATION_UNSET;
+    bool d = false;
+    if (S.terminate_on_self_collision && col_self) { d = true; r = SMR_TERMINATION_SELF_COLLISION; }
+    if (!d && S.terminate_on_static_collision && col_static) { d = true; r = SMR_TERMINATION_COLLISION_WITH_STATIC_OBSTACLE; }
+    if (!d && S.terminate_on_moving_collision && col_moving) { d = true; r = SMR_TERMINATION_COLLISION_WITH_MOVING_OBSTACLE; }
+    if (!d && finished) { d = true; r = SMR_TERMINATION_TRAJECTORY_LENGTH; }
+    *done = d ? 1 : 0;
+    *reason = (int8_t)r;
+    if (info) {
+        info[INFO_D_STATIC] = d_static; info[INFO_D_SELF] = d_self; info[INFO_D_MOVING] = d_moving;
+        info[INFO_ACTION_PUNISHMENT] = action_punishment; info[INFO_R_SELF] = r_self;
+        info[INFO_R_STATIC] = r_static; info[INFO_R_MOVING] = r_moving; info[INFO_EPISODE_LENGTH] = st.step_count;
+    }
+    if (d && S.auto_reset) reset_env(O, e);
+    observation(O, st, obs);
+}
+
+}  // namespace
+
+/* ------------------------------------------------------------------------------------------- *
+ * C entry points (ctypes; see oracle/oracle.py).  Host memory only.
+ * ------------------------------------------------------------------------------------------- */
+extern "C" {
+
+size_t smo_scene_sizeof(void) { return sizeof(smr_scene_t); }
+
+void *smo_create(const smr_scene_t *scene, int32_t num_envs, uint64_t seed, int32_t num_threads) {
+    if (!scene || scene->version != SMR_SCENE_VERSION || num_envs <= 0) return nullptr;
+    if (scene->collision_checks_per_step <= 0 || scene->updates_per_step % scene->collision_checks_per_step) return nullptr;
+    Oracle *O = new Oracle();
+    O->S = *scene;
+    O->verts.assign(scene->verts, scene->verts + 3 * (size_t)scene->n_verts);
+    O->pieces.assign(scene->pieces, scene->pieces + scene->n_pieces);
+    for (int p = 0; p < scene->n_planets; ++p) {
+        size_t n = (size_t)scene->planet[p].n_orbit;
+        O->orbit_pose[p].assign(scene->planet[p].orbit_pose, scene->planet[p].orbit_pose + 7 * n);
+        O->orbit_local[p].assign(scene->planet[p].orbit_local, scene->planet[p].orbit_local + 2 * n);
+    }
+    O->S.verts = nullptr; O->S.pieces = nullptr;
+    O->B = num_envs;
+    O->seed = seed;
+    O->num_threads = num_threads > 0 ? num_threads : 1;
+    O->st.assign(num_envs, EnvState());
+    for (auto &s : O->st) std::memset(&s, 0, sizeof s);
+    return O;
+}
+
+void smo_destroy(void *h) { delete (Oracle *)h; }
+
+/* mask: NULL = all envs */
+void smo_reset(void *h, const uint8_t *mask, float *obs) {
+    Oracle &O = *(Oracle *)h;
+    int os = O.S.obs_size;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(O.num_threads)
+    for (int e = 0; e < O.B; ++e) {
+        if (mask && !mask[e]) continue;
+        reset_env(O, e);
+        if (obs) observation(O, O.st[e], obs + (size_t)e * os);
+    }
+}
+
+void smo_observe(void *h, float *obs) {
+    Oracle &O = *(Oracle *)h;
+    for (int e = 0; e < O.B; ++e) observation(O, O.st[e], obs + (size_t)e * O.S.obs_size);
+}
+
+void smo_step(void *h, const double *actions, float *obs, double *reward, uint8_t *done, int8_t *reason, double *info) {
+    Oracle &O = *(Oracle *)h;
+    int os = O.S.obs_size;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(O.num_threads)
+    for (int e = 0; e < O.B; ++e)
+        step_env(O, e, actions + (size_t)e * SMR_NJ, obs + (size_t)e * os, reward + e, done + e, reason + e,
+                 info ? info + (size_t)e * INFO_N : nullptr);
+}
+
+void smo_get_state(void *h, double *q, double *v, double *a, int32_t *planet_idx, int32_t *step_count,
+                   int32_t *moving_hit, uint32_t *rng_draws) {
+    Oracle &O = *(Oracle *)h;
+    for (int e = 0; e < O.B; ++e) {
+        const EnvState &s = O.st[e];
+        for (int j = 0; j < SMR_NJ; ++j) {
+            if (q) q[e * SMR_NJ + j] = s.q[j];
+            if (v) v[e * SMR_NJ + j] = s.v[j];
+            if (a) a[e * SMR_NJ + j] = s.a[j];
+        }
+        if (planet_idx) for (int p = 0; p < SMR_MAX_PLANETS; ++p) planet_idx[e * SMR_MAX_PLANETS + p] = s.planet_idx[p];
+        if (step_count) step_count[e] = s.step_count;
+        if (moving_hit) moving_hit[e] = s.moving_hit;
+        if (rng_draws) rng_draws[e] = s.rng_draws;
+    }
+}
+
+void smo_set_state(void *h, const double *q, const double *v, const double *a, const int32_t *planet_idx,
+                   const int32_t *step_count, const int32_t *moving_hit, const uint32_t *rng_draws) {
+    Oracle &O = *(Oracle *)h;
+    for (int e = 0; e < O.B; ++e) {
+        EnvState &s = O.st[e];
+        for (int j = 0; j < SMR_NJ; ++j) {
+            if (q) s.q[j] = q[e * SMR_NJ + j];
+            if (v) s.v[j] = v[e * SMR_NJ + j];
+            if (a) s.a[j] = a[e * SMR_NJ + j];
+        }
+        if (planet_idx) for (int p = 0; p < SMR_MAX_PLANETS; ++p) s.planet_idx[p] = planet_idx[e * SMR_MAX_PLANETS + p];
+        if (step_count) s.step_count = step_count[e];
+        if (moving_hit) s.moving_hit = moving_hit[e];
+        if (rng_draws) s.rng_draws = rng_draws[e];
+    }
+}
+
+/* ---- component entry points for unit tests ---- */
+
+void smo_fk(void *h, const double *q, double *pos_out /*8x3*/, double *rot_out /*8x9*/) {
+    Oracle &O = *(Oracle *)h;
+    Xf link[SMR_NLINK];
+    forward_kinematics(O.S, q, link);
+    for (int k = 0; k < SMR_NLINK; ++k) {
+        pos_out[3 * k] = link[k].t.x; pos_out[3 * k + 1] = link[k].t.y; pos_out[3 * k + 2] = link[k].t.z;
+        std::memcpy(rot_out + 9 * k, link[k].R, sizeof link[k].R);
+    }
+}
+
+void smo_safe_acc_range(void *h, const double *p, const double *v, const double *a, double *lo, double *hi, int32_t *code) {
+    Oracle &O = *(Oracle *)h;
+    for (int j = 0; j < SMR_NJ; ++j) {
+        int c;
+        safe_acc_range_joint(joint_lim(O.S, j), p[j], v[j], a[j], lo[j], hi[j], c);
+        code[j] = c;
+    }
+}
+
+/* single-joint variant with explicit limits (tests sweep jerk factors) */
+void smo_safe_acc_range_joint(double plo, double phi, double V, double A, double J, double dt, double p, double v,
+                              double a, double *lo, double *hi, int32_t *code) {
+    int c;
+    safe_acc_range_joint({plo, phi, V, A, J, dt}, p, v, a, *lo, *hi, c);
+    *code = c;
+}
+
+/* distance between two vertex clouds under rigid transforms (R row-major 3x3, t) */
+double smo_gjk(const double *va, int32_t na, const double *Ra, const double *ta, const double *vb, int32_t nb,
+               const double *Rb, const double *tb, double cutoff) {
+    Hull A = {va, na, identity_xf()}, B = {vb, nb, identity_xf()};
+    std::memcpy(A.X.R, Ra, 9 * sizeof(double)); A.X.t = {ta[0], ta[1], ta[2]};
+    std::memcpy(B.X.R, Rb, 9 * sizeof(double)); B.X.t = {tb[0], tb[1], tb[2]};
+    return gjk_distance(A, B, cutoff);
+}
+
+/* distances of one configuration: out = {d_static, d_self, d_moving (no latch), contact flag} */
+void smo_distances(void *h, const double *q, const int32_t *planet_idx, double *out) {
+    Oracle &O = *(Oracle *)h;
+    Xf link[SMR_NLINK];
+    forward_kinematics(O.S, q, link);
+    min_distance_static_self(O, link, out[0], out[1]);
+    out[2] = O.S.n_planets > 0 ? min_distance_moving(O, link, planet_idx) : O.S.moving_max_distance + 0.002;
+    out[3] = (O.S.n_planets > 0 && moving_contact(O, link, planet_idx)) ? 1.0 : 0.0;
+}
+
+/* exact (cutoff-free) distance between link k and piece `piece` of planet p at orbit index idx */
+double smo_link_planet_piece_distance(void *h, const double *q, int32_t k, int32_t p, int32_t piece, int32_t idx) {
+    Oracle &O = *(Oracle *)h;
+    Xf link[SMR_NLINK];
+    forward_kinematics(O.S, q, link);
+    return piece_distance(O, O.S.planet[p].piece_begin + piece, planet_pose(O, p, idx), O.S.link_piece[k], link[k], 1e30);
+}
+
+int32_t smo_position_is_valid(void *h, const double *q) { return position_is_valid(*(Oracle *)h, q) ? 1 : 0; }
+
+void smo_count_work(int32_t enable) { g_count_work = enable != 0; g_support_calls = 0; }
+int64_t smo_support_vertex_visits(void) { return g_support_calls; }
+
+uint32_t smo_philox_word(uint64_t seed, uint32_t env, uint32_t draw) {
+    Rng r = {seed, env, draw};
+    return r.next_u32();
+}
+
+}  // extern "C"

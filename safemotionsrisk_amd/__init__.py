@@ -1,0 +1,8 @@
+"""safemotionsrisk_amd - MI355X-native batched hot path of translearn/safeMotionsRisk.
+
+Host mirror of the reference's env surface over a C-ABI library of HIP kernels (gfx950):
+``VecSafeMotionsEnv`` (env.py), scene construction from ``env_config`` (scene.py), the ctypes binding
+(lib.py), rollout sharding over the GPUs of a node (dist.py).
+"""
+from .scene import SPACE_ENV_CONFIG, BALL_ENV_CONFIG, build_scene  # noqa: F401
+from .env import VecSafeMotionsEnv, SafeMotionsEnvCollisionAvoidance  # noqa: F401

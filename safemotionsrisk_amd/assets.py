@@ -1,0 +1,206 @@
+"""Asset compiler: reference URDF + collision meshes -> small committed geometry tables.
+
+Build-time tool (runs where a checkout of the reference is mounted):
+
+    python -m safemotionsrisk_amd.assets /root/reference
+
+It parses the *data files* of the reference (no reference Python is imported or executed):
+
+* ``safemotions/description/urdf/robot.urdf``  -> kinematic chain (joint origins, axes, limits)
+* ``safemotions/description/meshes/iiwa7/collision/*.stl`` -> one convex hull per robot link
+* ``safemotions/description/urdf/obstacles/{table,ISS,asteroid,basketball_red}.urdf`` and
+  ``meshes/obstacles/collision/{ISS,asteroid,basketball}.obj`` -> obstacle convex pieces
+
+and writes ``safemotionsrisk_amd/data/iiwa7_assets.npz``.  That file is data (vertex coordinates and
+URDF numbers), it is what travels to the GPU box, and `scene.py` builds the device tables from it.
+
+Geometry model (the one PyBullet 3.1.6 builds from these files, see DESIGN.md "geometry model"):
+every mesh collision element becomes the convex hull of its vertices (one hull per ``o`` group of
+an OBJ, i.e. the ISS is a compound of 24 hulls; `ctlp.py:727-776` loads ISS at globalScaling 0.6,
+the asteroid at 1.0, `ctlp.py:4043-4051` the ball at radius/0.12), a URDF ``<box>`` becomes a box;
+every shape carries Bullet's URDF collision margin of 1 mm.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+URDF_COLLISION_MARGIN = 0.001  # Bullet: gUrdfDefaultCollisionMargin
+
+ROBOT_LINK_NAMES = ["iiwa_link_0", "iiwa_link_1", "iiwa_link_2", "iiwa_link_3",
+                    "iiwa_link_4", "iiwa_link_5", "iiwa_link_6", "iiwa_link_7"]
+
+
+def rpy_to_matrix(rpy):
+    """URDF fixed-axis roll/pitch/yaw -> rotation matrix R = Rz(y) Ry(p) Rx(r)."""
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return rz @ ry @ rx
+
+
+def load_stl_vertices(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    n = struct.unpack("<I", data[80:84])[0]
+    if len(data) != 84 + 50 * n:
+        raise ValueError("%s is not a binary STL" % path)
+    rec = np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")])
+    tris = np.frombuffer(data[84:], dtype=rec)
+    return tris["v"].reshape(-1, 3).astype(np.float64)
+
+
+def load_obj_groups(path):
+    """Vertices of an OBJ split by ``o``/``g`` statements (tinyobj 'shapes')."""
+    groups, cur = [], None
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] in ("o", "g"):
+                cur = []
+                groups.append(cur)
+            elif t[0] == "v":
+                if cur is None:
+                    cur = []
+                    groups.append(cur)
+                cur.append([float(x) for x in t[1:4]])
+    return [np.asarray(g, dtype=np.float64) for g in groups if len(g)]
+
+
+def hull_vertices(points):
+    """Extreme points of a point cloud (support function is unchanged by dropping the rest)."""
+    from scipy.spatial import ConvexHull
+    pts = np.unique(np.asarray(points, dtype=np.float64), axis=0)
+    if len(pts) <= 4:
+        return pts
+    hull = ConvexHull(pts)
+    return pts[np.sort(hull.vertices)]
+
+
+def _floats(s):
+    return [float(x) for x in s.split()]
+
+
+def parse_robot_urdf(path):
+    root = ET.parse(path).getroot()
+    joints = {j.get("name"): j for j in root.findall("joint")}
+    links = {l.get("name"): l for l in root.findall("link")}
+    child_to_joint = {j.find("child").get("link"): j for j in joints.values()}
+
+    # world -> iiwa_link_0 is a chain of fixed joints
+    base_xyz = np.zeros(3)
+    name = "iiwa_link_0"
+    while name != "world":
+        j = child_to_joint[name]
+        assert j.get("type") == "fixed"
+        o = j.find("origin")
+        assert np.allclose(_floats(o.get("rpy")), 0.0)
+        base_xyz += np.array(_floats(o.get("xyz")))
+        name = j.find("parent").get("link")
+
+    joint_xyz, joint_axis, lower, upper, vel, effort = [], [], [], [], [], []
+    for i in range(1, 8):
+        j = joints["iiwa_joint_%d" % i]
+        assert j.get("type") == "revolute"
+        assert j.find("parent").get("link") == "iiwa_link_%d" % (i - 1)
+        o = j.find("origin")
+        assert np.allclose(_floats(o.get("rpy")), 0.0)
+        joint_xyz.append(_floats(o.get("xyz")))
+        joint_axis.append(_floats(j.find("axis").get("xyz")))
+        lim = j.find("limit")
+        lower.append(float(lim.get("lower")))
+        upper.append(float(lim.get("upper")))
+        vel.append(float(lim.get("velocity")))
+        effort.append(float(lim.get("effort")))
+
+    meshes = {}
+    for lname in ROBOT_LINK_NAMES:
+        col = links[lname].find("collision")
+        assert col.find("origin") is None
+        meshes[lname] = col.find("geometry").find("mesh").get("filename")
+    return dict(base_xyz=base_xyz, joint_xyz=np.array(joint_xyz), joint_axis=np.array(joint_axis),
+                lower=np.array(lower), upper=np.array(upper), velocity=np.array(vel),
+                effort=np.array(effort), meshes=meshes)
+
+
+def parse_obstacle_urdf(path):
+    """Single-link obstacle URDF -> (geometry kind, params, origin xyz, origin rpy)."""
+    root = ET.parse(path).getroot()
+    col = root.find("link").find("collision")
+    o = col.find("origin")
+    xyz = np.array(_floats(o.get("xyz"))) if o is not None else np.zeros(3)
+    rpy = np.array(_floats(o.get("rpy"))) if o is not None else np.zeros(3)
+    geom = col.find("geometry")
+    if geom.find("box") is not None:
+        return "box", np.array(_floats(geom.find("box").get("size"))), xyz, rpy
+    mesh = geom.find("mesh")
+    scale = np.array(_floats(mesh.get("scale"))) if mesh.get("scale") else np.ones(3)
+    return "mesh", (mesh.get("filename"), scale), xyz, rpy
+
+
+def _resolve(ref_root, package_uri):
+    assert package_uri.startswith("package://")
+    return os.path.join(ref_root, package_uri[len("package://"):])
+
+
+def compile_assets(ref_root):
+    urdf_dir = os.path.join(ref_root, "safemotions", "description", "urdf")
+    out = {}
+
+    robot = parse_robot_urdf(os.path.join(urdf_dir, "robot.urdf"))
+    for k in ("base_xyz", "joint_xyz", "joint_axis", "lower", "upper", "velocity", "effort"):
+        out["robot_" + k] = robot[k]
+
+    verts, offsets = [], [0]
+    for lname in ROBOT_LINK_NAMES:
+        hv = hull_vertices(load_stl_vertices(_resolve(ref_root, robot["meshes"][lname])))
+        verts.append(hv)
+        offsets.append(offsets[-1] + len(hv))
+    out["link_verts"] = np.concatenate(verts)
+    out["link_offsets"] = np.array(offsets, dtype=np.int32)
+
+    # table: <box> in the obstacle's base frame
+    kind, size, xyz, rpy = parse_obstacle_urdf(os.path.join(urdf_dir, "obstacles", "table.urdf"))
+    assert kind == "box" and np.allclose(rpy, 0)
+    out["table_box_size"] = size
+    out["table_box_center"] = xyz
+
+    def mesh_obstacle(urdf_name):
+        kind, (fname, scale), xyz, rpy = parse_obstacle_urdf(
+            os.path.join(urdf_dir, "obstacles", urdf_name + ".urdf"))
+        assert kind == "mesh"
+        rot = rpy_to_matrix(rpy)
+        groups = load_obj_groups(_resolve(ref_root, fname))
+        # vertices in the *unscaled* body frame: R * (scale * v) + xyz; globalScaling multiplies all of it
+        pieces = [hull_vertices((g * scale) @ rot.T + xyz) for g in groups]
+        offs = np.cumsum([0] + [len(p) for p in pieces]).astype(np.int32)
+        return np.concatenate(pieces), offs
+
+    for key, urdf_name in (("iss", "ISS"), ("asteroid", "asteroid"), ("ball", "basketball_red")):
+        v, offs = mesh_obstacle(urdf_name)
+        out[key + "_verts"] = v
+        out[key + "_offsets"] = offs
+
+    out["urdf_collision_margin"] = np.array(URDF_COLLISION_MARGIN)
+    return out
+
+
+def main(argv):
+    ref_root = argv[1] if len(argv) > 1 else "/root/reference"
+    out = compile_assets(ref_root)
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "iiwa7_assets.npz")
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main(sys.argv)

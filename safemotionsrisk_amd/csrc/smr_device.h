@@ -1,0 +1,517 @@
+// smr_device.h - device-side tables and device functions of libsmr_hip.so (gfx950 / CDNA4 only).
+//
+// One environment per wavefront lane.  Everything that is shared by the whole batch (limits, chain,
+// hull vertices, piece table, planet orbit tables) lives in read-only device memory and is indexed
+// with wave-uniform indices, so the compiler fetches it with scalar loads (s_load_dwordx4/x8) into
+// SGPRs and the inner loops are pure VALU on per-lane registers; per-env state is SoA in HBM.
+//
+// Reference short names as in include/smr_scene.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/safemotions_hip.h"
+
+namespace smr {
+
+// Batch-shared read-only tables are read through the constant address space: with a wave-uniform
+// index the compiler then emits s_load_* (scalar cache -> SGPRs) instead of per-lane flat loads.
+// (A pointer fetched from a struct is a generic pointer, and LLVM treats generic loads as divergent.)
+#define SMR_CONST __attribute__((address_space(4)))
+#define SMR_GLOBAL __attribute__((address_space(1)))
+
+// ---------------------------------------------------------------------------------------------
+// tables (float32 images of smr_scene_t, built by smr_create)
+// ---------------------------------------------------------------------------------------------
+struct DPiece {
+    int begin, count;
+    float cx, cy, cz, radius;   // bounding sphere of the hull, piece frame
+    float margin;
+    float hx, hy, hz;           // half extents of the hull's AABB about (cx,cy,cz), piece frame
+};
+
+struct DPlanet {
+    int piece_begin, piece_count, n_orbit, index_shift, coupled;
+    float radius_x, radius_y;
+    const float *orbit_pose;    // [n_orbit][8]: pos xyz, quat xyzw, pad
+    const float *orbit_local;   // [n_orbit][2]
+};
+
+struct DScene {
+    int B, obs_size, episode_steps, updates_per_step, checks_per_step, auto_reset;
+    float dt;
+    float pos_lo[SMR_NJ], pos_hi[SMR_NJ], vel_max[SMR_NJ], acc_max[SMR_NJ], jerk_max[SMR_NJ];
+    float base[3], joint_xyz[SMR_NJ][3], joint_axis[SMR_NJ][3], ee_offset[3];
+    const float4 *verts;
+    const DPiece *pieces;
+    int link_piece[SMR_NLINK];
+    int n_static, static_piece[SMR_MAX_STATIC];
+    unsigned static_mask;
+    float static_max;
+    unsigned moving_mask, contact_mask;
+    float moving_max, contact_dist;
+    int n_planets, obs_planet_size, obs_num_planets;
+    DPlanet planet[SMR_MAX_PLANETS];
+    float planet_obs_min[3], planet_obs_max[3];
+    int punish_action, term_self, term_static, term_moving;
+    float action_thr, action_max_pun;
+    float self_max_reward, self_max_dist, static_max_reward, static_max_dist, moving_max_reward, moving_max_dist;
+    float low_acc_reward, low_acc_thr, low_vel_reward, low_vel_thr;
+    float term_bonus, early_term_pun, collision_dist;
+    float start_box[3][2];
+    float start_min_static, start_min_self;
+    int kin_mode;
+    float kin_prob, stay_prob;
+    unsigned seed_lo, seed_hi;
+};
+
+// per-env state, struct of arrays ([component][B]) so that lane e of a wave reads consecutive words
+struct DState {
+    float *q, *v, *a;          // [7][B]
+    int *planet_idx;           // [2][B]
+    int *step_count;           // [B]
+    int *moving_hit;           // [B]
+    unsigned *rng_draws;       // [B]
+    float *a1;                 // [7][B]   plan -> collide/finish
+    float *res;                // [N][4][B] collide -> finish: contact, d_static, d_moving, -
+    int *done_list;            // [B]
+    int *done_count;           // [1]
+};
+
+// ---------------------------------------------------------------------------------------------
+// small vector algebra
+// ---------------------------------------------------------------------------------------------
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ F3 cross(F3 a, F3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ F3 neg(F3 a) { return {-a.x, -a.y, -a.z}; }
+
+struct Xf { float r[9]; F3 t; };   // x_world = R x_body + t, R row-major
+
+__device__ __forceinline__ F3 rot(const Xf &X, F3 v) {
+    return {fmaf(X.r[2], v.z, fmaf(X.r[1], v.y, X.r[0] * v.x)), fmaf(X.r[5], v.z, fmaf(X.r[4], v.y, X.r[3] * v.x)),
+            fmaf(X.r[8], v.z, fmaf(X.r[7], v.y, X.r[6] * v.x))};
+}
+__device__ __forceinline__ F3 rot_t(const Xf &X, F3 v) {
+    return {fmaf(X.r[6], v.z, fmaf(X.r[3], v.y, X.r[0] * v.x)), fmaf(X.r[7], v.z, fmaf(X.r[4], v.y, X.r[1] * v.x)),
+            fmaf(X.r[8], v.z, fmaf(X.r[5], v.y, X.r[2] * v.x))};
+}
+__device__ __forceinline__ F3 apply(const Xf &X, F3 v) { return rot(X, v) + X.t; }
+
+// ---------------------------------------------------------------------------------------------
+// RNG: Philox4x32-10, counter = (draw >> 2, env, 0, 0), key = seed; draw d uses word d & 3.
+// 24-bit uniforms are exact in float32.  (Reference: numpy global RNG, base.py:1704-1710.)
+// ---------------------------------------------------------------------------------------------
+struct Rng {
+    unsigned k0, k1, env, draws;
+    __device__ unsigned next_u32() {
+        unsigned c0 = draws >> 2, c1 = env, c2 = 0u, c3 = 0u, a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            unsigned n0 = hi1 ^ c1 ^ a, n2 = hi0 ^ c3 ^ b;
+            c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+            a += 0x9E3779B9u; b += 0xBB67AE85u;
+        }
+        unsigned sel = draws & 3u;
+        ++draws;
+        return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
+    }
+    __device__ float uniform01() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+    __device__ float uniform(float lo, float hi) { return fmaf(uniform01(), hi - lo, lo); }
+    __device__ int randint(int n) { return (int)(((unsigned long long)(next_u32() >> 8) * (unsigned long long)n) >> 24); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// A3: constant-jerk segment (actions.py:468-487)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float interp_pos(float p0, float v0, float a0, float a1, float t, float dt) {
+    return p0 + v0 * t + 0.5f * a0 * t * t + (1.0f / 6.0f) * ((a1 - a0) / dt) * t * t * t;
+}
+__device__ __forceinline__ float interp_vel(float v0, float a0, float a1, float t, float dt) {
+    return v0 + a0 * t + 0.5f * ((a1 - a0) / dt) * t * t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A4: safe acceleration range (klimits call sites actions.py:97-106,206-211).  Exact discrete-time
+// viability test per limit + bisection; see DESIGN.md "safe acceleration range".
+// ---------------------------------------------------------------------------------------------
+struct JointLim { float plo, phi, V, A, J, dt; };
+
+__device__ __forceinline__ float seg_vmax(float v0, float a0, float a1, float dt) {
+    float m = v0 + 0.5f * (a0 + a1) * dt;
+    if (a0 > 0.f && a1 < 0.f) m = fmaxf(m, v0 + 0.5f * a0 * (dt * a0 / (a0 - a1)));
+    return m;
+}
+
+__device__ __forceinline__ float seg_pmax(float p0, float v0, float a0, float a1, float dt) {
+    float m = interp_pos(p0, v0, a0, a1, dt, dt);
+    float j = (a1 - a0) / dt;
+    float disc = a0 * a0 - 2.0f * j * v0;
+    if (disc >= 0.f) {
+        float sq = sqrtf(disc);
+        float qq = -(a0 + (a0 >= 0.f ? sq : -sq));
+        float r0 = qq / j, r1 = 2.0f * v0 / qq;      // inf/nan when a divisor is 0: rejected by the range test
+        if (r0 > 0.f && r0 < dt) m = fmaxf(m, interp_pos(p0, v0, a0, a1, r0, dt));
+        if (r1 > 0.f && r1 < dt) m = fmaxf(m, interp_pos(p0, v0, a0, a1, r1, dt));
+    }
+    return m;
+}
+
+__device__ inline bool vel_upper_ok(float v0, float a0, float a1, float Vlim, const JointLim &L) {
+    if (seg_vmax(v0, a0, a1, L.dt) > Vlim) return false;
+    float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
+    for (int it = 0; it < 4096; ++it) {
+        if (a <= 0.f) return true;
+        float an = fmaxf(a - D, -L.A);
+        if (seg_vmax(v, a, an, L.dt) > Vlim) return false;
+        v += 0.5f * (a + an) * L.dt;
+        a = an;
+    }
+    return false;
+}
+
+__device__ inline bool pos_upper_ok(float p0, float v0, float a0, float a1, float Plim, const JointLim &L) {
+    if (seg_pmax(p0, v0, a0, a1, L.dt) > Plim) return false;
+    float p = interp_pos(p0, v0, a0, a1, L.dt, L.dt);
+    float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
+    for (int it = 0; it < 4096; ++it) {
+        if (v <= 0.f && a <= 0.f) return true;
+        float an = fmaxf(a - D, -L.A);
+        if (seg_pmax(p, v, a, an, L.dt) > Plim) return false;
+        p = interp_pos(p, v, a, an, L.dt, L.dt);
+        v += 0.5f * (a + an) * L.dt;
+        a = an;
+    }
+    return false;
+}
+
+constexpr int kBisectIters = 30;
+
+// largest a1 in [lo, hi] accepted by the (monotone) predicate; POS selects the position test
+template <bool POS>
+__device__ inline float upper_end(float p, float v, float a, float lim, const JointLim &L, float lo, float hi, bool &violated) {
+    violated = false;
+    bool ok_hi = POS ? pos_upper_ok(p, v, a, hi, lim, L) : vel_upper_ok(v, a, hi, lim, L);
+    if (ok_hi) return hi;
+    bool ok_lo = POS ? pos_upper_ok(p, v, a, lo, lim, L) : vel_upper_ok(v, a, lo, lim, L);
+    if (!ok_lo) { violated = true; return lo; }
+    for (int it = 0; it < kBisectIters; ++it) {
+        float mid = 0.5f * (lo + hi);
+        bool ok = POS ? pos_upper_ok(p, v, a, mid, lim, L) : vel_upper_ok(v, a, mid, lim, L);
+        if (ok) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v, float a, float &lo, float &hi, int &code) {
+    const float D = L.J * L.dt;
+    float blo = fmaxf(-L.A, a - D), bhi = fminf(L.A, a + D);
+    if (blo > bhi) blo = bhi = fminf(fmaxf(a, -L.A), L.A);
+    const float Vlim = L.V * (1.0f + 1e-5f);
+    const float ptol = 1e-6f * (L.phi - L.plo);
+    bool viol;
+    code = 0;
+    float uv = upper_end<false>(0.f, v, a, Vlim, L, blo, bhi, viol);
+    if (viol) code |= 1;
+    float up = upper_end<true>(p, v, a, L.phi + ptol, L, blo, bhi, viol);
+    if (viol) code |= 2;
+    float lv = -upper_end<false>(0.f, -v, -a, Vlim, L, -bhi, -blo, viol);
+    if (viol) code |= 1;
+    float lp = -upper_end<true>(-p, -v, -a, -L.plo + ptol, L, -bhi, -blo, viol);
+    if (viol) code |= 2;
+    hi = fminf(uv, up);
+    lo = fmaxf(lv, lp);
+    if (lo > hi) {
+        code |= 4;
+        float mid = 0.5f * (lo + hi);
+        lo = hi = fminf(fmaxf(mid, blo), bhi);
+    }
+}
+
+__device__ __forceinline__ JointLim joint_lim(const DScene &S, int j) {
+    return {S.pos_lo[j], S.pos_hi[j], S.vel_max[j], S.acc_max[j], S.jerk_max[j], S.dt};
+}
+
+// ---------------------------------------------------------------------------------------------
+// A6: forward kinematics, one joint at a time (robot.urdf chain; ctlp.py:5163-5195)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Xf fk_base(const DScene &S) {
+    Xf T;
+    T.r[0] = 1.f; T.r[1] = 0.f; T.r[2] = 0.f; T.r[3] = 0.f; T.r[4] = 1.f; T.r[5] = 0.f; T.r[6] = 0.f; T.r[7] = 0.f; T.r[8] = 1.f;
+    T.t = {S.base[0], S.base[1], S.base[2]};
+    return T;
+}
+
+// T <- T * Trans(joint_xyz[k]) * Rot(joint_axis[k], qk): frame of iiwa_link_(k+1)
+__device__ __forceinline__ void fk_advance(const DScene &S, int k, float qk, Xf &T) {
+    T.t = apply(T, F3{S.joint_xyz[k][0], S.joint_xyz[k][1], S.joint_xyz[k][2]});
+    float ax = S.joint_axis[k][0], ay = S.joint_axis[k][1], az = S.joint_axis[k][2];
+    float s, c;
+    sincosf(qk, &s, &c);
+    float C = 1.f - c;
+    float j0 = c + ax * ax * C, j1 = ax * ay * C - az * s, j2 = ax * az * C + ay * s;
+    float j3 = ay * ax * C + az * s, j4 = c + ay * ay * C, j5 = ay * az * C - ax * s;
+    float j6 = az * ax * C - ay * s, j7 = az * ay * C + ax * s, j8 = c + az * az * C;
+    float n[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float r0 = T.r[3 * i], r1 = T.r[3 * i + 1], r2 = T.r[3 * i + 2];
+        n[3 * i] = r0 * j0 + r1 * j3 + r2 * j6;
+        n[3 * i + 1] = r0 * j1 + r1 * j4 + r2 * j7;
+        n[3 * i + 2] = r0 * j2 + r1 * j5 + r2 * j8;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T.r[i] = n[i];
+}
+
+__device__ __forceinline__ Xf quat_pose(const SMR_GLOBAL float *row) {   // row: pos xyz, quat xyzw
+    float x = row[3], y = row[4], z = row[5], w = row[6];
+    float n = x * x + y * y + z * z + w * w;
+    float s = n > 0.f ? 2.0f / n : 0.f;
+    Xf X;
+    X.r[0] = 1.f - s * (y * y + z * z); X.r[1] = s * (x * y - z * w);       X.r[2] = s * (x * z + y * w);
+    X.r[3] = s * (x * y + z * w);       X.r[4] = 1.f - s * (x * x + z * z); X.r[5] = s * (y * z - x * w);
+    X.r[6] = s * (x * z - y * w);       X.r[7] = s * (y * z + x * w);       X.r[8] = 1.f - s * (x * x + y * y);
+    X.t = {row[0], row[1], row[2]};
+    return X;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GJK distance between two convex vertex sets (the algorithm behind pybullet.getClosestPoints for
+// convex hulls).  Support mapping: a linear scan with the vertex in SGPRs (uniform index -> scalar
+// load) and the search direction per lane.  Sub-simplex selection: closest-point-on-segment /
+// triangle / tetrahedron region tests (Ericson, Real-Time Collision Detection, 5.1).
+// ---------------------------------------------------------------------------------------------
+template <bool IDENTITY>
+__device__ __forceinline__ F3 support(const SMR_CONST float4 *verts, int begin, int count, const Xf &X, F3 d) {
+    F3 dl = IDENTITY ? d : rot_t(X, d);
+    float best = -3.0e38f;
+    int bi = 0;
+    begin = __builtin_amdgcn_readfirstlane(begin);      // wave-uniform by construction (piece index is uniform)
+    count = __builtin_amdgcn_readfirstlane(count);
+#pragma unroll 4
+    for (int i = 0; i < count; ++i) {
+        float4 p = verts[begin + i];
+        float s = fmaf(p.z, dl.z, fmaf(p.y, dl.y, p.x * dl.x));
+        bool gt = s > best;
+        best = gt ? s : best;
+        bi = gt ? i : bi;
+    }
+    float4 p = verts[begin + bi];
+    F3 pl = {p.x, p.y, p.z};
+    return IDENTITY ? pl : apply(X, pl);
+}
+
+// closest point of triangle (a,b,c) to the origin; mask: bit0 a, bit1 b, bit2 c support it
+__device__ __forceinline__ F3 tri_closest(F3 a, F3 b, F3 c, int &mask) {
+    F3 ab = b - a, ac = c - a;
+    float d1 = -dot(ab, a), d2 = -dot(ac, a);
+    if (d1 <= 0.f && d2 <= 0.f) { mask = 1; return a; }
+    float d3 = -dot(ab, b), d4 = -dot(ac, b);
+    if (d3 >= 0.f && d4 <= d3) { mask = 2; return b; }
+    float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { mask = 3; return a + (d1 / (d1 - d3)) * ab; }
+    float d5 = -dot(ab, c), d6 = -dot(ac, c);
+    if (d6 >= 0.f && d5 <= d6) { mask = 4; return c; }
+    float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { mask = 5; return a + (d2 / (d2 - d6)) * ac; }
+    float va = d3 * d6 - d5 * d4;
+    if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { mask = 6; return b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b); }
+    float denom = 1.0f / (va + vb + vc);
+    mask = 7;
+    return a + (vb * denom) * ab + (vc * denom) * ac;
+}
+
+__device__ __forceinline__ F3 pick_lowest(int m, F3 a, F3 b, F3 c, F3 d) { return (m & 1) ? a : (m & 2) ? b : (m & 4) ? c : d; }
+
+// Closest point of the simplex {w0..w(n-1)} to the origin; the simplex is reduced to the vertices
+// supporting it.  Returns true when the origin is enclosed (n == 4 and inside).
+__device__ inline bool simplex_solve(F3 &w0, F3 &w1, F3 &w2, F3 &w3, int &n, F3 &v) {
+    int mask;
+    if (n == 1) { v = w0; return false; }
+    if (n == 2) {
+        F3 ab = w1 - w0;
+        float t = -dot(w0, ab), den = dot(ab, ab);
+        if (t <= 0.f) { mask = 1; v = w0; }
+        else if (t >= den) { mask = 2; v = w1; }
+        else { mask = 3; v = w0 + (t / den) * ab; }
+    } else if (n == 3) {
+        v = tri_closest(w0, w1, w2, mask);
+    } else {
+        // faces (vertex bits): abc|d, acd|b, adb|c, bdc|a
+        float best = 3.0e38f;
+        mask = 15;
+        F3 bv = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            F3 p = f == 3 ? w1 : w0;
+            F3 q = f == 0 ? w1 : f == 1 ? w2 : w3;
+            F3 r = f == 0 ? w2 : f == 1 ? w3 : f == 2 ? w1 : w2;
+            F3 o = f == 0 ? w3 : f == 1 ? w1 : f == 2 ? w2 : w0;
+            F3 nrm = cross(q - p, r - p);
+            float sp = -dot(p, nrm), so = dot(o - p, nrm);
+            bool outside = (sp * so < 0.f) || (fabsf(so) <= 1e-12f);
+            if (outside) {
+                int m3;
+                F3 pt = tri_closest(p, q, r, m3);
+                float d2 = dot(pt, pt);
+                if (d2 < best) {
+                    best = d2;
+                    bv = pt;
+                    int bp = f == 3 ? 2 : 1, bq = f == 0 ? 2 : f == 1 ? 4 : 8, br = f == 0 ? 4 : f == 1 ? 8 : f == 2 ? 2 : 4;
+                    mask = ((m3 & 1) ? bp : 0) | ((m3 & 2) ? bq : 0) | ((m3 & 4) ? br : 0);
+                }
+            }
+        }
+        if (mask == 15) return true;
+        v = bv;
+    }
+    int m = mask;
+    F3 n0 = pick_lowest(m, w0, w1, w2, w3);
+    m &= m - 1;
+    F3 n1 = pick_lowest(m, w0, w1, w2, w3);
+    m &= m - 1;
+    F3 n2 = pick_lowest(m, w0, w1, w2, w3);
+    w0 = n0; w1 = n1; w2 = n2;
+    n = __popc(mask);
+    return false;
+}
+
+// Distance between hull A (piece pa under XA; IDENTITY: XA is the identity) and hull B (piece pb under
+// XB), margins excluded.  Returns a lower bound > cutoff as soon as one is proven, and the current
+// upper bound as soon as it drops below stop_below (callers only test it against a threshold then).
+template <bool IDENTITY>
+__device__ inline float gjk_distance(const SMR_CONST float4 *verts, const DPiece &A, const Xf &XA, const DPiece &B,
+                                     const Xf &XB, F3 v, float cutoff, float stop_below) {
+    F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
+    int n = 0;
+    float vv = dot(v, v);
+    const float cutoff2 = cutoff * cutoff, stop2 = stop_below * stop_below;
+    for (int it = 0; it < 32; ++it) {
+        F3 w = support<IDENTITY>(verts, A.begin, A.count, XA, neg(v)) - support<false>(verts, B.begin, B.count, XB, v);
+        float vw = dot(v, w);
+        if (vw > 0.f && vw * vw > cutoff2 * vv) return (vw / sqrtf(vv));     // separating plane farther than cutoff
+        if (n > 0 && (vv - vw) <= 1e-6f * vv) break;                         // converged
+        if (n == 0) w0 = w; else if (n == 1) w1 = w; else if (n == 2) w2 = w; else w3 = w;
+        ++n;
+        F3 vn;
+        if (simplex_solve(w0, w1, w2, w3, n, vn)) return 0.f;                // origin inside the simplex
+        float vvn = dot(vn, vn);
+        if (it > 0 && vvn >= vv) break;                                      // no progress (rounding)
+        v = vn;
+        vv = vvn;
+        if (vv <= stop2) break;
+        if (n == 4) return 0.f;
+    }
+    return sqrtf(vv);
+}
+
+// signed distance (margins subtracted) between obstacle piece pa and link piece pb, or any value
+// > cutoff when they are farther apart than cutoff (ctlp.py:2915-2931: no closest point returned)
+template <bool IDENTITY>
+__device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, int pb, const Xf &XB, float cutoff,
+                                       float stop_below) {
+    const SMR_CONST DPiece *pieces = (const SMR_CONST DPiece *)S.pieces;
+    const DPiece A = pieces[__builtin_amdgcn_readfirstlane(pa)], B = pieces[__builtin_amdgcn_readfirstlane(pb)];
+    const float margins = A.margin + B.margin;
+    F3 cb = apply(XB, F3{B.cx, B.cy, B.cz});
+    F3 ca = IDENTITY ? F3{A.cx, A.cy, A.cz} : apply(XA, F3{A.cx, A.cy, A.cz});
+    F3 d = ca - cb;
+    float lb;
+    if (IDENTITY) {   // sphere of the link against the obstacle's axis-aligned box
+        float ex = fmaxf(fabsf(d.x) - A.hx, 0.f), ey = fmaxf(fabsf(d.y) - A.hy, 0.f), ez = fmaxf(fabsf(d.z) - A.hz, 0.f);
+        lb = sqrtf(ex * ex + ey * ey + ez * ez) - B.radius - margins;
+    } else {
+        lb = sqrtf(dot(d, d)) - A.radius - B.radius - margins;
+    }
+    if (lb > cutoff) return lb;
+    return gjk_distance<IDENTITY>((const SMR_CONST float4 *)S.verts, A, XA, B, XB, d, cutoff + margins, stop_below + margins) - margins;
+}
+
+__device__ __forceinline__ Xf planet_pose(const DScene &S, int p, int idx) {
+    return quat_pose((const SMR_GLOBAL float *)S.planet[p].orbit_pose + 8 * (size_t)idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One collision sample: FK of q and, per link, the table / planet queries it takes part in.
+//   want_dist   : compute d_static (A7) and d_moving (A8) - the end-of-step sample
+//   want_contact: compute the Bullet-contact flag between planets and robot links (A11)
+// ---------------------------------------------------------------------------------------------
+struct Sample { float d_static, d_moving; bool contact; };
+
+__device__ inline Sample collide_sample(const DScene &S, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS],
+                                        bool want_dist, bool want_contact) {
+    Sample out;
+    out.d_static = S.static_max;
+    out.d_moving = S.moving_max + 0.002f;          // ctlp.py:3261
+    out.contact = false;
+    Xf XP[SMR_MAX_PLANETS];
+#pragma unroll
+    for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+        if (p < S.n_planets) XP[p] = planet_pose(S, p, idx[p]);
+    // once a contact is certain the moving distance is 0 anyway (ctlp.py:3229-3234)
+    const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
+    Xf T = fk_base(S);
+    Xf I = T;   // unused placeholder for the identity branch
+    for (int l = 0; l < SMR_NLINK; ++l) {
+        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
+        const int pl = S.link_piece[l];
+        if (want_dist && ((S.static_mask >> l) & 1u)) {
+            for (int s = 0; s < S.n_static; ++s) {
+                float d = piece_distance<true>(S, S.static_piece[s], I, pl, T, out.d_static, S.collision_dist);
+                if (d <= S.static_max && d < out.d_static) out.d_static = d;
+            }
+        }
+        const bool mov_link = (S.moving_mask >> l) & 1u, con_link = (S.contact_mask >> l) & 1u;
+        if (!(mov_link || con_link)) continue;
+        for (int p = 0; p < S.n_planets; ++p) {
+            const int pb = S.planet[p].piece_begin, pc = S.planet[p].piece_count;
+            for (int c = 0; c < pc; ++c) {
+                const bool mov = want_dist && mov_link;
+                const bool con = want_contact && con_link && !out.contact;
+                if (!(mov || con)) continue;
+                float cutoff = mov ? fminf(out.d_moving, S.moving_max) : S.contact_dist;
+                if (con) cutoff = fmaxf(cutoff, S.contact_dist);
+                float d = piece_distance<false>(S, pb + c, XP[p], pl, T, cutoff, stop_moving);
+                if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
+                if (con && d <= S.contact_dist) out.contact = true;
+            }
+        }
+    }
+    return out;
+}
+
+// A15: observation row (obs.py:313-351), clipped to [-1, 1]
+__device__ inline void write_observation(const DScene &S, const float q[SMR_NJ], const float v[SMR_NJ],
+                                         const float a[SMR_NJ], const int idx[SMR_MAX_PLANETS], float *row) {
+    int o = 0;
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (q[j] - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) row[o++] = fminf(1.f, fmaxf(-1.f, v[j] / S.vel_max[j]));
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) row[o++] = fminf(1.f, fmaxf(-1.f, a[j] / S.acc_max[j]));
+    for (int p = 0; p < S.obs_num_planets; ++p) {
+        const int i = idx[p];
+        if (S.obs_planet_size == 1) {
+            row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (float)i / (float)S.planet[p].n_orbit));
+        } else if (S.obs_planet_size == 2) {
+            const SMR_GLOBAL float *loc = (const SMR_GLOBAL float *)S.planet[p].orbit_local + 2 * (size_t)i;
+            float rx = 1.05f * S.planet[p].radius_x, ry = 1.05f * S.planet[p].radius_y;
+            row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (loc[0] + rx) / (2.f * rx)));
+            row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (loc[1] + ry) / (2.f * ry)));
+        } else {
+            const SMR_GLOBAL float *pose = (const SMR_GLOBAL float *)S.planet[p].orbit_pose + 8 * (size_t)i;
+            for (int c = 0; c < 3; ++c)
+                row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (pose[c] - S.planet_obs_min[c]) / (S.planet_obs_max[c] - S.planet_obs_min[c])));
+        }
+    }
+}
+
+}  // namespace smr

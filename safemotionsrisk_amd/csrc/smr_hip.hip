@@ -1,0 +1,812 @@
+// smr_hip.hip - kernels and C ABI of libsmr_hip.so (include/safemotions_hip.h).  gfx950 only.
+//
+// step() = three launches on the handle's stream (+ one for the envs that finished):
+//   plan    (B lanes)      A2/A4  safe acceleration range of the current state, action -> end acceleration
+//   collide (B x N lanes)  A3/A6/A7/A8/A11  sample k of the cubic: FK + GJK contact test; the last sample
+//                          also yields the table / planet minimum distances of the reward
+//   finish  (B lanes)      A1/A12/A13/A15/A16  latch, state update, reward, termination, observation,
+//                          wave-aggregated append of finished envs to the reset list
+//   reset   (B lanes, only list entries work)  A17/A9  start state + planet phase by rejection sampling
+// The B x N grid of `collide` puts each collision sample on its own lane: 3x (N=3) the wavefronts of a
+// one-lane-per-env launch, which is what fills the 1024 SIMDs of the chip at B = 65 536.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "smr_device.h"
+
+namespace smr {
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions) {
+    const DScene &S = *Sp;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.B) return;
+    const int B = S.B;
+#pragma unroll 1
+    for (int j = 0; j < SMR_NJ; ++j) {
+        float lo, hi;
+        int code;
+        safe_acc_range_joint(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code);
+        float u = actions[(size_t)e * SMR_NJ + j];
+        st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
+    }
+}
+
+__global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.B) return;
+    const int B = S.B, N = S.checks_per_step;
+    const int k = (int)blockIdx.y + 1;                 // sample k of N, t_k = k dt / N
+    const bool final_sample = (k == N);
+    float *res = st.res + (size_t)(k - 1) * 4 * B;
+    const bool want_contact = S.term_moving && S.n_planets > 0 && st.moving_hit[e] == 0;
+    if (!final_sample && !want_contact) { res[e] = 0.f; return; }
+    const float t = S.dt * (float)k / (float)N;
+    float q[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j)
+        q[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], final_sample ? S.dt : t, S.dt);
+    int idx[SMR_MAX_PLANETS] = {0, 0};
+    const int upd = S.updates_per_step / N;
+#pragma unroll
+    for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+        if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
+    Sample r = collide_sample(S, q, idx, final_sample, want_contact);
+    res[e] = r.contact ? 1.f : 0.f;
+    if (final_sample) { res[B + e] = r.d_static; res[2 * B + e] = r.d_moving; }
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions,
+                                                     float *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ done,
+                                                     int8_t *__restrict__ reason, float *__restrict__ info) {
+    const DScene &S = *Sp;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.B) return;
+    const int B = S.B, N = S.checks_per_step;
+    const int steps = st.step_count[e] + 1;                                   // base.py:1044
+    int hit = st.moving_hit[e];
+    if (S.term_moving && S.n_planets > 0)                                     // ctlp.py:2631-2637
+        for (int k = 0; k < N; ++k) hit |= (st.res[(size_t)k * 4 * B + e] != 0.f) ? 1 : 0;
+    const float *resN = st.res + (size_t)(N - 1) * 4 * B;
+    float d_static = resN[B + e], d_self = S.static_max, d_moving = resN[2 * B + e];
+
+    float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ], amax = 0.f, vrel = 0.f, arel = 0.f;
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) {                                        // base.py:1179-1181
+        float q0 = st.q[j * B + e], v0 = st.v[j * B + e], a0 = st.a[j * B + e], a1 = st.a1[j * B + e];
+        q[j] = interp_pos(q0, v0, a0, a1, S.dt, S.dt);
+        v[j] = interp_vel(v0, a0, a1, S.dt, S.dt);
+        a[j] = a1;
+        amax = fmaxf(amax, fabsf(actions[(size_t)e * SMR_NJ + j]));
+        vrel = fmaxf(vrel, fabsf(v[j] / S.vel_max[j]));
+        arel = fmaxf(arel, fabsf(a[j] / S.acc_max[j]));
+    }
+    int idx[SMR_MAX_PLANETS] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+        if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + S.updates_per_step) % S.planet[p].n_orbit;   // ctlp.py:4504
+
+    // A12: rewards.py:95-162
+    bool col_static = false, col_self = false, col_moving = false;
+    if (d_static < S.collision_dist) { d_static = 0.f; col_static = true; }
+    if (d_self < S.collision_dist) { d_self = 0.f; col_self = true; }
+    if (hit) d_moving = 0.f;                                                  // ctlp.py:3229-3234
+    if (S.n_planets == 0) d_moving = S.moving_max + 0.002f;
+    if (d_moving < S.collision_dist) { d_moving = 0.f; col_moving = true; }
+    float r_self = 0.f, r_static = 0.f, r_moving;
+    if (S.self_max_reward != 0.f) { float r = fminf(1.f, d_self / S.self_max_dist); r_self = r * r; }
+    if (S.static_max_reward != 0.f) { float r = fminf(1.f, d_static / S.static_max_dist); r_static = r * r; }
+    { float r = fminf(1.f, d_moving / S.moving_max_dist); r_moving = r * r; }
+
+    // A13: rewards.py:432-502
+    float action_pun = 1.f;
+    if (S.punish_action) {
+        float p = (amax - S.action_thr) / (1.f - S.action_thr);
+        p = fmaxf(fminf(p, 1.f), 0.f);
+        action_pun = p * p;
+    }
+    float low_acc = 0.f, low_vel = 0.f;
+    if (S.low_acc_reward != 0.f) { float r = fminf(1.f, arel / S.low_acc_thr); low_acc = (r - 1.f) * (r - 1.f); }
+    if (S.low_vel_reward != 0.f) { float r = fminf(1.f, vrel / S.low_vel_thr); low_vel = (r - 1.f) * (r - 1.f); }
+    const bool term_col = (S.term_self && col_self) || (S.term_static && col_static) || (S.term_moving && col_moving);
+    const bool finished = steps >= S.episode_steps;                            // tm.py:187-192
+    const float bonus = (finished && !term_col) ? S.term_bonus : 0.f;
+    const float pun = term_col ? S.early_term_pun : 0.f;
+    reward[e] = (1.f - action_pun) * S.action_max_pun + r_self * S.self_max_reward + r_static * S.static_max_reward +
+                r_moving * S.moving_max_reward + low_acc * S.low_acc_reward + low_vel * S.low_vel_reward + bonus + pun;
+
+    // A16: base.py:1775-1799
+    int rs = SMR_TERMINATION_UNSET;
+    bool d = false;
+    if (S.term_self && col_self) { d = true; rs = SMR_TERMINATION_SELF_COLLISION; }
+    if (!d && S.term_static && col_static) { d = true; rs = SMR_TERMINATION_COLLISION_WITH_STATIC_OBSTACLE; }
+    if (!d && S.term_moving && col_moving) { d = true; rs = SMR_TERMINATION_COLLISION_WITH_MOVING_OBSTACLE; }
+    if (!d && finished) { d = true; rs = SMR_TERMINATION_TRAJECTORY_LENGTH; }
+    done[e] = d ? 1 : 0;
+    reason[e] = (int8_t)rs;
+    if (info) {
+        float *row = info + (size_t)e * SMR_INFO_N;
+        row[SMR_INFO_D_STATIC] = d_static; row[SMR_INFO_D_SELF] = d_self; row[SMR_INFO_D_MOVING] = d_moving;
+        row[SMR_INFO_ACTION_PUNISHMENT] = action_pun; row[SMR_INFO_R_SELF] = r_self; row[SMR_INFO_R_STATIC] = r_static;
+        row[SMR_INFO_R_MOVING] = r_moving; row[SMR_INFO_EPISODE_LENGTH] = (float)steps;
+    }
+
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) { st.q[j * B + e] = q[j]; st.v[j * B + e] = v[j]; st.a[j * B + e] = a[j]; }
+#pragma unroll
+    for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+        if (p < S.n_planets) st.planet_idx[p * B + e] = idx[p];
+    st.step_count[e] = steps;
+    st.moving_hit[e] = hit;
+
+    if (d && S.auto_reset) {
+        int slot = atomicAdd(st.done_count, 1);          // hipcc folds this into one atomic per wave
+        st.done_list[slot] = e;
+    } else {
+        write_observation(S, q, v, a, idx, obs + (size_t)e * S.obs_size);
+    }
+}
+
+// A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138, for one candidate q.
+// (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is outside the kinematic path.)
+__device__ inline bool position_is_valid(const DScene &S, const float q[SMR_NJ]) {
+    Xf T = fk_base(S), I = T;
+    bool ok = true;
+    for (int l = 0; l < SMR_NLINK; ++l) {
+        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
+        if (ok && ((S.static_mask >> l) & 1u)) {
+            for (int s = 0; s < S.n_static; ++s) {                                        // ctlp.py:2140-2168
+                float thr = S.start_min_static;
+                float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, thr - 1.0f);
+                if (d <= thr + 0.005f && d < thr) ok = false;
+            }
+        }
+    }
+    F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});                // ctlp.py:2051-2061
+    if (ee.x < S.start_box[0][0] || ee.x > S.start_box[0][1] || ee.y < S.start_box[1][0] || ee.y > S.start_box[1][1] ||
+        ee.z < S.start_box[2][0] || ee.z > S.start_box[2][1]) ok = false;
+    return ok;
+}
+
+__device__ inline void sample_position(const DScene &S, Rng &rng, float q[SMR_NJ]) {
+    for (int attempt = 0; attempt < 100000; ++attempt) {
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S.pos_lo[j], S.pos_hi[j]);   // ctlp.py:2035-2037
+        if (position_is_valid(S, q)) return;
+    }
+}
+
+// env.reset() for the envs in list[0..count): obs.py:144-149 -> base.py:913-1022
+__global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
+                                                   const int *__restrict__ count_ptr, int count_fixed, float *__restrict__ obs) {
+    const DScene &S = *Sp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int count = count_ptr ? *count_ptr : count_fixed;
+    if (i >= count) return;
+    const int e = list ? list[i] : i;
+    const int B = S.B;
+    Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, st.rng_draws[e]};
+    float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) { v[j] = 0.f; a[j] = 0.f; }
+    sample_position(S, rng, q);
+    // A17 part 2: get_starting_point_joint_pos_vel_acc, ctlp.py:1490-1654
+    if (S.kin_mode && rng.uniform01() < S.kin_prob) {
+        for (;;) {                                                                         // ctlp.py:1499-1556
+            bool all_found = true;
+#pragma unroll 1
+            for (int j = 0; j < SMR_NJ; ++j) {
+                if (!all_found) break;
+                bool found = false;
+                JointLim L = joint_lim(S, j);
+                for (int tv = 0; tv < 5 && !found; ++tv) {
+                    float vj = rng.uniform(-L.V, L.V);
+                    for (int ta = 0; ta < 10 && !found; ++ta) {
+                        float aj = rng.uniform(-L.A, L.A);
+                        float lo, hi;
+                        int code;
+                        safe_acc_range_joint(L, q[j], vj, aj, lo, hi, code);
+                        if (code == 0) { found = true; v[j] = vj; a[j] = aj; }
+                    }
+                }
+                if (!found) all_found = false;
+            }
+            if (all_found) break;
+            sample_position(S, rng, q);
+        }
+    } else {                                                                               // ctlp.py:1558-1654
+        // random walk of safe actions; ring of the three latest states
+        float hq[3][SMR_NJ], hv[3][SMR_NJ], ha[3][SMR_NJ];
+        int cnt = 1;
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) { hq[0][j] = q[j]; hv[0][j] = 0.f; ha[0][j] = 0.f; }
+        for (int walk = 0; walk < 64; ++walk) {
+            if (rng.uniform01() < S.stay_prob) break;
+            const int cur = (cnt - 1) % 3, nxt = cnt % 3;
+            float nq[SMR_NJ], nv[SMR_NJ], na[SMR_NJ], lo[SMR_NJ], hi[SMR_NJ];
+#pragma unroll 1
+            for (int j = 0; j < SMR_NJ; ++j) {
+                int code;
+                safe_acc_range_joint(joint_lim(S, j), hq[cur][j], hv[cur][j], ha[cur][j], lo[j], hi[j], code);
+            }
+#pragma unroll 1
+            for (int j = 0; j < SMR_NJ; ++j) {
+                float u = rng.uniform(-1.f, 1.f);
+                na[j] = lo[j] + 0.5f * (u + 1.f) * (hi[j] - lo[j]);
+                nv[j] = interp_vel(hv[cur][j], ha[cur][j], na[j], S.dt, S.dt);
+                nq[j] = interp_pos(hq[cur][j], hv[cur][j], ha[cur][j], na[j], S.dt, S.dt);
+            }
+            // end position collision free? table only (+ self: no pairs), ctlp.py:1605-1619
+            bool free_pos = true;
+            {
+                Xf T = fk_base(S), I = T;
+                for (int l = 0; l < SMR_NLINK; ++l) {
+                    if (l > 0) fk_advance(S, l - 1, nq[l - 1], T);
+                    if (free_pos && ((S.static_mask >> l) & 1u))
+                        for (int s = 0; s < S.n_static; ++s) {
+                            float thr = S.start_min_static;
+                            float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, thr - 1.0f);
+                            if (d <= thr + 0.005f && d < thr) free_pos = false;
+                        }
+                }
+            }
+            if (free_pos) {
+                for (int j = 0; j < SMR_NJ; ++j) { hq[nxt][j] = nq[j]; hv[nxt][j] = nv[j]; ha[nxt][j] = na[j]; }
+                ++cnt;
+            } else {
+                int sel = 1 + rng.randint(cnt < 3 ? cnt : 3);                              // ctlp.py:1641-1646
+                cnt = cnt - sel + 1;
+                break;
+            }
+        }
+        const int cur = (cnt - 1) % 3;
+        for (int j = 0; j < SMR_NJ; ++j) { q[j] = hq[cur][j]; v[j] = hv[cur][j]; a[j] = ha[cur][j]; }
+    }
+
+    int idx[SMR_MAX_PLANETS] = {0, 0};
+    int hit = 0;
+    if (S.n_planets > 0) {
+        // Planet.reset: random phase until contact free, ctlp.py:4470-4501
+        for (int attempt = 0; attempt < 100000; ++attempt) {
+#pragma unroll
+            for (int p = 0; p < SMR_MAX_PLANETS; ++p) {
+                if (p >= S.n_planets) continue;
+                const int n = S.planet[p].n_orbit;
+                if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % n + n) % n;
+                else idx[p] = rng.randint(n);
+            }
+            Sample r = collide_sample(S, q, idx, false, true);
+            if (!r.contact) break;
+        }
+        // obstacle_wrapper.update(update_after_reset=True): one planet update + contact check,
+        // base.py:980-985, ctlp.py:2626-2637
+#pragma unroll
+        for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+            if (p < S.n_planets) idx[p] = (idx[p] + 1) % S.planet[p].n_orbit;
+        if (S.term_moving) {
+            Sample r = collide_sample(S, q, idx, false, true);
+            hit = r.contact ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) { st.q[j * B + e] = q[j]; st.v[j * B + e] = v[j]; st.a[j * B + e] = a[j]; }
+    st.planet_idx[e] = idx[0];
+    st.planet_idx[B + e] = idx[1];
+    st.step_count[e] = 0;
+    st.moving_hit[e] = hit;
+    st.rng_draws[e] = rng.draws;
+    if (obs) write_observation(S, q, v, a, idx, obs + (size_t)e * S.obs_size);
+}
+
+__global__ void mask_to_list_kernel(const uint8_t *__restrict__ mask, int B, int *__restrict__ list, int *__restrict__ count) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    if (mask[e]) list[atomicAdd(count, 1)] = e;
+}
+
+__global__ void observe_kernel(const DScene *__restrict__ Sp, DState st, float *__restrict__ obs) {
+    const DScene &S = *Sp;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.B) return;
+    const int B = S.B;
+    float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
+    for (int j = 0; j < SMR_NJ; ++j) { q[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; a[j] = st.a[j * B + e]; }
+    int idx[SMR_MAX_PLANETS] = {st.planet_idx[e], st.planet_idx[B + e]};
+    write_observation(S, q, v, a, idx, obs + (size_t)e * S.obs_size);
+}
+
+// ---- component kernels for the parity tests ----
+__global__ void test_fk_kernel(const DScene *__restrict__ Sp, const float *__restrict__ q, int n, float *__restrict__ pos, float *__restrict__ rotm) {
+    const DScene &S = *Sp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Xf T = fk_base(S);
+    for (int l = 0; l < SMR_NLINK; ++l) {
+        if (l > 0) fk_advance(S, l - 1, q[i * SMR_NJ + l - 1], T);
+        float *p = pos + ((size_t)i * SMR_NLINK + l) * 3;
+        p[0] = T.t.x; p[1] = T.t.y; p[2] = T.t.z;
+        for (int c = 0; c < 9; ++c) rotm[((size_t)i * SMR_NLINK + l) * 9 + c] = T.r[c];
+    }
+}
+
+__global__ void test_range_kernel(const DScene *__restrict__ Sp, const float *__restrict__ p, const float *__restrict__ v,
+                                  const float *__restrict__ a, int n, float *__restrict__ lo, float *__restrict__ hi, int *__restrict__ code) {
+    const DScene &S = *Sp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 0; j < SMR_NJ; ++j) {
+        int k = i * SMR_NJ + j;
+        safe_acc_range_joint(joint_lim(S, j), p[k], v[k], a[k], lo[k], hi[k], code[k]);
+    }
+}
+
+__global__ void test_distances_kernel(const DScene *__restrict__ Sp, const float *__restrict__ q, const int *__restrict__ pidx, int n,
+                                      float *__restrict__ out) {
+    const DScene &S = *Sp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float qq[SMR_NJ];
+    for (int j = 0; j < SMR_NJ; ++j) qq[j] = q[i * SMR_NJ + j];
+    int idx[SMR_MAX_PLANETS] = {pidx[2 * i], pidx[2 * i + 1]};
+    Sample d = collide_sample(S, qq, idx, true, false);
+    Sample c = collide_sample(S, qq, idx, false, true);
+    out[4 * i] = d.d_static; out[4 * i + 1] = S.static_max; out[4 * i + 2] = d.d_moving; out[4 * i + 3] = c.contact ? 1.f : 0.f;
+}
+
+}  // namespace smr
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+using namespace smr;
+
+struct smr_env {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int B = 0, obs_size = 0, N = 1;
+    int auto_reset = 0;
+    DScene hscene;              // host copy (device pointers inside)
+    DScene *dscene = nullptr;
+    DState st;
+    std::vector<void *> allocs;
+    std::string err;
+    bool profiling = false;
+    hipEvent_t ev[SMR_K_COUNT][2];
+    bool ev_ok = false;
+    struct Pending { int k; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[SMR_K_COUNT] = {0, 0, 0, 0};
+    int64_t prof_n[SMR_K_COUNT] = {0, 0, 0, 0};
+};
+
+static thread_local std::string g_create_error;
+
+#define SMR_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            env->err = std::string(#call) + ": " + hipGetErrorString(_e);                               \
+            return SMR_E_HIP;                                                                           \
+        }                                                                                               \
+    } while (0)
+
+template <class T>
+static int dev_alloc(smr_env *env, T **out, size_t count) {
+    void *p = nullptr;
+    SMR_HIP(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    env->allocs.push_back(p);
+    *out = (T *)p;
+    return SMR_OK;
+}
+
+template <class T>
+static int dev_upload(smr_env *env, T **out, const std::vector<T> &host) {
+    int rc = dev_alloc(env, out, host.size());
+    if (rc) return rc;
+    if (!host.empty()) SMR_HIP(hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SMR_OK;
+}
+
+static void copy3(float *dst, const double *src, int n = 3) { for (int i = 0; i < n; ++i) dst[i] = (float)src[i]; }
+
+static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed) {
+    DScene &d = env->hscene;
+    std::memset(&d, 0, sizeof d);
+    d.B = env->B; d.obs_size = s.obs_size; d.episode_steps = s.episode_steps; d.updates_per_step = s.updates_per_step;
+    d.checks_per_step = s.collision_checks_per_step; d.auto_reset = s.auto_reset; d.dt = (float)s.dt;
+    copy3(d.pos_lo, s.pos_lo, SMR_NJ); copy3(d.pos_hi, s.pos_hi, SMR_NJ); copy3(d.vel_max, s.vel_max, SMR_NJ);
+    copy3(d.acc_max, s.acc_max, SMR_NJ); copy3(d.jerk_max, s.jerk_max, SMR_NJ);
+    copy3(d.base, s.base_xyz); copy3(d.ee_offset, s.ee_offset);
+    for (int j = 0; j < SMR_NJ; ++j) { copy3(d.joint_xyz[j], s.joint_xyz[j]); copy3(d.joint_axis[j], s.joint_axis[j]); }
+
+    std::vector<float4> verts((size_t)s.n_verts);
+    for (int i = 0; i < s.n_verts; ++i) verts[i] = make_float4((float)s.verts[3 * i], (float)s.verts[3 * i + 1], (float)s.verts[3 * i + 2], 0.f);
+    std::vector<DPiece> pieces((size_t)s.n_pieces);
+    for (int i = 0; i < s.n_pieces; ++i) {
+        const smr_piece_t &p = s.pieces[i];
+        if (p.vert_begin < 0 || p.vert_count <= 0 || p.vert_begin + p.vert_count > s.n_verts) { env->err = "piece vertex range out of bounds"; return SMR_E_INVALID; }
+        DPiece &q = pieces[i];
+        q.begin = p.vert_begin; q.count = p.vert_count;
+        q.cx = (float)p.center[0]; q.cy = (float)p.center[1]; q.cz = (float)p.center[2];
+        q.margin = (float)p.margin;
+        // bounding data recomputed in float32 around the float32 center, slightly inflated, so culling stays conservative
+        float r = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+        for (int k = 0; k < p.vert_count; ++k) {
+            const float4 &vv = verts[(size_t)p.vert_begin + k];
+            float dx = vv.x - q.cx, dy = vv.y - q.cy, dz = vv.z - q.cz;
+            r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
+            hx = std::max(hx, std::fabs(dx)); hy = std::max(hy, std::fabs(dy)); hz = std::max(hz, std::fabs(dz));
+        }
+        q.radius = r * 1.00001f + 1e-7f; q.hx = hx + 1e-7f; q.hy = hy + 1e-7f; q.hz = hz + 1e-7f;
+    }
+    float4 *dverts; DPiece *dpieces;
+    int rc;
+    if ((rc = dev_upload(env, &dverts, verts))) return rc;
+    if ((rc = dev_upload(env, &dpieces, pieces))) return rc;
+    d.verts = dverts; d.pieces = dpieces;
+    auto piece_ok = [&](int p) { return p >= 0 && p < s.n_pieces; };
+    for (int l = 0; l < SMR_NLINK; ++l) { if (!piece_ok(s.link_piece[l])) { env->err = "bad link_piece"; return SMR_E_INVALID; } d.link_piece[l] = s.link_piece[l]; }
+    if (s.n_static < 0 || s.n_static > SMR_MAX_STATIC) { env->err = "bad n_static"; return SMR_E_INVALID; }
+    d.n_static = s.n_static;
+    for (int i = 0; i < s.n_static; ++i) { if (!piece_ok(s.static_piece[i])) { env->err = "bad static_piece"; return SMR_E_INVALID; } d.static_piece[i] = s.static_piece[i]; }
+    d.static_mask = s.static_link_mask; d.static_max = (float)s.static_max_distance;
+    d.moving_mask = s.moving_link_mask; d.contact_mask = s.contact_link_mask;
+    d.moving_max = (float)s.moving_max_distance; d.contact_dist = (float)s.contact_distance;
+    if (s.n_planets < 0 || s.n_planets > SMR_MAX_PLANETS) { env->err = "bad n_planets"; return SMR_E_INVALID; }
+    d.n_planets = s.n_planets; d.obs_planet_size = s.obs_planet_size_per_planet; d.obs_num_planets = s.obs_num_planets;
+    for (int p = 0; p < s.n_planets; ++p) {
+        const smr_planet_t &pl = s.planet[p];
+        if (pl.n_orbit <= 0 || !pl.orbit_pose || !pl.orbit_local || !piece_ok(pl.piece_begin) || pl.piece_count <= 0 ||
+            !piece_ok(pl.piece_begin + pl.piece_count - 1)) { env->err = "bad planet table"; return SMR_E_INVALID; }
+        std::vector<float> pose((size_t)pl.n_orbit * 8, 0.f), local((size_t)pl.n_orbit * 2);
+        for (int i = 0; i < pl.n_orbit; ++i) {
+            for (int c = 0; c < 7; ++c) pose[(size_t)i * 8 + c] = (float)pl.orbit_pose[(size_t)i * 7 + c];
+            local[(size_t)i * 2] = (float)pl.orbit_local[(size_t)i * 2]; local[(size_t)i * 2 + 1] = (float)pl.orbit_local[(size_t)i * 2 + 1];
+        }
+        float *dpose, *dlocal;
+        if ((rc = dev_upload(env, &dpose, pose))) return rc;
+        if ((rc = dev_upload(env, &dlocal, local))) return rc;
+        DPlanet &q = d.planet[p];
+        q.piece_begin = pl.piece_begin; q.piece_count = pl.piece_count; q.n_orbit = pl.n_orbit; q.index_shift = pl.index_shift;
+        q.coupled = pl.coupled; q.radius_x = (float)pl.radius_xy[0]; q.radius_y = (float)pl.radius_xy[1];
+        q.orbit_pose = dpose; q.orbit_local = dlocal;
+    }
+    copy3(d.planet_obs_min, s.planet_obs_pos_min); copy3(d.planet_obs_max, s.planet_obs_pos_max);
+    d.punish_action = s.punish_action; d.term_self = s.terminate_on_self_collision; d.term_static = s.terminate_on_static_collision;
+    d.term_moving = s.terminate_on_moving_collision;
+    d.action_thr = (float)s.action_punishment_min_threshold; d.action_max_pun = (float)s.action_max_punishment;
+    d.self_max_reward = (float)s.self_max_reward; d.self_max_dist = (float)s.self_max_reward_distance;
+    d.static_max_reward = (float)s.static_max_reward; d.static_max_dist = (float)s.static_max_reward_distance;
+    d.moving_max_reward = (float)s.moving_max_reward; d.moving_max_dist = (float)s.moving_max_reward_distance;
+    d.low_acc_reward = (float)s.low_acc_max_reward; d.low_acc_thr = (float)s.low_acc_threshold;
+    d.low_vel_reward = (float)s.low_vel_max_reward; d.low_vel_thr = (float)s.low_vel_threshold;
+    d.term_bonus = (float)s.termination_bonus; d.early_term_pun = (float)s.early_termination_punishment;
+    d.collision_dist = (float)s.collision_distance;
+    for (int c = 0; c < 3; ++c) { d.start_box[c][0] = (float)s.start_box[c][0]; d.start_box[c][1] = (float)s.start_box[c][1]; }
+    d.start_min_static = (float)s.start_min_dist_static; d.start_min_self = (float)s.start_min_dist_self;
+    d.kin_mode = s.kinematic_state_sampling_mode; d.kin_prob = (float)s.kinematic_state_sampling_probability;
+    d.stay_prob = (float)s.stay_in_state_probability;
+    d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32);
+    if ((rc = dev_alloc(env, &env->dscene, 1))) return rc;
+    SMR_HIP(hipMemcpy(env->dscene, &d, sizeof d, hipMemcpyHostToDevice));
+    return SMR_OK;
+}
+
+static int check_scene(const smr_scene_t *s, int32_t num_envs, std::string &err) {
+    if (!s) { err = "scene is NULL"; return SMR_E_INVALID; }
+    if (s->version != SMR_SCENE_VERSION) { err = "smr_scene_t version mismatch"; return SMR_E_INVALID; }
+    if (num_envs <= 0) { err = "num_envs must be positive"; return SMR_E_INVALID; }
+    if (s->collision_checks_per_step <= 0 || s->updates_per_step <= 0 || s->updates_per_step % s->collision_checks_per_step) {
+        err = "collision_checks_per_step must divide updates_per_step"; return SMR_E_INVALID;
+    }
+    if (s->use_ball) { err = "ball scene not available in this build"; return SMR_E_INVALID; }
+    if (!s->verts || !s->pieces || s->n_verts <= 0 || s->n_pieces <= 0) { err = "scene has no geometry"; return SMR_E_INVALID; }
+    int expect = 3 * SMR_NJ + s->obs_num_planets * s->obs_planet_size_per_planet;
+    if (s->obs_size != expect) { err = "obs_size does not match the scene"; return SMR_E_INVALID; }
+    if (!(s->dt > 0) || s->episode_steps <= 0) { err = "bad time parameters"; return SMR_E_INVALID; }
+    return SMR_OK;
+}
+
+extern "C" {
+
+int smr_abi_version(void) { return SMR_ABI_VERSION; }
+size_t smr_scene_sizeof(void) { return sizeof(smr_scene_t); }
+
+const char *smr_last_error(const smr_env_t *env) { return env ? env->err.c_str() : g_create_error.c_str(); }
+
+int smr_destroy(smr_env_t *env) {
+    if (!env) return SMR_OK;
+    (void)hipSetDevice(env->device);
+    (void)hipStreamSynchronize(env->stream);
+    for (auto &p : env->pending) { env->event_pool.push_back(p.a); env->event_pool.push_back(p.b); }
+    for (auto e : env->event_pool) (void)hipEventDestroy(e);
+    for (void *p : env->allocs) (void)hipFree(p);
+    delete env;
+    return SMR_OK;
+}
+
+int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint64_t seed, void *stream, smr_env_t **out) {
+    if (!out) { g_create_error = "out is NULL"; return SMR_E_INVALID; }
+    *out = nullptr;
+    int rc = check_scene(scene, num_envs, g_create_error);
+    if (rc) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device: libsmr_hip has no CPU path (the CPU restatement lives in oracle/ and is test-only)";
+        return SMR_E_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { g_create_error = "device ordinal out of range"; return SMR_E_INVALID; }
+    smr_env *env = new smr_env();
+    env->device = device; env->stream = (hipStream_t)stream; env->B = num_envs; env->obs_size = scene->obs_size;
+    env->N = scene->collision_checks_per_step; env->auto_reset = scene->auto_reset;
+    auto fail = [&](int code) { g_create_error = env->err; smr_destroy(env); return code; };
+    if (hipSetDevice(device) != hipSuccess) { env->err = "hipSetDevice failed"; return fail(SMR_E_HIP); }
+    if ((rc = build_device_scene(env, *scene, seed))) return fail(rc);
+    const size_t B = (size_t)num_envs;
+    DState &st = env->st;
+    if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
+        (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
+        (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.rng_draws, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)env->N * 4 * B)) || (rc = dev_alloc(env, &st.done_list, B)) ||
+        (rc = dev_alloc(env, &st.done_count, 1)))
+        return fail(rc);
+    hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
+               e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
+               e7 = hipMemset(st.rng_draws, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
+    if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (hipDeviceSynchronize() != hipSuccess) { env->err = "hipDeviceSynchronize failed"; return fail(SMR_E_HIP); }
+    *out = env;
+    return SMR_OK;
+}
+
+int32_t smr_num_envs(const smr_env_t *env) { return env ? env->B : 0; }
+int32_t smr_obs_size(const smr_env_t *env) { return env ? env->obs_size : 0; }
+
+}  // extern "C"
+
+// ---- profiling helpers: a pair of events around one launch, resolved lazily ----
+static hipEvent_t pool_get(smr_env *env) {
+    if (!env->event_pool.empty()) { hipEvent_t e = env->event_pool.back(); env->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct LaunchTimer {
+    smr_env *env; int k; hipEvent_t a = nullptr, b = nullptr;
+    LaunchTimer(smr_env *e, int kk) : env(e), k(kk) {
+        if (env->profiling) { a = pool_get(env); b = pool_get(env); (void)hipEventRecord(a, env->stream); }
+    }
+    ~LaunchTimer() {
+        if (env->profiling) { (void)hipEventRecord(b, env->stream); env->pending.push_back({k, a, b}); }
+    }
+};
+
+static int resolve_profile(smr_env *env) {
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    for (auto &p : env->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { env->prof_ms[p.k] += ms; env->prof_n[p.k] += 1; }
+        env->event_pool.push_back(p.a); env->event_pool.push_back(p.b);
+    }
+    env->pending.clear();
+    return SMR_OK;
+}
+
+// host [B][C] row-major <-> device [C][B]
+template <class T>
+static int state_get(smr_env *env, T *host, const T *dev, int C) {
+    if (!host) return SMR_OK;
+    const size_t B = (size_t)env->B;
+    std::vector<T> tmp(B * C);
+    SMR_HIP(hipMemcpy(tmp.data(), dev, tmp.size() * sizeof(T), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < B; ++e) for (int c = 0; c < C; ++c) host[e * C + c] = tmp[(size_t)c * B + e];
+    return SMR_OK;
+}
+template <class T>
+static int state_set(smr_env *env, const T *host, T *dev, int C) {
+    if (!host) return SMR_OK;
+    const size_t B = (size_t)env->B;
+    std::vector<T> tmp(B * C);
+    for (size_t e = 0; e < B; ++e) for (int c = 0; c < C; ++c) tmp[(size_t)c * B + e] = host[e * C + c];
+    SMR_HIP(hipMemcpy(dev, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return SMR_OK;
+}
+
+// ---- component entry points ----
+struct TmpBuf {
+    smr_env *env; std::vector<void *> ptrs;
+    ~TmpBuf() { for (void *p : ptrs) (void)hipFree(p); }
+    template <class T> T *up(const T *host, size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        if (host && n && hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return (T *)p;
+    }
+};
+
+static int launch_reset_list(smr_env *env, float *obs_dev) {
+    // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
+    LaunchTimer t(env, SMR_K_RESET);
+    const int B = env->B;
+    hipLaunchKernelGGL(reset_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st, env->st.done_list,
+                       env->st.done_count, 0, obs_dev);
+    SMR_HIP(hipGetLastError());
+    return SMR_OK;
+}
+
+extern "C" {
+
+int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
+    if (!env) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    const int B = env->B;
+    if (!mask_dev) {
+        LaunchTimer t(env, SMR_K_RESET);
+        hipLaunchKernelGGL(reset_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st, (const int *)nullptr,
+                           (const int *)nullptr, B, obs_dev);
+        SMR_HIP(hipGetLastError());
+        return SMR_OK;
+    }
+    SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));
+    hipLaunchKernelGGL(mask_to_list_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, mask_dev, B, env->st.done_list, env->st.done_count);
+    SMR_HIP(hipGetLastError());
+    return launch_reset_list(env, obs_dev);
+}
+
+int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *reward_dev, uint8_t *done_dev, int8_t *reason_dev,
+             float *info_dev) {
+    if (!env) return SMR_E_INVALID;
+    if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !reason_dev) { env->err = "smr_step: NULL buffer"; return SMR_E_INVALID; }
+    SMR_HIP(hipSetDevice(env->device));
+    const int B = env->B;
+    if (env->auto_reset) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));
+    {
+        LaunchTimer t(env, SMR_K_PLAN);
+        hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
+    }
+    SMR_HIP(hipGetLastError());
+    {
+        LaunchTimer t(env, SMR_K_COLLIDE);
+        hipLaunchKernelGGL(collide_kernel, dim3((B + 63) / 64, env->N), dim3(64), 0, env->stream, env->dscene, env->st);
+    }
+    SMR_HIP(hipGetLastError());
+    {
+        LaunchTimer t(env, SMR_K_FINISH);
+        hipLaunchKernelGGL(finish_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, obs_dev,
+                           reward_dev, done_dev, reason_dev, info_dev);
+    }
+    SMR_HIP(hipGetLastError());
+    if (env->auto_reset) return launch_reset_list(env, obs_dev);
+    return SMR_OK;
+}
+
+int smr_observe(smr_env_t *env, float *obs_dev) {
+    if (!env || !obs_dev) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    hipLaunchKernelGGL(observe_kernel, dim3((env->B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, obs_dev);
+    SMR_HIP(hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_synchronize(smr_env_t *env) {
+    if (!env) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    return SMR_OK;
+}
+
+int smr_get_state(smr_env_t *env, const smr_host_state_t *h) {
+    if (!env || !h) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    int rc;
+    if ((rc = state_get(env, h->q, env->st.q, 7)) || (rc = state_get(env, h->v, env->st.v, 7)) || (rc = state_get(env, h->a, env->st.a, 7)) ||
+        (rc = state_get(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_get(env, h->step_count, env->st.step_count, 1)) ||
+        (rc = state_get(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_get(env, h->rng_draws, env->st.rng_draws, 1)))
+        return rc;
+    return SMR_OK;
+}
+
+int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
+    if (!env || !h) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    if (h->planet_idx)
+        for (size_t e = 0; e < (size_t)env->B; ++e)
+            for (int p = 0; p < env->hscene.n_planets; ++p) {
+                int v = h->planet_idx[e * 2 + p];
+                if (v < 0 || v >= env->hscene.planet[p].n_orbit) { env->err = "smr_set_state: planet_idx out of range"; return SMR_E_INVALID; }
+            }
+    int rc;
+    if ((rc = state_set(env, h->q, env->st.q, 7)) || (rc = state_set(env, h->v, env->st.v, 7)) || (rc = state_set(env, h->a, env->st.a, 7)) ||
+        (rc = state_set(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_set(env, h->step_count, env->st.step_count, 1)) ||
+        (rc = state_set(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_set(env, h->rng_draws, env->st.rng_draws, 1)))
+        return rc;
+    SMR_HIP(hipDeviceSynchronize());
+    return SMR_OK;
+}
+
+int smr_set_profiling(smr_env_t *env, int32_t enable) {
+    if (!env) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    int rc = resolve_profile(env);
+    env->profiling = enable != 0;
+    return rc;
+}
+
+int smr_get_profile(smr_env_t *env, double ms_out[SMR_K_COUNT], int64_t launches_out[SMR_K_COUNT]) {
+    if (!env) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    int rc = resolve_profile(env);
+    if (rc) return rc;
+    for (int k = 0; k < SMR_K_COUNT; ++k) {
+        if (ms_out) ms_out[k] = env->prof_ms[k];
+        if (launches_out) launches_out[k] = env->prof_n[k];
+        env->prof_ms[k] = 0; env->prof_n[k] = 0;
+    }
+    return SMR_OK;
+}
+
+int smr_test_fk(smr_env_t *env, const float *q_host, int32_t n, float *pos_out, float *rot_out) {
+    if (!env || !q_host || n <= 0 || !pos_out || !rot_out) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    TmpBuf t{env, {}};
+    float *q = t.up(q_host, (size_t)n * 7), *pos = t.up<float>(nullptr, (size_t)n * 24), *r = t.up<float>(nullptr, (size_t)n * 72);
+    if (!q || !pos || !r) { env->err = "smr_test_fk: allocation failed"; return SMR_E_HIP; }
+    hipLaunchKernelGGL(test_fk_kernel, dim3((n + 63) / 64), dim3(64), 0, env->stream, env->dscene, q, n, pos, r);
+    SMR_HIP(hipGetLastError());
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    SMR_HIP(hipMemcpy(pos_out, pos, (size_t)n * 24 * 4, hipMemcpyDeviceToHost));
+    SMR_HIP(hipMemcpy(rot_out, r, (size_t)n * 72 * 4, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_test_safe_acc_range(smr_env_t *env, const float *p_host, const float *v_host, const float *a_host, int32_t n, float *lo_out,
+                            float *hi_out, int32_t *code_out) {
+    if (!env || !p_host || !v_host || !a_host || n <= 0 || !lo_out || !hi_out || !code_out) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    TmpBuf t{env, {}};
+    size_t m = (size_t)n * 7;
+    float *p = t.up(p_host, m), *v = t.up(v_host, m), *a = t.up(a_host, m), *lo = t.up<float>(nullptr, m), *hi = t.up<float>(nullptr, m);
+    int *code = t.up<int>(nullptr, m);
+    if (!p || !v || !a || !lo || !hi || !code) { env->err = "smr_test_safe_acc_range: allocation failed"; return SMR_E_HIP; }
+    hipLaunchKernelGGL(test_range_kernel, dim3((n + 63) / 64), dim3(64), 0, env->stream, env->dscene, p, v, a, n, lo, hi, code);
+    SMR_HIP(hipGetLastError());
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    SMR_HIP(hipMemcpy(lo_out, lo, m * 4, hipMemcpyDeviceToHost));
+    SMR_HIP(hipMemcpy(hi_out, hi, m * 4, hipMemcpyDeviceToHost));
+    SMR_HIP(hipMemcpy(code_out, code, m * 4, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_test_distances(smr_env_t *env, const float *q_host, const int32_t *planet_idx_host, int32_t n, float *out) {
+    if (!env || !q_host || !planet_idx_host || n <= 0 || !out) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    for (int i = 0; i < n; ++i)
+        for (int p = 0; p < env->hscene.n_planets; ++p) {
+            int v = planet_idx_host[2 * i + p];
+            if (v < 0 || v >= env->hscene.planet[p].n_orbit) { env->err = "smr_test_distances: planet_idx out of range"; return SMR_E_INVALID; }
+        }
+    TmpBuf t{env, {}};
+    float *q = t.up(q_host, (size_t)n * 7), *o = t.up<float>(nullptr, (size_t)n * 4);
+    int *idx = t.up(planet_idx_host, (size_t)n * 2);
+    if (!q || !o || !idx) { env->err = "smr_test_distances: allocation failed"; return SMR_E_HIP; }
+    hipLaunchKernelGGL(test_distances_kernel, dim3((n + 63) / 64), dim3(64), 0, env->stream, env->dscene, q, idx, n, o);
+    SMR_HIP(hipGetLastError());
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    SMR_HIP(hipMemcpy(out, o, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+}  // extern "C"

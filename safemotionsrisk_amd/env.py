@@ -1,0 +1,200 @@
+"""Batched drop-in for the reference's gym surface.
+
+``VecSafeMotionsEnv(num_envs=B, **env_config)`` mirrors ``SafeMotionsEnvCollisionAvoidance(**env_config)``
+(safemotions/envs/safe_motions_env.py:38, constructed at train.py:620): same ``env_config`` keys, same
+``TERMINATION_*`` constants, ``action_space`` / ``observation_space`` shapes, ``reset()`` -> obs and
+``step(action)`` -> (obs, reward, done, info) - batched over B environments that live on one GPU, one
+environment per wavefront lane.  All arithmetic runs in libsmr_hip.so; torch only provides device
+buffers and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .scene import NJ, build_scene
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency of the hot path)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = np.float32(low), np.float32(high), tuple(shape), dtype
+
+    def __repr__(self):
+        return "Box(%s, %s, %s, %s)" % (self.low, self.high, self.shape, np.dtype(self.dtype).name)
+
+
+class VecSafeMotionsEnv:
+    # base.py:63-70
+    TERMINATION_UNSET = -1
+    TERMINATION_SUCCESS = 0
+    TERMINATION_JOINT_LIMITS = 1
+    TERMINATION_TRAJECTORY_LENGTH = 2
+    TERMINATION_SELF_COLLISION = 3
+    TERMINATION_COLLISION_WITH_STATIC_OBSTACLE = 4
+    TERMINATION_COLLISION_WITH_MOVING_OBSTACLE = 5
+
+    INFO_COLUMNS = ("minimum_distance_to_static_obstacles", "minimum_distance_self_collision",
+                    "minimum_distance_to_moving_obstacles", "action_punishment", "self_collision_reward",
+                    "static_obstacles_collision_reward", "moving_obstacles_collision_reward", "episode_length")
+
+    def __init__(self, num_envs, device=0, seed=None, auto_reset=True, collision_checks_per_step=None,
+                 contact_distance=None, return_info=True, env_index_offset=0, **env_config):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("VecSafeMotionsEnv needs a GPU: the HIP library has no CPU path")
+        self._torch = torch
+        self._L = _lib.load()
+        kw = {} if contact_distance is None else dict(contact_distance=contact_distance)
+        self.scene = build_scene(env_config, collision_checks_per_step=collision_checks_per_step,
+                                 auto_reset=auto_reset, **kw)
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", int(device))
+        self.observation_size = self.scene.obs_size
+        self.action_space = Box(-1, 1, (NJ,))                                   # actions.py:49-51
+        self.observation_space = Box(-1, 1, (self.observation_size,))           # obs.py:116-117
+        self.trajectory_time_step = float(self.scene.struct.dt)
+        self.episode_counter = 0
+        self._return_info = bool(return_info)
+        self._seed = 0 if seed is None else int(seed)                           # base.py:1704-1710
+        with torch.cuda.device(self.device):
+            self._stream = torch.cuda.current_stream(self.device)
+            handle = C.c_void_p()
+            rc = self._L.smr_create(C.cast(self.scene.pointer(), C.c_void_p), self.num_envs, int(device),
+                                    C.c_uint64(self._seed + (int(env_index_offset) << 32)),
+                                    C.c_void_p(self._stream.cuda_stream), C.byref(handle))
+            _lib.check(self._L, None, rc, "smr_create")
+        self._h = handle
+        B, O = self.num_envs, self.observation_size
+        self.obs = torch.zeros((B, O), dtype=torch.float32, device=self.device)
+        self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
+        self.done = torch.zeros(B, dtype=torch.uint8, device=self.device)
+        self.termination_reason = torch.full((B,), -1, dtype=torch.int8, device=self.device)
+        self.info = torch.zeros((B, _lib.INFO_N), dtype=torch.float32, device=self.device) if return_info else None
+
+    # ---- gym surface ----
+    def set_seed(self, seed=None):
+        raise NotImplementedError("pass seed= to the constructor: the per-env Philox streams are keyed at creation")
+
+    def reset(self, mask=None):
+        """obs = env.reset() for all envs (or those selected by a bool/uint8 mask tensor)."""
+        t = self._torch
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=t.uint8).contiguous()
+        rc = self._L.smr_reset(self._h, None if m is None else C.c_void_p(m.data_ptr()), C.c_void_p(self.obs.data_ptr()))
+        _lib.check(self._L, self._h, rc, "smr_reset")
+        self.episode_counter += self.num_envs if m is None else int(m.sum().item())
+        return self.obs
+
+    def step(self, action):
+        """(obs, reward, done, info) = env.step(action); action float32 [B, 7] on the env's device."""
+        t = self._torch
+        if not isinstance(action, t.Tensor):
+            action = t.as_tensor(np.asarray(action, dtype=np.float32))
+        a = action.to(device=self.device, dtype=t.float32).contiguous()
+        if a.shape != (self.num_envs, NJ):
+            raise ValueError("action must have shape (%d, %d), got %s" % (self.num_envs, NJ, tuple(a.shape)))
+        rc = self._L.smr_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                              C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
+                              C.c_void_p(self.termination_reason.data_ptr()),
+                              None if self.info is None else C.c_void_p(self.info.data_ptr()))
+        _lib.check(self._L, self._h, rc, "smr_step")
+        info = {"termination_reason": self.termination_reason}
+        if self.info is not None:
+            info["columns"] = self.INFO_COLUMNS
+            info["values"] = self.info
+        return self.obs, self.reward, self.done, info
+
+    def observe(self):
+        rc = self._L.smr_observe(self._h, C.c_void_p(self.obs.data_ptr()))
+        _lib.check(self._L, self._h, rc, "smr_observe")
+        return self.obs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.smr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _lib.check(self._L, self._h, self._L.smr_synchronize(self._h), "smr_synchronize")
+
+    # ---- state injection / checkpointing (base.py:1801-1891 counterpart) ----
+    def get_state(self):
+        B = self.num_envs
+        st = dict(q=np.zeros((B, NJ), np.float32), v=np.zeros((B, NJ), np.float32), a=np.zeros((B, NJ), np.float32),
+                  planet_idx=np.zeros((B, 2), np.int32), step_count=np.zeros(B, np.int32),
+                  moving_hit=np.zeros(B, np.int32), rng_draws=np.zeros(B, np.uint32))
+        hs = _lib.HostState(*[st[k].ctypes.data for k in ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "rng_draws")])
+        _lib.check(self._L, self._h, self._L.smr_get_state(self._h, C.byref(hs)), "smr_get_state")
+        return st
+
+    def set_state(self, **kw):
+        B = self.num_envs
+        spec = dict(q=(np.float32, (B, NJ)), v=(np.float32, (B, NJ)), a=(np.float32, (B, NJ)),
+                    planet_idx=(np.int32, (B, 2)), step_count=(np.int32, (B,)), moving_hit=(np.int32, (B,)),
+                    rng_draws=(np.uint32, (B,)))
+        keep, ptrs = [], []
+        for k in ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "rng_draws"):
+            if kw.get(k) is None:
+                ptrs.append(None)
+            else:
+                arr = np.ascontiguousarray(np.broadcast_to(np.asarray(kw[k], dtype=spec[k][0]), spec[k][1]))
+                keep.append(arr)
+                ptrs.append(arr.ctypes.data)
+        unknown = set(kw) - set(spec)
+        if unknown:
+            raise TypeError("unknown state fields: %s" % sorted(unknown))
+        hs = _lib.HostState(*ptrs)
+        _lib.check(self._L, self._h, self._L.smr_set_state(self._h, C.byref(hs)), "smr_set_state")
+
+    # ---- profiling ----
+    def set_profiling(self, enable):
+        _lib.check(self._L, self._h, self._L.smr_set_profiling(self._h, int(bool(enable))), "smr_set_profiling")
+
+    def get_profile(self):
+        ms = (C.c_double * _lib.K_COUNT)()
+        n = (C.c_int64 * _lib.K_COUNT)()
+        _lib.check(self._L, self._h, self._L.smr_get_profile(self._h, ms, n), "smr_get_profile")
+        return {name: dict(ms=ms[i], launches=int(n[i])) for i, name in enumerate(_lib.KERNEL_NAMES)}
+
+    # ---- component entry points (parity tests) ----
+    def test_fk(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, NJ)
+        n = len(q)
+        pos = np.zeros((n, 8, 3), np.float32)
+        rot = np.zeros((n, 8, 3, 3), np.float32)
+        rc = self._L.smr_test_fk(self._h, q.ctypes.data, n, pos.ctypes.data, rot.ctypes.data)
+        _lib.check(self._L, self._h, rc, "smr_test_fk")
+        return pos, rot
+
+    def test_safe_acc_range(self, p, v, a):
+        p, v, a = [np.ascontiguousarray(x, dtype=np.float32).reshape(-1, NJ) for x in (p, v, a)]
+        n = len(p)
+        lo, hi, code = np.zeros((n, NJ), np.float32), np.zeros((n, NJ), np.float32), np.zeros((n, NJ), np.int32)
+        rc = self._L.smr_test_safe_acc_range(self._h, p.ctypes.data, v.ctypes.data, a.ctypes.data, n,
+                                             lo.ctypes.data, hi.ctypes.data, code.ctypes.data)
+        _lib.check(self._L, self._h, rc, "smr_test_safe_acc_range")
+        return lo, hi, code
+
+    def test_distances(self, q, planet_idx):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, NJ)
+        idx = np.ascontiguousarray(planet_idx, dtype=np.int32).reshape(-1, 2)
+        n = len(q)
+        out = np.zeros((n, 4), np.float32)
+        rc = self._L.smr_test_distances(self._h, q.ctypes.data, idx.ctypes.data, n, out.ctypes.data)
+        _lib.check(self._L, self._h, rc, "smr_test_distances")
+        return out
+
+
+#: name parity with the reference class (safe_motions_env.py:38)
+SafeMotionsEnvCollisionAvoidance = VecSafeMotionsEnv

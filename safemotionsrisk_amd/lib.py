@@ -1,0 +1,102 @@
+"""ctypes binding of libsmr_hip.so (include/safemotions_hip.h) and its in-tree build.
+
+This is the reference-side stub a maintainer adds under ``SafeMotionsEnv``.  There is
+no CPU fallback: if the shared library is missing, or no GPU is present, every constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from .scene import Scene
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libsmr_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
+
+ABI_VERSION = 1
+INFO_N = 8
+K_COUNT = 4
+KERNEL_NAMES = ("plan", "collide", "finish", "reset")
+
+#: every symbol include/safemotions_hip.h declares
+EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "smr_last_error", "smr_num_envs",
+           "smr_obs_size", "smr_reset", "smr_step", "smr_observe", "smr_get_state", "smr_set_state",
+           "smr_synchronize", "smr_set_profiling", "smr_get_profile", "smr_test_fk", "smr_test_safe_acc_range",
+           "smr_test_distances")
+
+
+class HostState(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("a", C.c_void_p), ("planet_idx", C.c_void_p),
+                ("step_count", C.c_void_p), ("moving_hit", C.c_void_p), ("rng_draws", C.c_void_p)]
+
+
+def _sources():
+    return [os.path.join(CSRC, "smr_hip.hip"), os.path.join(CSRC, "smr_device.h"),
+            os.path.join(INCLUDE, "safemotions_hip.h"), os.path.join(INCLUDE, "smr_scene.h")]
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> safemotionsrisk_amd/libsmr_hip.so (cross-compiles without a GPU)."""
+    srcs = _sources()
+    if not force and os.path.exists(LIB_PATH) and all(not os.path.exists(s) or os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, srcs[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the product has no CPU path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.smr_abi_version.restype = C.c_int
+    L.smr_scene_sizeof.restype = C.c_size_t
+    L.smr_last_error.restype = C.c_char_p
+    L.smr_last_error.argtypes = [C.c_void_p]
+    L.smr_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.smr_destroy.argtypes = [C.c_void_p]
+    L.smr_num_envs.argtypes = [C.c_void_p]
+    L.smr_obs_size.argtypes = [C.c_void_p]
+    L.smr_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.smr_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.smr_observe.argtypes = [C.c_void_p, C.c_void_p]
+    L.smr_get_state.argtypes = [C.c_void_p, C.POINTER(HostState)]
+    L.smr_set_state.argtypes = [C.c_void_p, C.POINTER(HostState)]
+    L.smr_synchronize.argtypes = [C.c_void_p]
+    L.smr_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    L.smr_get_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.smr_test_fk.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.smr_test_safe_acc_range.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+    L.smr_test_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    if L.smr_abi_version() != ABI_VERSION:
+        raise RuntimeError("libsmr_hip.so ABI %d != binding ABI %d" % (L.smr_abi_version(), ABI_VERSION))
+    if L.smr_scene_sizeof() != C.sizeof(Scene):
+        raise RuntimeError("smr_scene_t layout mismatch: library %d bytes, binding %d bytes"
+                           % (L.smr_scene_sizeof(), C.sizeof(Scene)))
+    _lib = L
+    return L
+
+
+class SmrError(RuntimeError):
+    pass
+
+
+def check(L, handle, rc, what):
+    if rc != 0:
+        msg = L.smr_last_error(handle)
+        raise SmrError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,523 @@
+"""Host-side scene construction: reference ``env_config`` keys -> ``smr_scene_t`` (include/smr_scene.h).
+
+Mirrors what the reference does once per process in its constructors:
+
+* joint limits, ``scene.py:20-22,350-371,441-455`` (A5)
+* observed-link bookkeeping, ``ctlp.py:579-586,2419-2434``, ``scene.py:226-228,288-292``
+* planet orbit tables, ``ctlp.py:4403-4437`` (A9)
+* reward / termination / start-sampling constants, ``rewards.py:40-93,409-427``, ``ctlp.py:172-183,1468-1477``
+
+The geometry comes from ``data/iiwa7_assets.npz`` (see assets.py).  Unsupported configurations raise
+``NotImplementedError`` / ``ValueError`` instead of silently running something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+SCENE_VERSION = 3
+NJ = 7
+NLINK = 8
+MAX_PLANETS = 2
+MAX_STATIC = 4
+
+SIM_TIME_STEP = 1.0 / 240.0                      # base.py:34
+JOINT_LIMITS_SAFETY_BUFFER_IIWA = 0.035          # scene.py:20
+MAX_ACCELERATION_IIWA = [15.0, 7.5, 10.0, 12.5, 15.0, 20.0, 20.0]   # scene.py:21
+MAX_JERK_IIWA = [7500, 3750, 5000, 6250, 7500, 10000, 10000]         # scene.py:22
+BULLET_CONTACT_BREAKING_THRESHOLD = 0.02         # Bullet gContactBreakingThreshold
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "iiwa7_assets.npz")
+
+
+class Piece(C.Structure):
+    _fields_ = [("vert_begin", C.c_int32), ("vert_count", C.c_int32), ("center", C.c_double * 3),
+                ("radius", C.c_double), ("margin", C.c_double)]
+
+
+class Planet(C.Structure):
+    _fields_ = [("piece_begin", C.c_int32), ("piece_count", C.c_int32), ("n_orbit", C.c_int32),
+                ("index_shift", C.c_int32), ("coupled", C.c_int32), ("_pad", C.c_int32),
+                ("orbit_pose", C.POINTER(C.c_double)), ("orbit_local", C.POINTER(C.c_double)),
+                ("radius_xy", C.c_double * 2)]
+
+
+_D3 = C.c_double * 3
+_D7 = C.c_double * NJ
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("version", C.c_int32), ("obs_size", C.c_int32),
+        ("dt", C.c_double), ("episode_steps", C.c_int32), ("updates_per_step", C.c_int32),
+        ("collision_checks_per_step", C.c_int32), ("auto_reset", C.c_int32),
+        ("pos_lo", _D7), ("pos_hi", _D7), ("vel_max", _D7), ("acc_max", _D7), ("jerk_max", _D7),
+        ("base_xyz", _D3), ("joint_xyz", _D3 * NJ), ("joint_axis", _D3 * NJ), ("ee_offset", _D3),
+        ("verts", C.POINTER(C.c_double)), ("pieces", C.POINTER(Piece)),
+        ("n_verts", C.c_int32), ("n_pieces", C.c_int32), ("link_piece", C.c_int32 * NLINK),
+        ("n_static", C.c_int32), ("static_piece", C.c_int32 * MAX_STATIC), ("static_link_mask", C.c_uint32),
+        ("static_max_distance", C.c_double),
+        ("moving_link_mask", C.c_uint32), ("contact_link_mask", C.c_uint32),
+        ("moving_max_distance", C.c_double), ("contact_distance", C.c_double),
+        ("n_planets", C.c_int32), ("obs_planet_size_per_planet", C.c_int32), ("obs_num_planets", C.c_int32),
+        ("_pad1", C.c_int32),
+        ("planet", Planet * MAX_PLANETS),
+        ("planet_obs_pos_min", _D3), ("planet_obs_pos_max", _D3),
+        ("use_ball", C.c_int32), ("ball_piece", C.c_int32), ("ball_radius", C.c_double), ("ball_speed", C.c_double),
+        ("ball_sphere_center", _D3), ("ball_sphere_radius", C.c_double), ("ball_sphere_height", C.c_double * 2),
+        ("ball_sphere_angle", C.c_double * 2), ("ball_high_angle_prob", C.c_double),
+        ("ball_check_invalid_target", C.c_int32), ("ball_random_initial_position", C.c_int32),
+        ("ball_invalid_min", _D3), ("ball_invalid_max", _D3), ("ball_final_min", _D3), ("ball_final_max", _D3),
+        ("ball_obs_pos_min", _D3), ("ball_obs_pos_max", _D3), ("ball_obs_vel_min", _D3), ("ball_obs_vel_max", _D3),
+        ("ball_active_xy_radius", C.c_double), ("ball_target_box", (C.c_double * 2) * 3),
+        ("ball_target_min_dist_static", C.c_double), ("plane_z", C.c_double), ("table_half_xy", C.c_double * 2),
+        ("punish_action", C.c_int32), ("terminate_on_self_collision", C.c_int32),
+        ("terminate_on_static_collision", C.c_int32), ("terminate_on_moving_collision", C.c_int32),
+        ("action_punishment_min_threshold", C.c_double), ("action_max_punishment", C.c_double),
+        ("self_max_reward", C.c_double), ("self_max_reward_distance", C.c_double),
+        ("static_max_reward", C.c_double), ("static_max_reward_distance", C.c_double),
+        ("moving_max_reward", C.c_double), ("moving_max_reward_distance", C.c_double),
+        ("low_acc_max_reward", C.c_double), ("low_acc_threshold", C.c_double),
+        ("low_vel_max_reward", C.c_double), ("low_vel_threshold", C.c_double),
+        ("termination_bonus", C.c_double), ("early_termination_punishment", C.c_double),
+        ("collision_distance", C.c_double),
+        ("start_box", (C.c_double * 2) * 3), ("start_min_dist_static", C.c_double),
+        ("start_min_dist_self", C.c_double),
+        ("kinematic_state_sampling_mode", C.c_int32), ("_pad2", C.c_int32),
+        ("kinematic_state_sampling_probability", C.c_double), ("stay_in_state_probability", C.c_double),
+    ]
+
+
+# --------------------------------------------------------------------------------------------
+# env_config handling
+# --------------------------------------------------------------------------------------------
+
+#: README "Training of the backup policy / Space environment" command as an env_config (README.md:74,
+#: train.py:168-309); identical to trained_networks/backup_networks/space/params.json except
+#: ball_machine_mode (False here: plain robot.urdf).
+SPACE_ENV_CONFIG = dict(
+    experiment_name="backup_space", acc_limit_factor=1.0, action_max_punishment=0.4,
+    action_punishment_min_threshold=0.95, closest_point_safety_distance=0.01,
+    collision_avoidance_episode_early_termination_punishment=-15.0,
+    collision_avoidance_episode_termination_bonus=15.0,
+    collision_avoidance_kinematic_state_sampling_mode=True,
+    collision_avoidance_kinematic_state_sampling_probability=0.7,
+    collision_avoidance_low_acceleration_max_reward=0.0, collision_avoidance_low_acceleration_threshold=1.0,
+    collision_avoidance_low_velocity_max_reward=0.0, collision_avoidance_low_velocity_threshold=1.0,
+    collision_avoidance_mode=True, collision_avoidance_moving_obstacles_max_reward_distance=0.6,
+    collision_avoidance_moving_obstacles_max_reward=3.0, collision_avoidance_self_collision_max_reward_distance=0.05,
+    collision_avoidance_self_collision_max_reward=1.0, collision_avoidance_static_obstacles_max_reward_distance=0.1,
+    collision_avoidance_static_obstacles_max_reward=1.0, collision_avoidance_stay_in_state_probability=0.3,
+    collision_check_time=0.033, episodes_per_simulation_reset=4000, jerk_limit_factor=1.0,
+    obs_planet_size_per_planet=2, obstacle_scene=5, planet_mode=True,
+    planet_one_center=[-0.1, 0.0, 0.8], planet_one_euler_angles=[0.35, 0, 0], planet_one_period=5.0,
+    planet_one_radius_xy=[0.65, 0.8], planet_two_center=[-0.1, 0, 0.8], planet_two_euler_angles=[-0.35, 0, 0],
+    planet_two_radius_xy=[0.75, 0.8], planet_two_time_shift=-2.0, pos_limit_factor=1.0, punish_action=True,
+    robot_scene=0, solver_iterations=50, starting_point_cartesian_range_scene=1,
+    terminate_on_collision_with_moving_obstacle=True, terminate_on_collision_with_static_obstacle=True,
+    terminate_on_self_collision=True, trajectory_duration=2.0, trajectory_time_step=0.1,
+    use_controller_target_velocities=True, vel_limit_factor=1.0,
+)
+
+#: README ball-environment command as env_config (README.md "Ball environment").
+BALL_ENV_CONFIG = dict(
+    {k: v for k, v in SPACE_ENV_CONFIG.items() if not k.startswith("planet_") and k != "obs_planet_size_per_planet"},
+    experiment_name="backup_ball", moving_object_sphere_center=[0, 0, 0.5], moving_object_sphere_radius=2.5,
+    moving_object_sphere_height_min_max=[-0.5, 0.5], moving_object_sphere_angle_min_max=[0, 6.2831],
+    moving_object_speed_meter_per_second=6.0, moving_object_check_invalid_target_link_point_positions=True,
+    moving_object_random_initial_position=True, use_moving_objects=True,
+)
+
+# constructor defaults of the reference for the keys this path reads (base.py:85-207, rewards.py:26-54,409-417,
+# obs.py:48, actions.py:29-44)
+_DEFAULTS = dict(
+    pos_limit_factor=1, vel_limit_factor=1, acc_limit_factor=1, jerk_limit_factor=1,
+    trajectory_duration=8.0, trajectory_time_step=0.1, robot_scene=0, obstacle_scene=0,
+    closest_point_safety_distance=0.1, starting_point_cartesian_range_scene=0, collision_check_time=None,
+    use_moving_objects=False, planet_mode=False, planet_one_center=None, planet_one_radius_xy=None,
+    planet_one_euler_angles=None, planet_one_period=None, planet_two_center=None, planet_two_radius_xy=None,
+    planet_two_euler_angles=None, planet_two_period=None, planet_two_time_shift=None,
+    ball_machine_mode=False, terminate_on_self_collision=False, terminate_on_collision_with_static_obstacle=False,
+    terminate_on_collision_with_moving_obstacle=False, collision_avoidance_mode=False,
+    collision_avoidance_kinematic_state_sampling_mode=False,
+    collision_avoidance_kinematic_state_sampling_probability=1.0, collision_avoidance_stay_in_state_probability=0.3,
+    collision_avoidance_new_state_sample_time_range=None, target_link_offset=None, target_link_name=None,
+    obs_planet_size_per_planet=1, punish_action=False, action_punishment_min_threshold=0.9,
+    action_max_punishment=1.0, collision_avoidance_self_collision_max_reward=0.0,
+    collision_avoidance_self_collision_max_reward_distance=0.05, collision_avoidance_static_obstacles_max_reward=0.0,
+    collision_avoidance_static_obstacles_max_reward_distance=0.1, collision_avoidance_moving_obstacles_max_reward=0.0,
+    collision_avoidance_moving_obstacles_max_reward_distance=0.30,
+    collision_avoidance_low_acceleration_max_reward=1.0, collision_avoidance_low_acceleration_threshold=0.1,
+    collision_avoidance_low_velocity_max_reward=1.0, collision_avoidance_low_velocity_threshold=0.1,
+    collision_avoidance_episode_termination_bonus=0, collision_avoidance_episode_early_termination_punishment=-0,
+    normalize_reward_to_frequency=False, action_mapping_factor=1.0, action_preprocessing_function=None,
+    moving_object_sequence=0, moving_object_sphere_center=None, moving_object_sphere_radius=None,
+    moving_object_sphere_height_min_max=None, moving_object_sphere_angle_min_max=None,
+    moving_object_speed_meter_per_second=1.0, moving_object_aim_at_current_robot_position=False,
+    moving_object_check_invalid_target_link_point_positions=False, moving_object_random_initial_position=False,
+    target_point_cartesian_range_scene=0,
+)
+
+# features of the reference outside the hot-path scope ("out of scope"/"next")
+_UNSUPPORTED_TRUE = ("use_real_robot", "use_target_points", "check_braking_trajectory_collisions",
+                     "check_braking_trajectory_torque_limits", "ball_machine_mode", "use_gui", "render_video",
+                     "risk_check_initial_backup_trajectory", "risk_store_ground_truth", "static_robot",
+                     "moving_object_aim_at_current_robot_position", "normalize_reward_to_frequency",
+                     "obstacle_use_computed_actual_values", "always_use_collision_avoidance_starting_point_sampling")
+_UNSUPPORTED_NOT_NONE = ("human_network_checkpoint", "risk_config", "risk_config_dir",
+                         "collision_avoidance_new_state_sample_time_range", "action_preprocessing_function",
+                         "target_link_name")
+
+
+def _cfg(config, key):
+    """config[key], falling back to the reference constructor's default when absent or None."""
+    value = config.get(key)
+    return _DEFAULTS.get(key) if value is None else value
+
+
+def validate_env_config(config):
+    """Reject reference options the batched path does not implement (loudly, never silently)."""
+    if "experiment_name" not in config:
+        raise TypeError("__init__() missing 1 required positional argument: 'experiment_name'")  # base.py:86
+    for k in _UNSUPPORTED_TRUE:
+        if config.get(k):
+            raise NotImplementedError("env_config[%r]=%r is outside the batched hot path" % (k, config[k]))
+    for k in _UNSUPPORTED_NOT_NONE:
+        if config.get(k) is not None:
+            raise NotImplementedError("env_config[%r]=%r is outside the batched hot path" % (k, config[k]))
+    if not config.get("collision_avoidance_mode", False):
+        raise NotImplementedError("only SafeMotionsEnvCollisionAvoidance (collision_avoidance_mode=True) is "
+                                  "implemented; the target-point task is SURVEY section 8f row 1")
+    if _cfg(config, "robot_scene") != 0:
+        raise NotImplementedError("robot_scene=%r: only the single iiwa7 (robot_scene=0)" % config["robot_scene"])
+    if _cfg(config, "obstacle_scene") not in (0, 5):
+        raise NotImplementedError("obstacle_scene=%r: only 0 (none) and 5 (table mesh)" % config["obstacle_scene"])
+    if _cfg(config, "action_mapping_factor") != 1.0:
+        raise NotImplementedError("action_mapping_factor != 1.0")
+    if _cfg(config, "moving_object_sequence") != 0:
+        raise NotImplementedError("moving_object_sequence != 0")
+    if config.get("planet_mode") and config.get("use_moving_objects"):
+        raise NotImplementedError("planet_mode together with use_moving_objects")
+    if config.get("max_resampling_attempts", 0):
+        # base.py:1663 unpacks 4 values from a 2-tuple: the reference itself raises here
+        raise ValueError("max_resampling_attempts > 0 is broken in the reference (base.py:1663)")
+
+
+# --------------------------------------------------------------------------------------------
+# A9: planet orbit tables
+# --------------------------------------------------------------------------------------------
+
+def quaternion_from_euler(rpy):
+    """pybullet.getQuaternionFromEuler: q = qz(yaw) * qy(pitch) * qx(roll), xyzw."""
+    r, p, y = [0.5 * float(a) for a in rpy]
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    return np.array([sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy,
+                     cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy])
+
+
+def quaternion_multiply(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def quaternion_to_matrix(q):
+    x, y, z, w = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def planet_orbit_tables(center, radius_xy, euler_angles, period, update_time_step, rotations_per_period,
+                        default_orn, orbit_interpolation_steps=1000):
+    """Per-update-step pose of a planet: equal arc length per update (ctlp.py:4397-4433).
+
+    Returns (pose[n,7] = global xyz + quaternion xyzw, local_xy[n,2]).
+    """
+    center = np.asarray(center, dtype=np.float64)
+    direction = 1.0
+    if period < 0:
+        period, direction = -period, -1.0
+    theta = np.linspace(0.0, direction * 2 * np.pi, orbit_interpolation_steps)
+    local = np.stack([radius_xy[0] * np.cos(theta), radius_xy[1] * np.sin(theta), np.zeros_like(theta)], axis=1)
+    seg = np.linalg.norm(np.diff(local, axis=0), axis=1)
+    cum = np.concatenate(([0.0], np.cumsum(seg)))
+    t = np.arange(0, period, update_time_step)
+    idx = np.searchsorted(cum, t / period * cum[-1])
+    orn_shift = quaternion_from_euler(euler_angles)
+    rot_shift = quaternion_to_matrix(orn_shift)
+    pos = center + local[idx] @ rot_shift.T
+    n = len(t)
+    quat = np.tile(np.asarray(default_orn, dtype=np.float64), (n, 1))
+    if rotations_per_period:
+        z_rot = direction * t / period * 2 * np.pi * rotations_per_period
+        for i in range(n):
+            q = quaternion_from_euler([0.0, 0.0, z_rot[i]])
+            if tuple(default_orn) != (0, 0, 0, 1):
+                q = quaternion_multiply(default_orn, q)
+            if tuple(orn_shift) != (0, 0, 0, 1):
+                q = quaternion_multiply(orn_shift, q)
+            quat[i] = q
+    return np.ascontiguousarray(np.concatenate([pos, quat], axis=1)), np.ascontiguousarray(local[idx, :2])
+
+
+# --------------------------------------------------------------------------------------------
+# scene builder
+# --------------------------------------------------------------------------------------------
+
+def _bounding_sphere(v):
+    c = 0.5 * (v.min(axis=0) + v.max(axis=0))
+    return c, float(np.linalg.norm(v - c, axis=1).max())
+
+
+class SceneBundle:
+    """Owns the numpy buffers the ``smr_scene_t`` points into."""
+
+    def __init__(self):
+        self.struct = Scene()
+        self._keep = []
+        self.pieces = []
+        self.verts = None
+        self.env_config = None
+
+    def pointer(self):
+        return C.byref(self.struct)
+
+    @property
+    def obs_size(self):
+        return int(self.struct.obs_size)
+
+
+def joint_limits(config, assets):
+    """A5: scene.py:350-371 (URDF +- safety buffer) and :441-455 (factors, jerk = min(2 a/dt, max_jerk))."""
+    dt = float(_cfg(config, "trajectory_time_step"))
+    pos_lo = (assets["robot_lower"] + JOINT_LIMITS_SAFETY_BUFFER_IIWA) * _cfg(config, "pos_limit_factor")
+    pos_hi = (assets["robot_upper"] - JOINT_LIMITS_SAFETY_BUFFER_IIWA) * _cfg(config, "pos_limit_factor")
+    vel = assets["robot_velocity"] * _cfg(config, "vel_limit_factor")
+    acc = np.array(MAX_ACCELERATION_IIWA) * _cfg(config, "acc_limit_factor")
+    jerk = np.array([min(2 * acc[i] / dt, MAX_JERK_IIWA[i]) * _cfg(config, "jerk_limit_factor") for i in range(NJ)])
+    return pos_lo, pos_hi, vel, acc, jerk
+
+
+def _link_mask(names):
+    mask = 0
+    for n in names:
+        mask |= 1 << int(n.rsplit("_", 1)[1])
+    return mask
+
+
+def build_scene(env_config, collision_checks_per_step=None, contact_distance=BULLET_CONTACT_BREAKING_THRESHOLD,
+                auto_reset=True, assets_path=_DATA):
+    """Build the scene description for ``Env(**env_config)`` of the reference (train.py:620).
+
+    collision_checks_per_step: N samples of the moving-obstacle contact latch per step.  Default:
+    ``round(max(1, dt / collision_check_time))`` (ctlp.py:99-103; 3 for the README configs), or 1 when
+    ``collision_check_time`` is absent.  N=24 reproduces the reference's 1/240 s contact cadence
+    (ctlp.py:2632-2637).
+    """
+    config = dict(env_config)
+    validate_env_config(config)
+    assets = np.load(assets_path)
+    b = SceneBundle()
+    b.env_config = config
+    s = b.struct
+    s.version = SCENE_VERSION
+
+    dt = float(_cfg(config, "trajectory_time_step"))
+    s.dt = dt
+    s.episode_steps = int(round(float(_cfg(config, "trajectory_duration")) / dt))      # tm.py:87,189
+    s.updates_per_step = int(round(dt / SIM_TIME_STEP))                                 # base.py:755
+    if collision_checks_per_step is None:
+        cct = _cfg(config, "collision_check_time")
+        collision_checks_per_step = 1 if cct is None else int(round(max(1, dt / cct)))  # ctlp.py:99-103
+    if collision_checks_per_step < 1 or s.updates_per_step % collision_checks_per_step:
+        raise ValueError("collision_checks_per_step=%d must divide the %d obstacle updates per step"
+                         % (collision_checks_per_step, s.updates_per_step))
+    s.collision_checks_per_step = int(collision_checks_per_step)
+    s.auto_reset = int(bool(auto_reset))
+
+    pos_lo, pos_hi, vel, acc, jerk = joint_limits(config, assets)
+    for j in range(NJ):
+        s.pos_lo[j], s.pos_hi[j], s.vel_max[j], s.acc_max[j], s.jerk_max[j] = pos_lo[j], pos_hi[j], vel[j], acc[j], jerk[j]
+        for c in range(3):
+            s.joint_xyz[j][c] = assets["robot_joint_xyz"][j][c]
+            s.joint_axis[j][c] = assets["robot_joint_axis"][j][c]
+    offset = _cfg(config, "target_link_offset")
+    if offset is None:
+        offset = [0, 0, 0.126]                                                           # scene.py:203-204
+    for c in range(3):
+        s.base_xyz[c] = assets["robot_base_xyz"][c]
+        s.ee_offset[c] = offset[c]
+
+    # ---- geometry: pieces ----
+    margin = float(assets["urdf_collision_margin"])
+    vert_blocks, pieces = [], []
+
+    def add_piece(v):
+        begin = sum(len(x) for x in vert_blocks)
+        vert_blocks.append(np.asarray(v, dtype=np.float64))
+        c, r = _bounding_sphere(vert_blocks[-1])
+        pieces.append((begin, len(v), c, r, margin))
+        return len(pieces) - 1
+
+    lo = assets["link_offsets"]
+    for k in range(NLINK):
+        s.link_piece[k] = add_piece(assets["link_verts"][lo[k]:lo[k + 1]])
+
+    closest_point_active = ["iiwa_link_%d" % i for i in range(2, 8)]                    # ctlp.py:579-581
+    s.n_static = 0
+    s.static_link_mask = 0
+    if _cfg(config, "obstacle_scene") == 5:
+        # table: Bullet box of half extents h has the implicit core h - margin plus the margin
+        half = 0.5 * assets["table_box_size"] - margin
+        corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+        s.static_piece[0] = add_piece(assets["table_box_center"] + corners * half)
+        s.n_static = 1
+        observed = ["iiwa_link_%d" % i for i in range(1, 8)]                            # ctlp.py:2419-2434
+        s.static_link_mask = _link_mask([n for n in observed if n in closest_point_active])
+        s.table_half_xy[0], s.table_half_xy[1] = 0.6, 0.8                               # ctlp.py:1901-1902
+    s.plane_z = -0.94                                                                    # scene.py:172
+
+    # _closest_point_maximum_relevant_distance, ctlp.py:354-366 with rewards.py:81-93
+    safety = float(_cfg(config, "closest_point_safety_distance"))
+    rmax = -1.0
+    if _cfg(config, "collision_avoidance_self_collision_max_reward") != 0:
+        rmax = float(_cfg(config, "collision_avoidance_self_collision_max_reward_distance"))
+    if _cfg(config, "collision_avoidance_static_obstacles_max_reward") != 0 and \
+            float(_cfg(config, "collision_avoidance_static_obstacles_max_reward_distance")) > rmax:
+        rmax = float(_cfg(config, "collision_avoidance_static_obstacles_max_reward_distance"))
+    if rmax == -1.0:
+        s.static_max_distance = safety + 0.002
+    else:
+        if rmax <= safety:
+            raise ValueError("reward_maximum_relevant_distance {} needs to be greater than "
+                             "closest_point_safety_distance {}".format(rmax, safety))        # ctlp.py:361-364
+        s.static_max_distance = rmax + 0.002
+
+    # ---- moving obstacles ----
+    moving_reward = float(_cfg(config, "collision_avoidance_moving_obstacles_max_reward"))
+    s.moving_max_distance = 0.001 if moving_reward == 0 else \
+        float(_cfg(config, "collision_avoidance_moving_obstacles_max_reward_distance"))  # rewards.py:142-145
+    s.contact_distance = float(contact_distance)
+    s.contact_link_mask = (1 << NLINK) - 1
+    s.n_planets = 0
+    s.obs_planet_size_per_planet = int(_cfg(config, "obs_planet_size_per_planet"))
+    s.obs_num_planets = 0
+    s.use_ball = 0
+    obs_size = 3 * NJ                                                                    # obs.py:54,108
+    if config.get("planet_mode"):
+        s.moving_link_mask = _link_mask(["iiwa_link_%d" % i for i in range(3, 8)])      # scene.py:288-290
+        update_time_step = dt / s.updates_per_step                                       # ctlp.py:97
+        one_center = config.get("planet_one_center")
+        two_center = config.get("planet_two_center")
+        one_period = _cfg(config, "planet_one_period") or 5.0                            # scene.py:267-268
+        specs = []
+        if one_center is not None:                                                       # ctlp.py:726-750
+            specs.append(dict(center=one_center,
+                              radius_xy=config.get("planet_one_radius_xy") or [0.65, 0.8],
+                              euler=config.get("planet_one_euler_angles") if config.get("planet_one_euler_angles")
+                              is not None else [0.35, 0, 0],
+                              period=one_period, rotations=1, default_orn=quaternion_from_euler([0, 0, -np.pi / 2]),
+                              verts=assets["iss_verts"] * 0.6, offsets=assets["iss_offsets"], time_shift=None))
+        if two_center is not None:                                                       # ctlp.py:751-776
+            time_shift = config.get("planet_two_time_shift") if one_center is not None else None  # scene.py:276
+            period2 = one_period if time_shift is not None else (config.get("planet_two_period") or 5.0)
+            specs.append(dict(center=two_center,
+                              radius_xy=config.get("planet_two_radius_xy") or [0.75, 0.8],
+                              euler=config.get("planet_two_euler_angles") if config.get("planet_two_euler_angles")
+                              is not None else [-0.35, 0, 0],
+                              period=period2, rotations=4, default_orn=np.array([0.0, 0.0, 0.0, 1.0]),
+                              verts=assets["asteroid_verts"], offsets=assets["asteroid_offsets"],
+                              time_shift=time_shift))
+        if len(specs) > MAX_PLANETS:
+            raise ValueError("too many planets")
+        for p, sp in enumerate(specs):
+            pose, local = planet_orbit_tables(sp["center"], sp["radius_xy"], sp["euler"], sp["period"],
+                                              update_time_step, sp["rotations"], sp["default_orn"])
+            b._keep += [pose, local]
+            pl = s.planet[p]
+            first = None
+            for i in range(len(sp["offsets"]) - 1):
+                idx = add_piece(sp["verts"][sp["offsets"][i]:sp["offsets"][i + 1]])
+                first = idx if first is None else first
+            pl.piece_begin, pl.piece_count = first, len(sp["offsets"]) - 1
+            pl.n_orbit = len(pose)
+            pl.coupled = 0
+            pl.index_shift = 0
+            if sp["time_shift"]:                                                         # ctlp.py:778-779 (truthy)
+                pl.index_shift = int(pl.n_orbit * sp["time_shift"] / abs(sp["period"]))  # ctlp.py:4435-4437
+                pl.coupled = 1
+            elif sp["time_shift"] is not None:
+                # time_shift == 0: the reference computes index_shift 0 but never couples the planet -> its
+                # reset leaves current_time_step_index None (ctlp.py:4473) and update() raises
+                raise ValueError("planet_two_time_shift == 0 crashes the reference (ctlp.py:4473,4504)")
+            pl.orbit_pose = pose.ctypes.data_as(C.POINTER(C.c_double))
+            pl.orbit_local = local.ctypes.data_as(C.POINTER(C.c_double))
+            pl.radius_xy[0], pl.radius_xy[1] = sp["radius_xy"][0], sp["radius_xy"][1]
+        s.n_planets = len(specs)
+        if s.n_planets == 2 and s.planet[1].coupled and s.planet[0].n_orbit != s.planet[1].n_orbit:
+            raise ValueError("coupled planets need equal periods")
+        s.obs_num_planets = s.n_planets                                                  # obs.py:93-98
+        if s.n_planets and config.get("planet_two_time_shift") is not None:
+            s.obs_num_planets = 1
+        if s.obs_planet_size_per_planet not in (1, 2, 3):
+            raise ValueError("obs_planet_size_per_planet must be 1, 2 or 3")
+        obs_size += s.obs_num_planets * s.obs_planet_size_per_planet
+        for c, (a, bb) in enumerate([[-0.9, 0.7], [-0.85, 0.85], [0.45, 1.2]]):          # scene.py:283-284
+            s.planet_obs_pos_min[c], s.planet_obs_pos_max[c] = a, bb
+    elif config.get("use_moving_objects"):
+        raise NotImplementedError("ball scene (use_moving_objects) is not wired yet")
+    else:
+        s.moving_link_mask = 0
+
+    s.obs_size = obs_size
+
+    # ---- reward / termination ----
+    s.punish_action = int(bool(_cfg(config, "punish_action")))
+    s.terminate_on_self_collision = int(bool(_cfg(config, "terminate_on_self_collision")))
+    s.terminate_on_static_collision = int(bool(_cfg(config, "terminate_on_collision_with_static_obstacle")))
+    s.terminate_on_moving_collision = int(bool(_cfg(config, "terminate_on_collision_with_moving_obstacle")))
+    s.action_punishment_min_threshold = float(_cfg(config, "action_punishment_min_threshold"))
+    s.action_max_punishment = float(_cfg(config, "action_max_punishment"))
+    s.self_max_reward = float(_cfg(config, "collision_avoidance_self_collision_max_reward"))
+    s.self_max_reward_distance = float(_cfg(config, "collision_avoidance_self_collision_max_reward_distance"))
+    s.static_max_reward = float(_cfg(config, "collision_avoidance_static_obstacles_max_reward"))
+    s.static_max_reward_distance = float(_cfg(config, "collision_avoidance_static_obstacles_max_reward_distance"))
+    s.moving_max_reward = moving_reward
+    s.moving_max_reward_distance = float(_cfg(config, "collision_avoidance_moving_obstacles_max_reward_distance"))
+    s.low_acc_max_reward = float(_cfg(config, "collision_avoidance_low_acceleration_max_reward"))
+    s.low_acc_threshold = float(_cfg(config, "collision_avoidance_low_acceleration_threshold"))
+    s.low_vel_max_reward = float(_cfg(config, "collision_avoidance_low_velocity_max_reward"))
+    s.low_vel_threshold = float(_cfg(config, "collision_avoidance_low_velocity_threshold"))
+    s.termination_bonus = float(_cfg(config, "collision_avoidance_episode_termination_bonus"))
+    s.early_termination_punishment = float(_cfg(config, "collision_avoidance_episode_early_termination_punishment"))
+    s.collision_distance = 0.001                                                         # rewards.py:115,119,153
+
+    # ---- reset ----
+    box = {0: [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]], 1: [[-1.1, 1.1], [-1.1, 1.1], [-0.1, 1.5]],
+           2: [[-0.1, 0.6], [-0.8, 0.8], [-0.1, 1.2]]}.get(_cfg(config, "starting_point_cartesian_range_scene"),
+                                                             [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]])  # ctlp.py:172-183
+    for c in range(3):
+        s.start_box[c][0], s.start_box[c][1] = box[c]
+    s.start_min_dist_static = 0.001                                                      # ctlp.py:1468-1472
+    s.start_min_dist_self = 0.001
+    s.kinematic_state_sampling_mode = int(bool(_cfg(config, "collision_avoidance_kinematic_state_sampling_mode")))
+    s.kinematic_state_sampling_probability = float(_cfg(config, "collision_avoidance_kinematic_state_sampling_probability"))
+    s.stay_in_state_probability = float(_cfg(config, "collision_avoidance_stay_in_state_probability"))
+
+    # ---- finalise geometry buffers ----
+    b.verts = np.ascontiguousarray(np.concatenate(vert_blocks), dtype=np.float64)
+    arr = (Piece * len(pieces))()
+    for i, (begin, count, c, r, m) in enumerate(pieces):
+        arr[i].vert_begin, arr[i].vert_count, arr[i].radius, arr[i].margin = begin, count, r, m
+        for k in range(3):
+            arr[i].center[k] = c[k]
+    b.pieces = arr
+    s.verts = b.verts.ctypes.data_as(C.POINTER(C.c_double))
+    s.pieces = C.cast(arr, C.POINTER(Piece))
+    s.n_verts = len(b.verts)
+    s.n_pieces = len(pieces)
+    return b
