@@ -40,6 +40,10 @@ def lib():
         L.smo_gjk.restype = C.c_double
         L.smo_link_planet_piece_distance.restype = C.c_double
         L.smo_support_vertex_visits.restype = C.c_int64
+        L.smo_vel_upper_a1max.restype = C.c_double
+        L.smo_vel_upper_a1max.argtypes = [C.c_double] * 6
+        L.smo_vel_peak_bruteforce.restype = C.c_double
+        L.smo_vel_peak_bruteforce.argtypes = [C.c_double] * 7
         L.smo_philox_word.restype = C.c_uint32
         L.smo_philox_word.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         _lib = L
@@ -160,3 +164,11 @@ def safe_acc_range_joint(plo, phi, V, A, J, dt, p, v, a):
 
 def philox_word(seed, env, draw):
     return lib().smo_philox_word(seed, env, draw)
+
+
+def vel_upper_a1max(V, A, J, dt, v0, a0):
+    return lib().smo_vel_upper_a1max(V, A, J, dt, v0, a0)
+
+
+def vel_peak_bruteforce(V, A, J, dt, v0, a0, a1):
+    return lib().smo_vel_peak_bruteforce(V, A, J, dt, v0, a0, a1)

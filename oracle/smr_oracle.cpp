@@ -95,9 +95,8 @@ struct Rng {
     }
     double uniform01() { return (double)(next_u32() >> 8) * (1.0 / 16777216.0); }
     double uniform(double lo, double hi) { return lo + uniform01() * (hi - lo); }
-    int randint(int n) {                 // [0, n)
-        int k = (int)(uniform01() * n);
-        return k < n ? k : n - 1;
+    int randint(int n) {                 // [0, n), integer arithmetic so float32 and float64 agree
+        return (int)(((uint64_t)(next_u32() >> 8) * (uint64_t)n) >> 24);
     }
 };
 
@@ -115,28 +114,45 @@ inline double interp_vel(double v0, double a0, double a1, double t, double dt) {
  * A4: range of end-of-step accelerations a1 from which pos/vel/acc/jerk limits remain satisfiable
  * forever (call sites actions.py:97-106,206-211; klimits.PosVelJerkLimitation, source absent).
  * Restated from Kiemel & Kroeger, "Learning Robot Trajectories subject to Kinematic Joint
- * Constraints" (ICRA 2021), Sec. IV, as an exact discrete-time viability test per constraint:
- *   a1 is admissible for the upper velocity (position) limit iff, after the segment a0->a1, the
- *   profile that lowers the acceleration by jerk_max*dt per step (floored at -acc_max) never
- *   exceeds vel_max (pos_hi) before the velocity stops increasing (the joint stops moving up).
- * That braking profile minimises a(t), hence v(t), hence p(t) pointwise, so the test is exact for
- * piecewise-linear accelerations with knots every dt.  The admissible set is an interval; its end
- * is found by bisection.  Lower limits use the mirrored state.
+ * Constraints" (ICRA 2021), Sec. IV, as a discrete-time viability test (accelerations are piecewise
+ * linear with knots every dt, |a| <= A, knot-to-knot change <= D = J dt):
+ *
+ *  velocity (closed form): after the segment a0->a1 the profile that lowers a by D per knot (floor -A)
+ *    minimises v(t) pointwise; a1 is admissible iff its velocity peak stays <= V.  With r the last
+ *    positive knot value the peak is  v0 + (a0+a1) dt/2 + [ramp area]  where the ramp area is
+ *    a1^2/(2J) when the final partial step can use the full jerk (r + A >= D) and a1^2 dt/(2(a1+A))
+ *    when the floor -A cuts it short (only possible for D > A, then a1 itself is the last knot).
+ *  position: a1 is admissible for the upper limit iff the profile that always takes the LOWEST
+ *    velocity-admissible acceleration (so the brake never drives the joint through -V afterwards)
+ *    keeps p <= pos_hi until the joint moves down again; found by bisection over a1 inside the
+ *    velocity-admissible interval.  Lower limits use the mirrored state.
  * violation code bits: 1 velocity, 2 position, 4 empty intersection.
  * ------------------------------------------------------------------------------------------- */
 struct JointLim { double plo, phi, V, A, J, dt; };
 
-const double kVelTolRel = 1e-5;   /* slack on the limits so that a state that sits on a limit */
-const double kPosTolRel = 1e-6;   /* up to rounding is still "feasible"                        */
+/* The range is designed against limit*(1+tol); a state is only REPORTED infeasible when even the most
+ * braking a1 misses the limit by more than the wider report tolerance.  The band between the two absorbs
+ * rounding when a trajectory rides exactly on a limit. */
+const double kVelTolRel = 1e-5, kVelReportTolRel = 3e-5;
+const double kPosTolRel = 1e-6, kPosReportTolRel = 4e-6;   /* relative to (pos_hi - pos_lo) */
 const int kBrakeMaxSteps = 4096;
+const double kNoBound = 1e300;
 
-inline double seg_vmax(double v0, double a0, double a1, double dt) {
-    double m = v0 + 0.5 * (a0 + a1) * dt;
-    if (a0 > 0 && a1 < 0) {
-        double tau = dt * a0 / (a0 - a1);
-        m = std::max(m, v0 + 0.5 * a0 * tau);
+/* largest a1 (unclamped) for which the velocity never exceeds Vlim; -kNoBound: none exists */
+double vel_upper_a1max(double v0, double a0, double Vlim, const JointLim &L) {
+    const double dt = L.dt, D = L.J * dt;
+    double c = Vlim - v0 - 0.5 * a0 * dt;                 /* head room if the segment ends with a1 = 0 */
+    if (c >= 0) {
+        double x = L.J * (-0.5 * dt + std::sqrt(0.25 * dt * dt + 2.0 * c / L.J));   /* ramp at full jerk */
+        if (D > L.A) {
+            double K = 2.0 * c / dt;                       /* ramp cut short by the floor -A */
+            double xa = ((K - L.A) + std::sqrt((L.A - K) * (L.A - K) + 8.0 * K * L.A)) / 4.0;
+            if (xa < D - L.A) x = xa;
+        }
+        return x;
     }
-    return m;
+    if (a0 > 0 && Vlim - v0 > 0) return a0 - a0 * a0 * dt / (2.0 * (Vlim - v0));   /* peak inside the segment */
+    return -kNoBound;
 }
 
 inline double seg_pmax(double p0, double v0, double a0, double a1, double dt) {
@@ -157,26 +173,14 @@ inline double seg_pmax(double p0, double v0, double a0, double a1, double dt) {
     return m;
 }
 
-bool vel_upper_ok(double v0, double a0, double a1, double Vlim, const JointLim &L) {
-    if (seg_vmax(v0, a0, a1, L.dt) > Vlim) return false;
-    double v = v0 + 0.5 * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
-    for (int it = 0; it < kBrakeMaxSteps; ++it) {
-        if (a <= 0) return true;
-        double an = std::max(a - D, -L.A);
-        if (seg_vmax(v, a, an, L.dt) > Vlim) return false;
-        v += 0.5 * (a + an) * L.dt;
-        a = an;
-    }
-    return false;
-}
-
-bool pos_upper_ok(double p0, double v0, double a0, double a1, double Plim, const JointLim &L) {
+bool pos_upper_ok(double p0, double v0, double a0, double a1, double Plim, double Vlim, const JointLim &L) {
     if (seg_pmax(p0, v0, a0, a1, L.dt) > Plim) return false;
     double p = interp_pos(p0, v0, a0, a1, L.dt, L.dt);
     double v = v0 + 0.5 * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
     for (int it = 0; it < kBrakeMaxSteps; ++it) {
         if (v <= 0 && a <= 0) return true;
-        double an = std::max(a - D, -L.A);
+        double floor_v = -vel_upper_a1max(-v, -a, Vlim, L);         /* lowest a that can still avoid -V */
+        double an = std::max(std::max(a - D, -L.A), std::min(floor_v, std::min(a + D, L.A)));
         if (seg_pmax(p, v, a, an, L.dt) > Plim) return false;
         p = interp_pos(p, v, a, an, L.dt, L.dt);
         v += 0.5 * (a + an) * L.dt;
@@ -186,10 +190,10 @@ bool pos_upper_ok(double p0, double v0, double a0, double a1, double Plim, const
 }
 
 template <class Pred>
-double upper_end(Pred ok, double lo, double hi, bool &violated) {
-    violated = false;
+double upper_end(Pred ok, double lo, double hi, bool &infeasible) {
+    infeasible = false;
     if (ok(hi)) return hi;
-    if (!ok(lo)) { violated = true; return lo; }
+    if (!ok(lo)) { infeasible = true; return lo; }
     for (int it = 0; it < 60; ++it) {
         double mid = 0.5 * (lo + hi);
         if (ok(mid)) lo = mid; else hi = mid;
@@ -201,25 +205,46 @@ void safe_acc_range_joint(const JointLim &L, double p, double v, double a, doubl
     double D = L.J * L.dt;
     double blo = std::max(-L.A, a - D), bhi = std::min(L.A, a + D);
     if (blo > bhi) { blo = bhi = std::min(std::max(a, -L.A), L.A); }
-    double Vlim = L.V * (1.0 + kVelTolRel);
-    double ptol = kPosTolRel * (L.phi - L.plo);
-    bool viol;
+    const double Vlim = L.V * (1.0 + kVelTolRel), Vrep = L.V * (1.0 + kVelReportTolRel);
+    const double ptol = kPosTolRel * (L.phi - L.plo), prep = kPosReportTolRel * (L.phi - L.plo);
     code = 0;
-    double uv = upper_end([&](double a1) { return vel_upper_ok(v, a, a1, Vlim, L); }, blo, bhi, viol);
-    if (viol) code |= 1;
-    double up = upper_end([&](double a1) { return pos_upper_ok(p, v, a, a1, L.phi + ptol, L); }, blo, bhi, viol);
-    if (viol) code |= 2;
-    double lv = -upper_end([&](double a1) { return vel_upper_ok(-v, -a, a1, Vlim, L); }, -bhi, -blo, viol);
-    if (viol) code |= 1;
-    double lp = -upper_end([&](double a1) { return pos_upper_ok(-p, -v, -a, a1, -L.plo + ptol, L); }, -bhi, -blo, viol);
-    if (viol) code |= 2;
-    hi = std::min(uv, up);
-    lo = std::max(lv, lp);
+    /* velocity-admissible interval */
+    double uv = vel_upper_a1max(v, a, Vlim, L), lv = -vel_upper_a1max(-v, -a, Vlim, L);
+    if (uv < blo) { if (vel_upper_a1max(v, a, Vrep, L) < blo) code |= 1; uv = blo; }
+    if (lv > bhi) { if (-vel_upper_a1max(-v, -a, Vrep, L) > bhi) code |= 1; lv = bhi; }
+    double vlo = std::max(blo, lv), vhi = std::min(bhi, uv);
+    if (vlo > vhi) { code |= 4; vlo = vhi = 0.5 * (vlo + vhi); }
+    /* position inside it */
+    bool inf;
+    double up = upper_end([&](double a1) { return pos_upper_ok(p, v, a, a1, L.phi + ptol, Vlim, L); }, vlo, vhi, inf);
+    if (inf && !pos_upper_ok(p, v, a, vlo, L.phi + prep, Vlim, L)) code |= 2;
+    double lp = -upper_end([&](double a1) { return pos_upper_ok(-p, -v, -a, a1, -L.plo + ptol, Vlim, L); }, -vhi, -vlo, inf);
+    if (inf && !pos_upper_ok(-p, -v, -a, -vhi, -L.plo + prep, Vlim, L)) code |= 2;
+    hi = up;
+    lo = lp;
     if (lo > hi) {
         code |= 4;
         double mid = 0.5 * (lo + hi);
-        lo = hi = std::min(std::max(mid, blo), bhi);
+        lo = hi = std::min(std::max(mid, vlo), vhi);
     }
+}
+
+/* brute force for the tests: velocity peak of the "lower a by D per knot" profile after a0 -> a1 */
+double vel_peak_bruteforce(double v0, double a0, double a1, const JointLim &L) {
+    auto seg_vmax = [&](double v, double x0, double x1) {
+        double m = v + 0.5 * (x0 + x1) * L.dt;
+        if (x0 > 0 && x1 < 0) m = std::max(m, v + 0.5 * x0 * (L.dt * x0 / (x0 - x1)));
+        return m;
+    };
+    double peak = seg_vmax(v0, a0, a1);
+    double v = v0 + 0.5 * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
+    for (int it = 0; it < kBrakeMaxSteps && a > 0; ++it) {
+        double an = std::max(a - D, -L.A);
+        peak = std::max(peak, seg_vmax(v, a, an));
+        v += 0.5 * (a + an) * L.dt;
+        a = an;
+    }
+    return peak;
 }
 
 /* ------------------------------------------------------------------------------------------- *
@@ -331,8 +356,9 @@ static V3 simplex_closest(V3 w[4], int &n) {
  * the search stops and a lower bound > cutoff is returned. */
 double gjk_distance(const Hull &A, const Hull &B, double cutoff) {
     V3 w[4];
-    int n = 0;
     V3 v = apply(A.X, {A.v[0], A.v[1], A.v[2]}) - apply(B.X, {B.v[0], B.v[1], B.v[2]});
+    w[0] = v;                       /* the start point is a point of A - B: it seeds the simplex */
+    int n = 1;
     double vv = dot(v, v);
     for (int it = 0; it < 128; ++it) {
         if (vv < 1e-24) return 0.0;
@@ -847,6 +873,14 @@ void smo_safe_acc_range_joint(double plo, double phi, double V, double A, double
     int c;
     safe_acc_range_joint({plo, phi, V, A, J, dt}, p, v, a, *lo, *hi, c);
     *code = c;
+}
+
+/* closed-form velocity bound and the brute-force peak it must reproduce (tests only) */
+double smo_vel_upper_a1max(double V, double A, double J, double dt, double v0, double a0) {
+    return vel_upper_a1max(v0, a0, V, {0, 0, V, A, J, dt});
+}
+double smo_vel_peak_bruteforce(double V, double A, double J, double dt, double v0, double a0, double a1) {
+    return vel_peak_bruteforce(v0, a0, a1, {0, 0, V, A, J, dt});
 }
 
 /* distance between two vertex clouds under rigid transforms (R row-major 3x3, t) */

@@ -138,15 +138,33 @@ __device__ __forceinline__ float interp_vel(float v0, float a0, float a1, float 
 }
 
 // ---------------------------------------------------------------------------------------------
-// A4: safe acceleration range (klimits call sites actions.py:97-106,206-211).  Exact discrete-time
-// viability test per limit + bisection; see DESIGN.md "safe acceleration range".
+// A4: safe acceleration range (klimits call sites actions.py:97-106,206-211; Kiemel & Kroeger 2021).
+// Velocity limits in closed form, position limits by bisection over a velocity-aware braking
+// profile; see DESIGN.md "safe acceleration range".  Accelerations are piecewise linear with knots
+// every dt, |a| <= A, knot-to-knot change <= D = J dt.
 // ---------------------------------------------------------------------------------------------
 struct JointLim { float plo, phi, V, A, J, dt; };
 
-__device__ __forceinline__ float seg_vmax(float v0, float a0, float a1, float dt) {
-    float m = v0 + 0.5f * (a0 + a1) * dt;
-    if (a0 > 0.f && a1 < 0.f) m = fmaxf(m, v0 + 0.5f * a0 * (dt * a0 / (a0 - a1)));
-    return m;
+constexpr float kNoBound = 3.0e38f;
+
+// largest end acceleration a1 (unclamped) that keeps v <= Vlim forever; -kNoBound if none exists.
+// c = head room when the segment ends with a1 = 0.  For a1 > 0 the profile that lowers a by D per knot
+// peaks at v1 + a1^2/(2J) (full-jerk ramp) or v1 + a1^2 dt/(2(a1+A)) when the floor -A cuts the ramp
+// short (only if D > A); for a1 < 0 with a0 > 0 the peak lies inside the first segment.
+__device__ __forceinline__ float vel_upper_a1max(float v0, float a0, float Vlim, const JointLim &L) {
+    const float dt = L.dt, D = L.J * dt;
+    const float c = Vlim - v0 - 0.5f * a0 * dt;
+    if (c >= 0.f) {
+        float x = L.J * (-0.5f * dt + sqrtf(0.25f * dt * dt + 2.0f * c / L.J));
+        if (D > L.A) {
+            float K = 2.0f * c / dt;
+            float xa = ((K - L.A) + sqrtf((L.A - K) * (L.A - K) + 8.0f * K * L.A)) * 0.25f;
+            if (xa < D - L.A) x = xa;
+        }
+        return x;
+    }
+    if (a0 > 0.f && Vlim - v0 > 0.f) return a0 - a0 * a0 * dt / (2.0f * (Vlim - v0));
+    return -kNoBound;
 }
 
 __device__ __forceinline__ float seg_pmax(float p0, float v0, float a0, float a1, float dt) {
@@ -163,26 +181,17 @@ __device__ __forceinline__ float seg_pmax(float p0, float v0, float a0, float a1
     return m;
 }
 
-__device__ inline bool vel_upper_ok(float v0, float a0, float a1, float Vlim, const JointLim &L) {
-    if (seg_vmax(v0, a0, a1, L.dt) > Vlim) return false;
-    float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
-    for (int it = 0; it < 4096; ++it) {
-        if (a <= 0.f) return true;
-        float an = fmaxf(a - D, -L.A);
-        if (seg_vmax(v, a, an, L.dt) > Vlim) return false;
-        v += 0.5f * (a + an) * L.dt;
-        a = an;
-    }
-    return false;
-}
-
-__device__ inline bool pos_upper_ok(float p0, float v0, float a0, float a1, float Plim, const JointLim &L) {
+// does the joint stay below Plim if, after a0 -> a1, it always takes the lowest acceleration that the
+// lower velocity limit still allows?
+__device__ inline bool pos_upper_ok(float p0, float v0, float a0, float a1, float Plim, float Vlim, const JointLim &L) {
     if (seg_pmax(p0, v0, a0, a1, L.dt) > Plim) return false;
     float p = interp_pos(p0, v0, a0, a1, L.dt, L.dt);
-    float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1, D = L.J * L.dt;
+    float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1;
+    const float D = L.J * L.dt;
     for (int it = 0; it < 4096; ++it) {
         if (v <= 0.f && a <= 0.f) return true;
-        float an = fmaxf(a - D, -L.A);
+        float floor_v = -vel_upper_a1max(-v, -a, Vlim, L);
+        float an = fmaxf(fmaxf(a - D, -L.A), fminf(floor_v, fminf(a + D, L.A)));
         if (seg_pmax(p, v, a, an, L.dt) > Plim) return false;
         p = interp_pos(p, v, a, an, L.dt, L.dt);
         v += 0.5f * (a + an) * L.dt;
@@ -193,18 +202,15 @@ __device__ inline bool pos_upper_ok(float p0, float v0, float a0, float a1, floa
 
 constexpr int kBisectIters = 30;
 
-// largest a1 in [lo, hi] accepted by the (monotone) predicate; POS selects the position test
-template <bool POS>
-__device__ inline float upper_end(float p, float v, float a, float lim, const JointLim &L, float lo, float hi, bool &violated) {
-    violated = false;
-    bool ok_hi = POS ? pos_upper_ok(p, v, a, hi, lim, L) : vel_upper_ok(v, a, hi, lim, L);
-    if (ok_hi) return hi;
-    bool ok_lo = POS ? pos_upper_ok(p, v, a, lo, lim, L) : vel_upper_ok(v, a, lo, lim, L);
-    if (!ok_lo) { violated = true; return lo; }
+// largest a1 in [lo, hi] accepted by the (monotone) position test
+__device__ inline float pos_upper_end(float p, float v, float a, float Plim, float Vlim, const JointLim &L, float lo, float hi,
+                                      bool &infeasible) {
+    infeasible = false;
+    if (pos_upper_ok(p, v, a, hi, Plim, Vlim, L)) return hi;
+    if (!pos_upper_ok(p, v, a, lo, Plim, Vlim, L)) { infeasible = true; return lo; }
     for (int it = 0; it < kBisectIters; ++it) {
         float mid = 0.5f * (lo + hi);
-        bool ok = POS ? pos_upper_ok(p, v, a, mid, lim, L) : vel_upper_ok(v, a, mid, lim, L);
-        if (ok) lo = mid; else hi = mid;
+        if (pos_upper_ok(p, v, a, mid, Plim, Vlim, L)) lo = mid; else hi = mid;
     }
     return lo;
 }
@@ -213,24 +219,26 @@ __device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v,
     const float D = L.J * L.dt;
     float blo = fmaxf(-L.A, a - D), bhi = fminf(L.A, a + D);
     if (blo > bhi) blo = bhi = fminf(fmaxf(a, -L.A), L.A);
-    const float Vlim = L.V * (1.0f + 1e-5f);
-    const float ptol = 1e-6f * (L.phi - L.plo);
-    bool viol;
+    // design tolerance for the range, wider report tolerance for the violation code (rounding hysteresis)
+    const float Vlim = L.V * (1.0f + 1e-5f), Vrep = L.V * (1.0f + 3e-5f);
+    const float ptol = 1e-6f * (L.phi - L.plo), prep = 4e-6f * (L.phi - L.plo);
     code = 0;
-    float uv = upper_end<false>(0.f, v, a, Vlim, L, blo, bhi, viol);
-    if (viol) code |= 1;
-    float up = upper_end<true>(p, v, a, L.phi + ptol, L, blo, bhi, viol);
-    if (viol) code |= 2;
-    float lv = -upper_end<false>(0.f, -v, -a, Vlim, L, -bhi, -blo, viol);
-    if (viol) code |= 1;
-    float lp = -upper_end<true>(-p, -v, -a, -L.plo + ptol, L, -bhi, -blo, viol);
-    if (viol) code |= 2;
-    hi = fminf(uv, up);
-    lo = fmaxf(lv, lp);
+    float uv = vel_upper_a1max(v, a, Vlim, L), lv = -vel_upper_a1max(-v, -a, Vlim, L);
+    if (uv < blo) { if (vel_upper_a1max(v, a, Vrep, L) < blo) code |= 1; uv = blo; }
+    if (lv > bhi) { if (-vel_upper_a1max(-v, -a, Vrep, L) > bhi) code |= 1; lv = bhi; }
+    float vlo = fmaxf(blo, lv), vhi = fminf(bhi, uv);
+    if (vlo > vhi) { code |= 4; vlo = vhi = 0.5f * (vlo + vhi); }
+    bool inf;
+    float up = pos_upper_end(p, v, a, L.phi + ptol, Vlim, L, vlo, vhi, inf);
+    if (inf && !pos_upper_ok(p, v, a, vlo, L.phi + prep, Vlim, L)) code |= 2;
+    float lp = -pos_upper_end(-p, -v, -a, -L.plo + ptol, Vlim, L, -vhi, -vlo, inf);
+    if (inf && !pos_upper_ok(-p, -v, -a, -vhi, -L.plo + prep, Vlim, L)) code |= 2;
+    hi = up;
+    lo = lp;
     if (lo > hi) {
         code |= 4;
         float mid = 0.5f * (lo + hi);
-        lo = hi = fminf(fmaxf(mid, blo), bhi);
+        lo = hi = fminf(fmaxf(mid, vlo), vhi);
     }
 }
 
@@ -289,23 +297,33 @@ __device__ __forceinline__ Xf quat_pose(const SMR_GLOBAL float *row) {   // row:
 // triangle / tetrahedron region tests (Ericson, Real-Time Collision Detection, 5.1).
 // ---------------------------------------------------------------------------------------------
 template <bool IDENTITY>
-__device__ __forceinline__ F3 support(const SMR_CONST float4 *verts, int begin, int count, const Xf &X, F3 d) {
+__device__ __forceinline__ F3 support(const SMR_CONST float *verts, int begin, int count, const Xf &X, F3 d) {
     F3 dl = IDENTITY ? d : rot_t(X, d);
     float best = -3.0e38f;
     int bi = 0;
     begin = __builtin_amdgcn_readfirstlane(begin);      // wave-uniform by construction (piece index is uniform)
     count = __builtin_amdgcn_readfirstlane(count);
+    const SMR_CONST float *base = verts + 4 * (size_t)begin;   // one vertex = 4 floats (x, y, z, 0)
 #pragma unroll 4
     for (int i = 0; i < count; ++i) {
-        float4 p = verts[begin + i];
-        float s = fmaf(p.z, dl.z, fmaf(p.y, dl.y, p.x * dl.x));
+        float px = base[4 * i], py = base[4 * i + 1], pz = base[4 * i + 2];
+        float s = fmaf(pz, dl.z, fmaf(py, dl.y, px * dl.x));
         bool gt = s > best;
         best = gt ? s : best;
         bi = gt ? i : bi;
     }
-    float4 p = verts[begin + bi];
-    F3 pl = {p.x, p.y, p.z};
+    F3 pl = {base[4 * bi], base[4 * bi + 1], base[4 * bi + 2]};   // per-lane gather of the winner
     return IDENTITY ? pl : apply(X, pl);
+}
+
+__device__ __forceinline__ DPiece load_piece(const DPiece *pieces, int idx) {
+    static_assert(sizeof(DPiece) == 40, "DPiece is read as 10 dwords");
+    const SMR_CONST int *w = (const SMR_CONST int *)pieces + 10 * (size_t)__builtin_amdgcn_readfirstlane(idx);
+    DPiece P;
+    P.begin = w[0]; P.count = w[1];
+    P.cx = __int_as_float(w[2]); P.cy = __int_as_float(w[3]); P.cz = __int_as_float(w[4]); P.radius = __int_as_float(w[5]);
+    P.margin = __int_as_float(w[6]); P.hx = __int_as_float(w[7]); P.hy = __int_as_float(w[8]); P.hz = __int_as_float(w[9]);
+    return P;
 }
 
 // closest point of triangle (a,b,c) to the origin; mask: bit0 a, bit1 b, bit2 c support it
@@ -355,8 +373,10 @@ __device__ inline bool simplex_solve(F3 &w0, F3 &w1, F3 &w2, F3 &w3, int &n, F3 
             F3 r = f == 0 ? w2 : f == 1 ? w3 : f == 2 ? w1 : w2;
             F3 o = f == 0 ? w3 : f == 1 ? w1 : f == 2 ? w2 : w0;
             F3 nrm = cross(q - p, r - p);
-            float sp = -dot(p, nrm), so = dot(o - p, nrm);
-            bool outside = (sp * so < 0.f) || (fabsf(so) <= 1e-12f);
+            F3 op = o - p;
+            float sp = -dot(p, nrm), so = dot(op, nrm);
+            // a (nearly) flat tetrahedron has no reliable inside: treat the face as a candidate
+            bool outside = (sp * so < 0.f) || (so * so <= 1e-10f * dot(nrm, nrm) * dot(op, op));
             if (outside) {
                 int m3;
                 F3 pt = tri_closest(p, q, r, m3);
@@ -387,7 +407,7 @@ __device__ inline bool simplex_solve(F3 &w0, F3 &w1, F3 &w2, F3 &w3, int &n, F3 
 // XB), margins excluded.  Returns a lower bound > cutoff as soon as one is proven, and the current
 // upper bound as soon as it drops below stop_below (callers only test it against a threshold then).
 template <bool IDENTITY>
-__device__ inline float gjk_distance(const SMR_CONST float4 *verts, const DPiece &A, const Xf &XA, const DPiece &B,
+__device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece &A, const Xf &XA, const DPiece &B,
                                      const Xf &XB, F3 v, float cutoff, float stop_below) {
     F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
     int n = 0;
@@ -417,8 +437,7 @@ __device__ inline float gjk_distance(const SMR_CONST float4 *verts, const DPiece
 template <bool IDENTITY>
 __device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, int pb, const Xf &XB, float cutoff,
                                        float stop_below) {
-    const SMR_CONST DPiece *pieces = (const SMR_CONST DPiece *)S.pieces;
-    const DPiece A = pieces[__builtin_amdgcn_readfirstlane(pa)], B = pieces[__builtin_amdgcn_readfirstlane(pb)];
+    const DPiece A = load_piece(S.pieces, pa), B = load_piece(S.pieces, pb);
     const float margins = A.margin + B.margin;
     F3 cb = apply(XB, F3{B.cx, B.cy, B.cz});
     F3 ca = IDENTITY ? F3{A.cx, A.cy, A.cz} : apply(XA, F3{A.cx, A.cy, A.cz});
@@ -431,7 +450,7 @@ __device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, in
         lb = sqrtf(dot(d, d)) - A.radius - B.radius - margins;
     }
     if (lb > cutoff) return lb;
-    return gjk_distance<IDENTITY>((const SMR_CONST float4 *)S.verts, A, XA, B, XB, d, cutoff + margins, stop_below + margins) - margins;
+    return gjk_distance<IDENTITY>((const SMR_CONST float *)S.verts, A, XA, B, XB, d, cutoff + margins, stop_below + margins) - margins;
 }
 
 __device__ __forceinline__ Xf planet_pose(const DScene &S, int p, int idx) {

@@ -184,11 +184,20 @@ __device__ inline void sample_position(const DScene &S, Rng &rng, float q[SMR_NJ
     }
 }
 
+constexpr int kResetLaneStride = 16;
+
 // env.reset() for the envs in list[0..count): obs.py:144-149 -> base.py:913-1022
 __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
-                                                   const int *__restrict__ count_ptr, int count_fixed, float *__restrict__ obs) {
+                                                   const int *__restrict__ count_ptr, int count_fixed, int lane_stride,
+                                                   float *__restrict__ obs) {
     const DScene &S = *Sp;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // Rejection sampling is a chain of data-dependent loops: lanes of one wave wait for each other, and the
+    // few envs that finish per step would only fill a few dozen wavefronts.  Only every lane_stride-th
+    // lane takes an entry, so the entries spread over lane_stride x more wavefronts (latency, not lane
+    // count, is what bounds this kernel).  A full reset (all B envs) runs dense, lane_stride = 1.
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t % lane_stride) return;
+    const int i = t / lane_stride;
     const int count = count_ptr ? *count_ptr : count_fixed;
     if (i >= count) return;
     const int e = list ? list[i] : i;
@@ -639,8 +648,8 @@ static int launch_reset_list(smr_env *env, float *obs_dev) {
     // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
     LaunchTimer t(env, SMR_K_RESET);
     const int B = env->B;
-    hipLaunchKernelGGL(reset_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st, env->st.done_list,
-                       env->st.done_count, 0, obs_dev);
+    hipLaunchKernelGGL(reset_kernel, dim3(((size_t)B * kResetLaneStride + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+                       env->st.done_list, env->st.done_count, 0, kResetLaneStride, obs_dev);
     SMR_HIP(hipGetLastError());
     return SMR_OK;
 }
@@ -653,8 +662,8 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     const int B = env->B;
     if (!mask_dev) {
         LaunchTimer t(env, SMR_K_RESET);
-        hipLaunchKernelGGL(reset_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st, (const int *)nullptr,
-                           (const int *)nullptr, B, obs_dev);
+        hipLaunchKernelGGL(reset_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+                           (const int *)nullptr, (const int *)nullptr, B, 1, obs_dev);
         SMR_HIP(hipGetLastError());
         return SMR_OK;
     }

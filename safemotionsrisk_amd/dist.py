@@ -1,0 +1,76 @@
+"""Rollout sharding over the GPUs of one node (BASELINE config 5).
+
+Environments are independent, so rank g of G owns the contiguous block [g*B_g, (g+1)*B_g) with its own
+handle, stream and Philox key; there is no collective on the data path of step().  The only exchange is
+the concatenation of the rollout batch: ONE all-gather per step of a packed byte buffer
+    [ obs float32 [B_g][O] | reward float32 [B_g] | done uint8 [B_g] | pad to 16 B ]
+(backend "nccl" is RCCL on ROCm; 7 xGMI links per GPU, so the gather is per-link bound: one call with
+the three arrays packed instead of three).  The reference has no counterpart (Ray actor RPC, train.py:598-648).
+"""
+from __future__ import annotations
+
+
+def shard_range(total, rank, world):
+    """Contiguous block of `total` envs owned by `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class PackedRollout:
+    """obs/reward/done buffers of one shard laid out in a single flat byte tensor."""
+
+    def __init__(self, torch, num_envs, obs_size, device):
+        self.torch, self.B, self.O = torch, int(num_envs), int(obs_size)
+        self.obs_bytes = self.B * self.O * 4
+        self.rew_bytes = self.B * 4
+        raw = self.obs_bytes + self.rew_bytes + self.B
+        self.nbytes = (raw + 15) // 16 * 16
+        self.flat = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+        self.obs, self.reward, self.done = self.views(self.flat)
+
+    def views(self, flat):
+        t = self.torch
+        obs = flat[:self.obs_bytes].view(t.float32).view(self.B, self.O)
+        rew = flat[self.obs_bytes:self.obs_bytes + self.rew_bytes].view(t.float32)
+        done = flat[self.obs_bytes + self.rew_bytes:self.obs_bytes + self.rew_bytes + self.B]
+        return obs, rew, done
+
+
+class ShardedRollout:
+    """step() the local shard, then all-gather (obs, reward, done) of every shard in one collective.
+
+    `env` is any object with num_envs, observation_size, obs/reward/done tensors and step()/reset()
+    (VecSafeMotionsEnv on a GPU).  `group` is a torch.distributed process group (None: default group).
+    """
+
+    def __init__(self, env, group=None, equal_shards=True):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.env, self.group = torch, dist, env, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.local = PackedRollout(torch, env.num_envs, env.observation_size, env.obs.device)
+        # the env writes straight into the packed views: no staging copy before the collective
+        env.obs, env.reward, env.done = self.local.obs, self.local.reward, self.local.done
+        if not equal_shards:
+            raise NotImplementedError("all_gather_into_tensor needs equal shards; pad num_envs to a multiple of world")
+        self.gathered = torch.zeros(self.world * self.local.nbytes, dtype=torch.uint8, device=env.obs.device)
+
+    def _gather(self):
+        self.dist.all_gather_into_tensor(self.gathered, self.local.flat, group=self.group)
+        n = self.local.nbytes
+        return [self.local.views(self.gathered[r * n:(r + 1) * n]) for r in range(self.world)]
+
+    def reset(self):
+        self.env.reset()
+        return self._gather()
+
+    def step(self, action):
+        """action: float32 [B_g, 7] for the local shard.  Returns [(obs, reward, done)] per rank."""
+        self.env.step(action)
+        return self._gather()
+
+    def concatenated(self, parts):
+        t = self.torch
+        return (t.cat([p[0] for p in parts]), t.cat([p[1] for p in parts]), t.cat([p[2] for p in parts]))

@@ -1,0 +1,35 @@
+"""The committed golden vectors are reproduced by the oracle (guards the oracle against silent change)."""
+import os
+
+import numpy as np
+
+from oracle.oracle import OracleEnv
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "space_step.npz")
+
+
+def test_oracle_reproduces_golden_step_vectors(built, space_scene):
+    g = np.load(GOLD)
+    B, T = int(g["B"]), int(g["T"])
+    env = OracleEnv(space_scene, B, seed=int(g["seed"]), num_threads=4)
+    env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], planet_idx=g["planet_idx0"], step_count=g["step_count0"],
+                  moving_hit=g["moving_hit0"])
+    for t in range(T):
+        o, r, d, rs, inf = env.step(g["actions"][t].astype(np.float64))
+        assert np.array_equal(d, g["done"][t]) and np.array_equal(rs, g["reason"][t])
+        assert np.allclose(o, g["obs"][t], atol=1e-7) and np.allclose(r, g["reward"][t], atol=1e-12)
+        assert np.allclose(inf, g["info"][t], atol=1e-12)
+        st = env.get_state()
+        env.set_state(q=st["q"].astype(np.float32), v=st["v"].astype(np.float32), a=st["a"].astype(np.float32),
+                      step_count=np.where(d, 0, st["step_count"]), moving_hit=np.where(d, 0, st["moving_hit"]))
+    assert g["done"].mean() > 0.02 and set(np.unique(g["reason"])) >= {-1, 2, 5}
+
+
+def test_oracle_reproduces_golden_components(built, space_scene):
+    g = np.load(GOLD)
+    env = OracleEnv(space_scene, 1)
+    for i in range(0, 256, 5):
+        assert np.allclose(env.distances(g["comp_q"][i].astype(np.float64), g["comp_idx"][i]), g["comp_dist"][i], atol=1e-12)
+        assert np.allclose(env.fk(g["comp_q"][i].astype(np.float64))[0], g["comp_fk"][i], atol=1e-14)
+        lo, hi, code = env.safe_acc_range(*[g[k][i].astype(np.float64) for k in ("comp_p", "comp_v", "comp_a")])
+        assert np.allclose(lo, g["comp_lo"][i]) and np.allclose(hi, g["comp_hi"][i]) and np.array_equal(code, g["comp_code"][i])

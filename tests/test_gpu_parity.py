@@ -1,0 +1,232 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the float64 oracle and the committed golden
+vectors.  Run on the GPU box: python -m pytest tests -m gpu.
+
+Tolerances (float32 kernels vs float64 oracle, one step from an injected state):
+  FK positions 2e-6 m; distances 2e-5 m; acceleration range 2e-4 of acc_max; obs 3e-4; reward 2e-3;
+  done / termination reason / collision flags: exact, except envs whose oracle distance lies within
+  2e-5 m of a decision threshold (0.001 m collision, 0.02 m contact), which are excluded and counted.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "space_step.npz")
+STATE_KEYS = ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "rng_draws")
+TIE = 2e-5
+
+
+def _env(B, **kw):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
+    kw.setdefault("auto_reset", False)
+    return VecSafeMotionsEnv(B, device=0, **kw, **SPACE_ENV_CONFIG)
+
+
+def _threshold_ties(ora, st):
+    """envs whose raw end-of-step distances sit on a decision threshold (oracle, float64)."""
+    B = len(st["q"])
+    tie = np.zeros(B, dtype=bool)
+    for e in range(B):
+        d = ora.distances(st["q"][e].astype(np.float64), st["planet_idx"][e])
+        tie[e] = abs(d[0] - 0.001) < TIE or abs(d[2] - 0.001) < TIE or abs(d[2] - 0.02) < TIE
+    return tie
+
+
+def test_native_library_is_loaded(built):
+    from safemotionsrisk_amd import lib
+    L = lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libsmr_hip.so" in maps and L.smr_abi_version() == 1
+
+
+def test_components_against_golden(built):
+    g = np.load(GOLD)
+    env = _env(256, seed=0)
+    pos, rot = env.test_fk(g["comp_q"])
+    assert np.abs(pos - g["comp_fk"]).max() < 2e-6
+    d = env.test_distances(g["comp_q"], g["comp_idx"])
+    gd = g["comp_dist"]
+    assert np.abs(d[:, 0] - gd[:, 0]).max() < 2e-5                      # static (table), incl. penetration -0.002
+    assert np.abs(np.maximum(d[:, 2], 0) - gd[:, 2]).max() < 2e-5       # moving; the oracle returns 0 for <= 0 (ctlp.py:3277)
+    safe = np.abs(gd[:, 2] - 0.02) > TIE
+    assert np.array_equal(d[safe, 3], gd[safe, 3])                      # contact flags
+    lo, hi, code = env.test_safe_acc_range(g["comp_p"], g["comp_v"], g["comp_a"])
+    A = np.array(env.scene.struct.acc_max)
+    assert np.abs((lo - g["comp_lo"]) / A).max() < 2e-4 and np.abs((hi - g["comp_hi"]) / A).max() < 2e-4
+    assert np.array_equal(code, g["comp_code"])
+    env.close()
+
+
+def test_step_against_golden(built):
+    import torch
+    g = np.load(GOLD)
+    B, T = int(g["B"]), int(g["T"])
+    env = _env(B, seed=int(g["seed"]))
+    env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], planet_idx=g["planet_idx0"], step_count=g["step_count0"],
+                  moving_hit=g["moving_hit0"])
+    from oracle.oracle import OracleEnv
+    ora = OracleEnv(env.scene, 1)
+    excluded = 0
+    for t in range(T):
+        obs, rew, done, info = env.step(torch.from_numpy(g["actions"][t]).cuda())
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        reason = info["termination_reason"].cpu().numpy()
+        vals = info["values"].cpu().numpy()
+        st = env.get_state()
+        tie = _threshold_ties(ora, st)
+        excluded += int(tie.sum())
+        ok = ~tie
+        assert np.array_equal(done[ok], g["done"][t][ok]) and np.array_equal(reason[ok], g["reason"][t][ok])
+        assert np.abs(obs[ok] - g["obs"][t][ok]).max() < 3e-4
+        assert np.abs(rew[ok] - g["reward"][t][ok]).max() < 2e-3
+        assert np.abs(vals[ok, :3] - g["info"][t][ok, :3]).max() < 2e-5
+        gs = g["state"][t]
+        A = np.array(env.scene.struct.acc_max)
+        assert np.abs(st["q"] - gs[:, :7]).max() < 5e-6 and np.abs(st["v"] - gs[:, 7:14]).max() < 5e-5
+        assert np.abs((st["a"] - gs[:, 14:]) / A).max() < 2e-4
+        # golden protocol: continue from the float32 image of the ORACLE state
+        env.set_state(q=gs[:, :7].astype(np.float32), v=gs[:, 7:14].astype(np.float32), a=gs[:, 14:].astype(np.float32),
+                      step_count=np.where(g["done"][t], 0, st["step_count"]), moving_hit=np.where(g["done"][t], 0, st["moving_hit"]))
+    assert excluded <= 0.01 * B * T
+    env.close()
+
+
+def test_rollout_against_oracle_with_state_injection(built):
+    """4096 envs x 12 steps of uniform random actions; after every step the oracle is restarted from the GPU's
+    float32 state, so each step is a one-step parity check on states the GPU path itself produced."""
+    import torch
+    from oracle.oracle import OracleEnv
+    B, T = 4096, 12
+    env = _env(B, seed=5)
+    env.reset()
+    ora = OracleEnv(env.scene, B, seed=5, num_threads=16)
+    rng = np.random.default_rng(9)
+    mism, excluded, dones = 0, 0, 0
+    for t in range(T):
+        st = env.get_state()
+        ora.set_state(**{k: st[k] for k in STATE_KEYS})
+        act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        o_obs, o_rew, o_done, o_reason, o_info = ora.step(act.astype(np.float64))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        reason = info["termination_reason"].cpu().numpy()
+        bad = (done != o_done) | (reason != o_reason)
+        if bad.any():
+            st1 = env.get_state()
+            tie = _threshold_ties(ora, {k: st1[k][bad] for k in ("q", "planet_idx")})
+            excluded += int(tie.sum())
+            mism += int((~tie).sum())
+        good = ~bad
+        assert np.abs(obs[good] - o_obs[good]).max() < 3e-4
+        assert np.abs(rew[good] - o_rew[good]).max() < 2e-3
+        dones += int(o_done.sum())
+        # envs that finished are re-sampled on the GPU so the rollout keeps all lanes busy
+        if done.any():
+            env.reset(mask=torch.from_numpy(done).cuda())
+    assert mism == 0, "%d unexplained done/reason mismatches" % mism
+    assert excluded <= 5 and dones > 0.2 * B
+    env.close()
+
+
+def test_reset_properties_and_oracle_agreement(built):
+    from oracle.oracle import OracleEnv
+    B = 8192
+    env = _env(B, seed=21)
+    obs = env.reset().cpu().numpy()
+    st = env.get_state()
+    s = env.scene.struct
+    lo, hi = np.array(s.pos_lo), np.array(s.pos_hi)
+    assert np.abs(obs).max() <= 1.0 and obs.shape == (B, 23)
+    assert (st["q"] >= lo - 1e-6).all() and (st["q"] <= hi + 1e-6).all()
+    assert (np.abs(st["v"]) <= np.array(s.vel_max) * 1.0001).all() and (np.abs(st["a"]) <= np.array(s.acc_max) * 1.0001).all()
+    assert (st["step_count"] == 0).all() and ((st["planet_idx"][:, 1] - st["planet_idx"][:, 0]) % 1200 == 720).all()
+    ora = OracleEnv(env.scene, 1)
+    for e in range(0, B, 64):                               # oracle-checked properties on a sample
+        q = st["q"][e].astype(np.float64)
+        assert ora.position_is_valid(q) or abs(ora.distances(q, st["planet_idx"][e])[0] - 0.001) < TIE
+        lo_a, hi_a, code = ora.safe_acc_range(q, st["v"][e].astype(np.float64), st["a"][e].astype(np.float64))
+        assert (code == 0).all()
+        d = ora.distances(q, st["planet_idx"][e])
+        assert d[3] == st["moving_hit"][e] or abs(d[2] - 0.02) < TIE
+    # same seed -> bit-identical states; the float64 oracle with the same Philox streams agrees on almost all envs
+    env2 = _env(B, seed=21)
+    env2.reset()
+    st2 = env2.get_state()
+    assert all(np.array_equal(st[k], st2[k]) for k in STATE_KEYS)
+    ora_b = OracleEnv(env.scene, B, seed=21, num_threads=16)
+    ora_b.reset()
+    ost = ora_b.get_state()
+    same = (ost["rng_draws"] == st["rng_draws"]) & (ost["planet_idx"] == st["planet_idx"]).all(axis=1)
+    assert same.mean() > 0.97
+    assert np.abs(st["q"][same] - ost["q"][same]).max() < 1e-5
+    A = np.array(s.acc_max)
+    assert np.abs((st["a"][same] - ost["a"][same]) / A).max() < 5e-4
+    # planet phases are uniform over the orbit (chi-square on 12 bins, very loose)
+    hist = np.bincount(st["planet_idx"][:, 0] // 100, minlength=12)
+    assert hist.min() > 0.6 * B / 12
+    env.close(); env2.close()
+
+
+def test_full_size_invariants_and_determinism(built):
+    """BASELINE size (65 536 envs, N=3, auto-reset): size-independent properties over 45 steps."""
+    import torch
+    B, T = 65536, 45
+    outs = []
+    for rep in range(2):
+        env = _env(B, seed=3, auto_reset=True)
+        env.reset()
+        s = env.scene.struct
+        gen = torch.Generator(device="cuda"); gen.manual_seed(77)
+        lens = np.zeros(B, dtype=np.int64)
+        n_done, reasons = 0, set()
+        acc = torch.zeros(B, device="cuda")
+        for t in range(T):
+            act = torch.rand((B, 7), device="cuda", generator=gen) * 2 - 1
+            if t % 5 == 0:
+                act = torch.sign(act)                        # bang-bang steps ride the limits
+            obs, rew, done, info = env.step(act)
+            assert float(obs.abs().max()) <= 1.0
+            acc += rew
+            d = done.cpu().numpy().astype(bool)
+            r = info["termination_reason"].cpu().numpy()
+            vals = info["values"].cpu().numpy()
+            lens += 1
+            assert (r[~d] == -1).all() and np.isin(r[d], [2, 4, 5]).all()
+            assert (lens[d] <= 20).all() and (lens[d & (r == 2)] == 20).all()
+            assert (vals[:, 7] == lens).all()
+            # reward bounds: 0.4 + 1 + 1 + 3 (+15) / (-15)
+            rw = rew.cpu().numpy()
+            assert rw.max() <= 5.4 + 15 + 1e-4 and rw.min() >= -15 - 1e-4
+            assert (rw[d & (r == 2)] >= 15 - 1e-4).all() and (rw[d & (r >= 4)] <= 5.4 - 15 + 1e-4).all()
+            lens[d] = 0
+            n_done += int(d.sum()); reasons |= set(r[d].tolist())
+            st = env.get_state() if t % 15 == 14 else None
+            if st is not None:
+                lo, hi = np.array(s.pos_lo), np.array(s.pos_hi)
+                assert np.abs(-1 + 2 * (st["q"] - lo) / (hi - lo)).max() <= 1.001          # obs.py:379
+                assert (np.abs(st["v"]) / np.array(s.vel_max)).max() <= 1.001               # obs.py:389
+                assert (np.abs(st["a"]) / np.array(s.acc_max)).max() <= 1.001               # obs.py:399
+                assert (st["step_count"] == lens).all()
+        assert n_done > B and {2, 5} <= reasons
+        outs.append((acc.cpu().numpy(), env.get_state()))
+        env.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert all(np.array_equal(outs[0][1][k], outs[1][1][k]) for k in STATE_KEYS)
+
+
+def test_profiling_counters(built):
+    import torch
+    env = _env(4096, seed=1, auto_reset=True)
+    env.reset()
+    env.set_profiling(True)
+    act = torch.zeros((4096, 7), device="cuda")
+    for _ in range(5):
+        env.step(act)
+    prof = env.get_profile()
+    assert all(prof[k]["launches"] == 5 for k in ("plan", "collide", "finish", "reset"))
+    assert prof["collide"]["ms"] > 0
+    env.close()

@@ -1,0 +1,148 @@
+"""Pins the oracle's geometry (A6 forward kinematics, GJK distance) with analytic known answers and an
+independent solver.  CPU only."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from oracle import oracle as O
+
+
+def qp_distance(A, B):
+    """Distance between conv(A) and conv(B) as a QP over barycentric weights (SLSQP) - not GJK."""
+    na, nb = len(A), len(B)
+
+    def f(z):
+        d = A.T @ z[:na] - B.T @ z[na:]
+        return d @ d
+
+    def g(z):
+        d = A.T @ z[:na] - B.T @ z[na:]
+        return np.concatenate([2 * A @ d, -2 * B @ d])
+    cons = [dict(type="eq", fun=lambda z: z[:na].sum() - 1, jac=lambda z: np.concatenate([np.ones(na), np.zeros(nb)])),
+            dict(type="eq", fun=lambda z: z[na:].sum() - 1, jac=lambda z: np.concatenate([np.zeros(na), np.ones(nb)]))]
+    z0 = np.concatenate([np.full(na, 1 / na), np.full(nb, 1 / nb)])
+    r = minimize(f, z0, jac=g, bounds=[(0, 1)] * (na + nb), constraints=cons, method="SLSQP",
+                 options=dict(maxiter=500, ftol=1e-16))
+    return np.sqrt(max(r.fun, 0))
+
+
+I3, Z3 = np.eye(3), np.zeros(3)
+
+
+def box(h):
+    return np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=float) * np.asarray(h)
+
+
+def test_gjk_matches_qp_on_random_polytopes(built):
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        A = rng.normal(size=(rng.integers(4, 30), 3)) * rng.uniform(0.05, 0.3, 3)
+        B = rng.normal(size=(rng.integers(4, 30), 3)) * rng.uniform(0.05, 0.3, 3) + rng.normal(size=3) * 0.5
+        assert abs(O.gjk(A, I3, Z3, B, I3, Z3) - qp_distance(A, B)) < 1e-6
+
+
+def test_gjk_box_box_known_answers(built):
+    a = box([0.5, 0.5, 0.5])
+    # face-face, edge-edge (diagonal offset), vertex-vertex
+    assert O.gjk(a, I3, Z3, a, I3, np.array([2.0, 0.2, -0.1])) == pytest.approx(1.0, abs=1e-12)
+    assert O.gjk(a, I3, Z3, a, I3, np.array([2.0, 2.0, 0.0])) == pytest.approx(np.sqrt(2.0), abs=1e-12)
+    assert O.gjk(a, I3, Z3, a, I3, np.array([2.0, 2.0, 2.0])) == pytest.approx(np.sqrt(3.0), abs=1e-12)
+    # overlapping boxes -> 0
+    assert O.gjk(a, I3, Z3, a, I3, np.array([0.3, 0.1, 0.2])) == 0.0
+    # rotated box: 45 deg about z, corner pointing at the face of the other
+    c, s = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    assert O.gjk(a, I3, Z3, a, R, np.array([2.0, 0, 0])) == pytest.approx(2.0 - 0.5 - np.sqrt(0.5), abs=1e-12)
+
+
+def test_gjk_point_box_and_cutoff(built):
+    a = box([0.6, 0.8, 0.1])
+    p = np.array([[0.0, 0.0, 0.0]])
+    assert O.gjk(a, I3, np.array([0, 0, -0.1]), p, I3, np.array([0.1, 0.2, 0.25])) == pytest.approx(0.25, abs=1e-12)
+    assert O.gjk(a, I3, np.array([0, 0, -0.1]), p, I3, np.array([1.6, 0.0, 0.0])) == pytest.approx(1.0, abs=1e-12)
+    # with a cutoff the result only has to exceed it
+    assert O.gjk(a, I3, Z3, p, I3, np.array([5.0, 0, 0]), cutoff=0.5) > 0.5
+
+
+def test_fk_zero_configuration(built, space_scene):
+    ora = O.OracleEnv(space_scene, 1)
+    pos, rot = ora.fk(np.zeros(7))
+    # robot.urdf joint origins stacked along z from the base at (-0.2, 0, 0.02)
+    z = 0.02 + np.cumsum([0, 0.157, 0.183, 0.185, 0.215, 0.4, 0.0, 0.0])
+    assert np.allclose(pos[:, 0], -0.2) and np.allclose(pos[:, 1], 0.0)
+    assert np.allclose(pos[:, 2], z)
+    assert np.allclose(pos[7], [-0.2, 0.0, 1.16])           # SURVEY section 8c known answer
+    assert np.allclose(rot, np.eye(3)[None])
+
+
+def test_fk_single_joint_rotations(built, space_scene):
+    ora = O.OracleEnv(space_scene, 1)
+    # joint 2 (axis +y) by +90 deg: everything above the shoulder (z = 0.36) swings to +x
+    q = np.zeros(7); q[1] = np.pi / 2
+    pos, rot = ora.fk(q)
+    shoulder = np.array([-0.2, 0.0, 0.02 + 0.157 + 0.183])
+    assert np.allclose(pos[2], shoulder)
+    assert np.allclose(pos[7], shoulder + [0.185 + 0.215 + 0.4, 0, 0])
+    # joint 4 has axis -y: +90 deg swings the forearm to -x
+    q = np.zeros(7); q[3] = np.pi / 2
+    pos, _ = ora.fk(q)
+    elbow = np.array([-0.2, 0.0, 0.02 + 0.157 + 0.183 + 0.185 + 0.215])
+    assert np.allclose(pos[4], elbow)
+    assert np.allclose(pos[7], elbow + [-0.4, 0, 0])
+    # joint 1 (axis z) turns the frame but not the positions at q_others = 0
+    q = np.zeros(7); q[0] = 0.7
+    pos, rot = ora.fk(q)
+    assert np.allclose(pos[7], [-0.2, 0, 1.16])
+    c, s = np.cos(0.7), np.sin(0.7)
+    assert np.allclose(rot[7], [[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def test_table_distance_equals_lowest_vertex_height(built, space_scene):
+    """Above the table top (z = 0) the closest point of a link is its lowest hull vertex, so the static
+    distance is min_z - 0.001: hull inflated by the 1 mm margin against the table surface."""
+    ora = O.OracleEnv(space_scene, 1)
+    s = space_scene.struct
+    verts = space_scene.verts
+    # straight-up arm: every observed link is farther than the 0.102 cut-off
+    d = ora.distances(np.zeros(7), [0, 720])
+    assert d[0] == pytest.approx(0.102) and d[1] == pytest.approx(0.102)
+    checked = 0
+    for q2 in (2.03, 2.05, 2.08, 2.1, 2.12):
+        q = np.array([0.3, q2, -0.2, 0.4, 0.1, -0.3, 0.5])
+        pos, rot = ora.fk(q)
+        zmin, at = np.inf, None
+        for k in range(2, 8):                                     # links observed by the table
+            pc = space_scene.pieces[s.link_piece[k]]
+            v = verts[pc.vert_begin:pc.vert_begin + pc.vert_count] @ rot[k].T + pos[k]
+            i = np.argmin(v[:, 2])
+            if v[i, 2] < zmin:
+                zmin, at = v[i, 2], v[i]
+        d = ora.distances(q, [0, 720])
+        if 0.003 < zmin < 0.1 and abs(at[0]) < 0.59 and abs(at[1]) < 0.79:
+            assert d[0] == pytest.approx(zmin - 0.001, abs=1e-9)
+            checked += 1
+    assert checked >= 2
+    # arm folded straight down through the table: penetration
+    assert ora.distances(np.array([0, np.pi, 0, 0, 0, 0, 0.0]), [0, 720])[0] < 0.0
+
+
+def test_planet_distance_against_qp(built, space_scene):
+    """Link-vs-planet-piece distances of the real geometry against the independent QP solver."""
+    ora = O.OracleEnv(space_scene, 1)
+    s = space_scene.struct
+    verts = space_scene.verts
+    rng = np.random.default_rng(5)
+    from safemotionsrisk_amd.scene import quaternion_to_matrix
+    for _ in range(2):
+        q = rng.uniform(-1.5, 1.5, 7)
+        idx = int(rng.integers(0, 1200))
+        link, planet = int(rng.integers(3, 8)), int(rng.integers(0, 2))
+        piece = int(rng.integers(0, s.planet[planet].piece_count))
+        pos, rot = ora.fk(q)
+        pl = space_scene.pieces[s.link_piece[link]]
+        A = verts[pl.vert_begin:pl.vert_begin + pl.vert_count] @ rot[link].T + pos[link]
+        pose = np.ctypeslib.as_array(s.planet[planet].orbit_pose, shape=(1200, 7))[idx]
+        pp = space_scene.pieces[s.planet[planet].piece_begin + piece]
+        B = verts[pp.vert_begin:pp.vert_begin + pp.vert_count] @ quaternion_to_matrix(pose[3:]).T + pose[:3]
+        d = ora.link_planet_piece_distance(q, link, planet, piece, idx)
+        assert d == pytest.approx(qp_distance(A, B) - 0.002, abs=2e-6)

@@ -1,0 +1,106 @@
+"""Host logic: env_config -> scene (A5 limits, masks, thresholds), validation of unsupported options,
+drop-in constants.  CPU only."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from safemotionsrisk_amd import scene as sc
+from safemotionsrisk_amd.scene import SPACE_ENV_CONFIG, build_scene
+
+REF_PARAMS = "/root/reference/safemotions/trained_networks/backup_networks/space/params.json"
+
+
+def test_joint_limits_match_survey(space_scene):
+    s = space_scene.struct
+    assert np.allclose(list(s.pos_hi), [2.93206, 2.059395, 2.93206, 2.059395, 2.93206, 2.059395, 3.019326], atol=1e-6)
+    assert np.allclose(list(s.pos_lo), -np.array(list(s.pos_hi)))
+    assert np.allclose(list(s.vel_max), [1.7104, 1.7104, 1.7453, 2.2689, 2.4435, 3.1416, 3.1416], atol=1e-4)
+    assert list(s.acc_max) == [15.0, 7.5, 10.0, 12.5, 15.0, 20.0, 20.0]
+    assert np.allclose(list(s.jerk_max), [300, 150, 200, 250, 300, 400, 400])           # min(2 a / dt, 7500 ...)
+
+
+def test_masks_thresholds_and_sizes(space_scene):
+    s = space_scene.struct
+    assert s.static_link_mask == 0b11111100        # iiwa_link_2..7: table observed AND closest_point_active
+    assert s.moving_link_mask == 0b11111000        # iiwa_link_3..7 (scene.py:288-290)
+    assert s.static_max_distance == pytest.approx(0.102) and s.moving_max_distance == pytest.approx(0.6)
+    assert s.collision_checks_per_step == 3 and s.updates_per_step == 24 and s.episode_steps == 20
+    assert s.obs_size == 23 and s.obs_num_planets == 1 and s.obs_planet_size_per_planet == 2
+    assert s.n_pieces == 8 + 1 + 24 + 1 and s.n_static == 1
+    assert [s.start_box[c][0] for c in range(3)] == [-1.1, -1.1, -0.1]
+    assert s.contact_distance == pytest.approx(0.02)
+    assert list(s.ee_offset) == [0.0, 0.0, 0.126]
+
+
+def test_collision_checks_option():
+    assert build_scene(SPACE_ENV_CONFIG, collision_checks_per_step=24).struct.collision_checks_per_step == 24
+    assert build_scene(dict(SPACE_ENV_CONFIG, collision_check_time=None)).struct.collision_checks_per_step == 1
+    with pytest.raises(ValueError):
+        build_scene(SPACE_ENV_CONFIG, collision_checks_per_step=5)     # must divide 24
+
+
+def test_obs_planet_size_variants():
+    assert build_scene(dict(SPACE_ENV_CONFIG, obs_planet_size_per_planet=1)).obs_size == 22
+    assert build_scene(dict(SPACE_ENV_CONFIG, obs_planet_size_per_planet=3)).obs_size == 24
+    cfg = dict(SPACE_ENV_CONFIG, planet_two_time_shift=None, planet_two_period=4.0)
+    b = build_scene(cfg)
+    assert b.obs_size == 25 and b.struct.planet[1].coupled == 0 and b.struct.planet[1].n_orbit == 960
+
+
+@pytest.mark.parametrize("key,value,exc", [
+    ("use_target_points", True, NotImplementedError), ("ball_machine_mode", True, NotImplementedError),
+    ("check_braking_trajectory_collisions", True, NotImplementedError), ("use_real_robot", True, NotImplementedError),
+    ("human_network_checkpoint", "human_network/checkpoint/checkpoint", NotImplementedError),
+    ("risk_config_dir", "risk_networks/state_action/space", NotImplementedError),
+    ("robot_scene", 9, NotImplementedError), ("obstacle_scene", 3, NotImplementedError),
+    ("collision_avoidance_mode", False, NotImplementedError), ("max_resampling_attempts", 3, ValueError),
+    ("closest_point_safety_distance", 0.2, ValueError),
+])
+def test_unsupported_options_fail_loudly(key, value, exc):
+    with pytest.raises(exc):
+        build_scene(dict(SPACE_ENV_CONFIG, **{key: value}))
+
+
+def test_missing_experiment_name():
+    cfg = dict(SPACE_ENV_CONFIG)
+    del cfg["experiment_name"]
+    with pytest.raises(TypeError):
+        build_scene(cfg)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PARAMS), reason="reference checkout not mounted")
+def test_readme_config_equals_shipped_params_json():
+    """SPACE_ENV_CONFIG = the shipped backup_networks/space env_config, except ball_machine_mode and
+    the target_link_offset that goes with it (fixture: SURVEY section 8c)."""
+    with open(REF_PARAMS) as f:
+        ref = json.load(f)["env_config"]
+    readme_only = set()
+    for k, v in SPACE_ENV_CONFIG.items():
+        if k in ("experiment_name",):
+            continue
+        if k not in ref:            # flags of the README command that are newer than the shipped checkpoint
+            readme_only.add(k)
+            continue
+        assert ref[k] == v or (isinstance(v, list) and list(ref[k]) == list(v)), (k, ref[k], v)
+    assert readme_only <= {"collision_avoidance_kinematic_state_sampling_probability"}
+    assert ref["ball_machine_mode"] is True
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/safemotions/description/urdf/robot.urdf"),
+                    reason="reference checkout not mounted")
+def test_committed_asset_tables_match_reference_assets():
+    from safemotionsrisk_amd.assets import compile_assets
+    fresh = compile_assets("/root/reference")
+    committed = np.load(sc._DATA)
+    assert set(fresh) == set(committed.files)
+    for k in fresh:
+        assert np.array_equal(np.asarray(fresh[k]), committed[k]), k
+
+
+def test_termination_constants_and_spaces():
+    from safemotionsrisk_amd.env import VecSafeMotionsEnv as E
+    assert (E.TERMINATION_UNSET, E.TERMINATION_JOINT_LIMITS, E.TERMINATION_TRAJECTORY_LENGTH, E.TERMINATION_SELF_COLLISION,
+            E.TERMINATION_COLLISION_WITH_STATIC_OBSTACLE, E.TERMINATION_COLLISION_WITH_MOVING_OBSTACLE) == (-1, 1, 2, 3, 4, 5)
