@@ -8,7 +8,9 @@
 // Reference short names as in include/smr_scene.h.
 #pragma once
 
+#ifndef SMR_HOST_EMUL          // tests/host_emul compiles these device functions for the host (debugging only)
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #include "../../include/safemotions_hip.h"
@@ -18,8 +20,10 @@ namespace smr {
 // Batch-shared read-only tables are read through the constant address space: with a wave-uniform
 // index the compiler then emits s_load_* (scalar cache -> SGPRs) instead of per-lane flat loads.
 // (A pointer fetched from a struct is a generic pointer, and LLVM treats generic loads as divergent.)
+#ifndef SMR_HOST_EMUL
 #define SMR_CONST __attribute__((address_space(4)))
 #define SMR_GLOBAL __attribute__((address_space(1)))
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // tables (float32 images of smr_scene_t, built by smr_create)
@@ -151,9 +155,12 @@ constexpr float kNoBound = 3.0e38f;
 // c = head room when the segment ends with a1 = 0.  For a1 > 0 the profile that lowers a by D per knot
 // peaks at v1 + a1^2/(2J) (full-jerk ramp) or v1 + a1^2 dt/(2(a1+A)) when the floor -A cuts the ramp
 // short (only if D > A); for a1 < 0 with a0 > 0 the peak lies inside the first segment.
-__device__ __forceinline__ float vel_upper_a1max(float v0, float a0, float Vlim, const JointLim &L) {
+// The limit is passed as (V, tol) so that the head room (V - v0) + tol keeps full float32 precision when the
+// joint rides on the limit (V - v0 is exact for v0 near V).
+__device__ __forceinline__ float vel_upper_a1max(float v0, float a0, float V, float tol, const JointLim &L) {
     const float dt = L.dt, D = L.J * dt;
-    const float c = Vlim - v0 - 0.5f * a0 * dt;
+    const float head = (V - v0) + tol;
+    const float c = head - 0.5f * a0 * dt;
     if (c >= 0.f) {
         float x = L.J * (-0.5f * dt + sqrtf(0.25f * dt * dt + 2.0f * c / L.J));
         if (D > L.A) {
@@ -163,37 +170,44 @@ __device__ __forceinline__ float vel_upper_a1max(float v0, float a0, float Vlim,
         }
         return x;
     }
-    if (a0 > 0.f && Vlim - v0 > 0.f) return a0 - a0 * a0 * dt / (2.0f * (Vlim - v0));
+    if (a0 > 0.f && head > 0.f) return a0 - a0 * a0 * dt / (2.0f * head);
     return -kNoBound;
 }
 
-__device__ __forceinline__ float seg_pmax(float p0, float v0, float a0, float a1, float dt) {
-    float m = interp_pos(p0, v0, a0, a1, dt, dt);
+// displacement of the constant-jerk segment after time t (interp_pos without the start position)
+__device__ __forceinline__ float seg_disp(float v0, float a0, float a1, float t, float dt) {
+    return v0 * t + 0.5f * a0 * t * t + (1.0f / 6.0f) * ((a1 - a0) / dt) * t * t * t;
+}
+
+// largest displacement reached inside (0, dt] of a segment
+__device__ __forceinline__ float seg_dmax(float v0, float a0, float a1, float dt) {
+    float m = seg_disp(v0, a0, a1, dt, dt);
     float j = (a1 - a0) / dt;
     float disc = a0 * a0 - 2.0f * j * v0;
     if (disc >= 0.f) {
         float sq = sqrtf(disc);
         float qq = -(a0 + (a0 >= 0.f ? sq : -sq));
         float r0 = qq / j, r1 = 2.0f * v0 / qq;      // inf/nan when a divisor is 0: rejected by the range test
-        if (r0 > 0.f && r0 < dt) m = fmaxf(m, interp_pos(p0, v0, a0, a1, r0, dt));
-        if (r1 > 0.f && r1 < dt) m = fmaxf(m, interp_pos(p0, v0, a0, a1, r1, dt));
+        if (r0 > 0.f && r0 < dt) m = fmaxf(m, seg_disp(v0, a0, a1, r0, dt));
+        if (r1 > 0.f && r1 < dt) m = fmaxf(m, seg_disp(v0, a0, a1, r1, dt));
     }
     return m;
 }
 
-// does the joint stay below Plim if, after a0 -> a1, it always takes the lowest acceleration that the
-// lower velocity limit still allows?
-__device__ inline bool pos_upper_ok(float p0, float v0, float a0, float a1, float Plim, float Vlim, const JointLim &L) {
-    if (seg_pmax(p0, v0, a0, a1, L.dt) > Plim) return false;
-    float p = interp_pos(p0, v0, a0, a1, L.dt, L.dt);
+// Does the joint stay below the position limit if, after a0 -> a1, it always takes the lowest acceleration
+// that the lower velocity limit still allows?  Works on displacements relative to the current position
+// (gap = limit - p0), so float32 resolves the few-micrometre margins that decide the bound near a limit.
+__device__ inline bool pos_upper_ok(float gap, float v0, float a0, float a1, float Vtol, const JointLim &L) {
+    if (seg_dmax(v0, a0, a1, L.dt) > gap) return false;
+    float d = seg_disp(v0, a0, a1, L.dt, L.dt);
     float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1;
     const float D = L.J * L.dt;
     for (int it = 0; it < 4096; ++it) {
         if (v <= 0.f && a <= 0.f) return true;
-        float floor_v = -vel_upper_a1max(-v, -a, Vlim, L);
+        float floor_v = -vel_upper_a1max(-v, -a, L.V, Vtol, L);
         float an = fmaxf(fmaxf(a - D, -L.A), fminf(floor_v, fminf(a + D, L.A)));
-        if (seg_pmax(p, v, a, an, L.dt) > Plim) return false;
-        p = interp_pos(p, v, a, an, L.dt, L.dt);
+        if (d + seg_dmax(v, a, an, L.dt) > gap) return false;
+        d += seg_disp(v, a, an, L.dt, L.dt);
         v += 0.5f * (a + an) * L.dt;
         a = an;
     }
@@ -203,14 +217,13 @@ __device__ inline bool pos_upper_ok(float p0, float v0, float a0, float a1, floa
 constexpr int kBisectIters = 30;
 
 // largest a1 in [lo, hi] accepted by the (monotone) position test
-__device__ inline float pos_upper_end(float p, float v, float a, float Plim, float Vlim, const JointLim &L, float lo, float hi,
-                                      bool &infeasible) {
+__device__ inline float pos_upper_end(float gap, float v, float a, float Vtol, const JointLim &L, float lo, float hi, bool &infeasible) {
     infeasible = false;
-    if (pos_upper_ok(p, v, a, hi, Plim, Vlim, L)) return hi;
-    if (!pos_upper_ok(p, v, a, lo, Plim, Vlim, L)) { infeasible = true; return lo; }
+    if (pos_upper_ok(gap, v, a, hi, Vtol, L)) return hi;
+    if (!pos_upper_ok(gap, v, a, lo, Vtol, L)) { infeasible = true; return lo; }
     for (int it = 0; it < kBisectIters; ++it) {
         float mid = 0.5f * (lo + hi);
-        if (pos_upper_ok(p, v, a, mid, Plim, Vlim, L)) lo = mid; else hi = mid;
+        if (pos_upper_ok(gap, v, a, mid, Vtol, L)) lo = mid; else hi = mid;
     }
     return lo;
 }
@@ -220,19 +233,20 @@ __device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v,
     float blo = fmaxf(-L.A, a - D), bhi = fminf(L.A, a + D);
     if (blo > bhi) blo = bhi = fminf(fmaxf(a, -L.A), L.A);
     // design tolerance for the range, wider report tolerance for the violation code (rounding hysteresis)
-    const float Vlim = L.V * (1.0f + 1e-5f), Vrep = L.V * (1.0f + 3e-5f);
+    const float vtol = 1e-5f * L.V, vrep = 3e-5f * L.V;
     const float ptol = 1e-6f * (L.phi - L.plo), prep = 4e-6f * (L.phi - L.plo);
     code = 0;
-    float uv = vel_upper_a1max(v, a, Vlim, L), lv = -vel_upper_a1max(-v, -a, Vlim, L);
-    if (uv < blo) { if (vel_upper_a1max(v, a, Vrep, L) < blo) code |= 1; uv = blo; }
-    if (lv > bhi) { if (-vel_upper_a1max(-v, -a, Vrep, L) > bhi) code |= 1; lv = bhi; }
+    float uv = vel_upper_a1max(v, a, L.V, vtol, L), lv = -vel_upper_a1max(-v, -a, L.V, vtol, L);
+    if (uv < blo) { if (vel_upper_a1max(v, a, L.V, vrep, L) < blo) code |= 1; uv = blo; }
+    if (lv > bhi) { if (-vel_upper_a1max(-v, -a, L.V, vrep, L) > bhi) code |= 1; lv = bhi; }
     float vlo = fmaxf(blo, lv), vhi = fminf(bhi, uv);
     if (vlo > vhi) { code |= 4; vlo = vhi = 0.5f * (vlo + vhi); }
     bool inf;
-    float up = pos_upper_end(p, v, a, L.phi + ptol, Vlim, L, vlo, vhi, inf);
-    if (inf && !pos_upper_ok(p, v, a, vlo, L.phi + prep, Vlim, L)) code |= 2;
-    float lp = -pos_upper_end(-p, -v, -a, -L.plo + ptol, Vlim, L, -vhi, -vlo, inf);
-    if (inf && !pos_upper_ok(-p, -v, -a, -vhi, -L.plo + prep, Vlim, L)) code |= 2;
+    const float gap_hi = L.phi - p, gap_lo = p - L.plo;       // exact for p near the limit (Sterbenz)
+    float up = pos_upper_end(gap_hi + ptol, v, a, vtol, L, vlo, vhi, inf);
+    if (inf && !pos_upper_ok(gap_hi + prep, v, a, vlo, vtol, L)) code |= 2;
+    float lp = -pos_upper_end(gap_lo + ptol, -v, -a, vtol, L, -vhi, -vlo, inf);
+    if (inf && !pos_upper_ok(gap_lo + prep, -v, -a, -vhi, vtol, L)) code |= 2;
     hi = up;
     lo = lp;
     if (lo > hi) {
@@ -326,24 +340,39 @@ __device__ __forceinline__ DPiece load_piece(const DPiece *pieces, int idx) {
     return P;
 }
 
-// closest point of triangle (a,b,c) to the origin; mask: bit0 a, bit1 b, bit2 c support it
+// closest point of segment (a,b) to the origin; mask: bit0 a, bit1 b support it
+__device__ __forceinline__ F3 seg_closest(F3 a, F3 b, int &mask) {
+    F3 e = b - a;
+    float t = -dot(a, e), den = dot(e, e);
+    if (t <= 0.f) { mask = 1; return a; }
+    if (t >= den) { mask = 2; return b; }
+    mask = 3;
+    return a + (t / den) * e;
+}
+
+// Closest point of triangle (a,b,c) to the origin; mask: bit0 a, bit1 b, bit2 c support it.
+// Barycentric signs come from triple products with the normal n = (b-a)x(c-a) (signed sub-areas), not from
+// the squared-dot-product form of Ericson 5.1.5: the Minkowski points of a metre-sized obstacle (the table)
+// form needle triangles whose vertices are ~1 m from the origin while the answer is centimetres, and the
+// squared form then loses 3-4 digits in float32.
 __device__ __forceinline__ F3 tri_closest(F3 a, F3 b, F3 c, int &mask) {
-    F3 ab = b - a, ac = c - a;
-    float d1 = -dot(ab, a), d2 = -dot(ac, a);
-    if (d1 <= 0.f && d2 <= 0.f) { mask = 1; return a; }
-    float d3 = -dot(ab, b), d4 = -dot(ac, b);
-    if (d3 >= 0.f && d4 <= d3) { mask = 2; return b; }
-    float vc = d1 * d4 - d3 * d2;
-    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { mask = 3; return a + (d1 / (d1 - d3)) * ab; }
-    float d5 = -dot(ab, c), d6 = -dot(ac, c);
-    if (d6 >= 0.f && d5 <= d6) { mask = 4; return c; }
-    float vb = d5 * d2 - d1 * d6;
-    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { mask = 5; return a + (d2 / (d2 - d6)) * ac; }
-    float va = d3 * d6 - d5 * d4;
-    if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) { mask = 6; return b + ((d4 - d3) / ((d4 - d3) + (d5 - d6))) * (c - b); }
-    float denom = 1.0f / (va + vb + vc);
-    mask = 7;
-    return a + (vb * denom) * ab + (vc * denom) * ac;
+    F3 e0 = b - a, e1 = c - a;
+    F3 n = cross(e0, e1);
+    float nn = dot(n, n);
+    float la = dot(n, cross(b, c)), lb = dot(n, cross(c, a)), lc = dot(n, cross(a, b));   // la + lb + lc = nn
+    if (nn > 0.f && la >= 0.f && lb >= 0.f && lc >= 0.f) {
+        mask = 7;
+        return (dot(a, n) / nn) * n;                      // foot of the perpendicular
+    }
+    // outside (or degenerate): the closest point lies on an edge opposite to a negative coordinate
+    float best = 3.0e38f;
+    F3 bv = a;
+    mask = 1;
+    const bool degenerate = !(nn > 0.f);
+    if (lc < 0.f || degenerate) { int m; F3 p = seg_closest(a, b, m); float d = dot(p, p); if (d < best) { best = d; bv = p; mask = m; } }
+    if (lb < 0.f || degenerate) { int m; F3 p = seg_closest(a, c, m); float d = dot(p, p); if (d < best) { best = d; bv = p; mask = (m & 1) | ((m & 2) << 1); } }
+    if (la < 0.f || degenerate) { int m; F3 p = seg_closest(b, c, m); float d = dot(p, p); if (d < best) { best = d; bv = p; mask = m << 1; } }
+    return bv;
 }
 
 __device__ __forceinline__ F3 pick_lowest(int m, F3 a, F3 b, F3 c, F3 d) { return (m & 1) ? a : (m & 2) ? b : (m & 4) ? c : d; }
@@ -354,11 +383,7 @@ __device__ inline bool simplex_solve(F3 &w0, F3 &w1, F3 &w2, F3 &w3, int &n, F3 
     int mask;
     if (n == 1) { v = w0; return false; }
     if (n == 2) {
-        F3 ab = w1 - w0;
-        float t = -dot(w0, ab), den = dot(ab, ab);
-        if (t <= 0.f) { mask = 1; v = w0; }
-        else if (t >= den) { mask = 2; v = w1; }
-        else { mask = 3; v = w0 + (t / den) * ab; }
+        v = seg_closest(w0, w1, mask);
     } else if (n == 3) {
         v = tri_closest(w0, w1, w2, mask);
     } else {
@@ -412,17 +437,33 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
     F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
     int n = 0;
     float vv = dot(v, v);
-    const float cutoff2 = cutoff * cutoff, stop2 = stop_below * stop_below;
+    const float cutoff2 = cutoff * cutoff, stop2 = stop_below > 0.f ? stop_below * stop_below : 0.f;
     for (int it = 0; it < 32; ++it) {
         F3 w = support<IDENTITY>(verts, A.begin, A.count, XA, neg(v)) - support<false>(verts, B.begin, B.count, XB, v);
         float vw = dot(v, w);
+#ifdef SMR_HOST_EMUL_TRACE
+        printf("  it %d n %d vv %.9g vw %.9g v=(%.7g %.7g %.7g) w=(%.7g %.7g %.7g)\n", it, n, vv, vw, v.x, v.y, v.z, w.x, w.y, w.z);
+#endif
         if (vw > 0.f && vw * vw > cutoff2 * vv) return (vw / sqrtf(vv));     // separating plane farther than cutoff
         if (n > 0 && (vv - vw) <= 1e-6f * vv) break;                         // converged
+        // the support point is already a simplex vertex: v is optimal up to rounding (in exact arithmetic
+        // v.w == v.v then; in float32 the test above can miss it and a duplicate vertex would make the
+        // sub-simplex degenerate)
+        {
+            F3 e0 = w - w0, e1 = w - w1, e2 = w - w2;
+            const float tiny = 1e-12f * fmaxf(dot(w, w), 1e-6f);
+            bool dup = (n > 0 && dot(e0, e0) <= tiny) || (n > 1 && dot(e1, e1) <= tiny) || (n > 2 && dot(e2, e2) <= tiny);
+#ifdef SMR_HOST_EMUL_TRACE
+            if (dup) printf("  dup: n %d w0=(%.7g %.7g %.7g) w1=(%.7g %.7g %.7g) w2=(%.7g %.7g %.7g)\n", n, w0.x, w0.y, w0.z, w1.x, w1.y, w1.z, w2.x, w2.y, w2.z);
+#endif
+            if (dup) break;
+        }
         if (n == 0) w0 = w; else if (n == 1) w1 = w; else if (n == 2) w2 = w; else w3 = w;
         ++n;
         F3 vn;
         if (simplex_solve(w0, w1, w2, w3, n, vn)) return 0.f;                // origin inside the simplex
         float vvn = dot(vn, vn);
+        if (!(vvn == vvn)) break;                                            // degenerate sub-simplex: keep the last valid v
         if (it > 0 && vvn >= vv) break;                                      // no progress (rounding)
         v = vn;
         vv = vvn;

@@ -165,7 +165,7 @@ __device__ inline bool position_is_valid(const DScene &S, const float q[SMR_NJ])
         if (ok && ((S.static_mask >> l) & 1u)) {
             for (int s = 0; s < S.n_static; ++s) {                                        // ctlp.py:2140-2168
                 float thr = S.start_min_static;
-                float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, thr - 1.0f);
+                float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, 0.f);
                 if (d <= thr + 0.005f && d < thr) ok = false;
             }
         }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
                     if (free_pos && ((S.static_mask >> l) & 1u))
                         for (int s = 0; s < S.n_static; ++s) {
                             float thr = S.start_min_static;
-                            float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, thr - 1.0f);
+                            float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, 0.f);
                             if (d <= thr + 0.005f && d < thr) free_pos = false;
                         }
                 }
@@ -437,26 +437,33 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     copy3(d.base, s.base_xyz); copy3(d.ee_offset, s.ee_offset);
     for (int j = 0; j < SMR_NJ; ++j) { copy3(d.joint_xyz[j], s.joint_xyz[j]); copy3(d.joint_axis[j], s.joint_axis[j]); }
 
-    std::vector<float4> verts((size_t)s.n_verts);
-    for (int i = 0; i < s.n_verts; ++i) verts[i] = make_float4((float)s.verts[3 * i], (float)s.verts[3 * i + 1], (float)s.verts[3 * i + 2], 0.f);
+    // Device vertex table: every piece starts on a 64-byte boundary (4 vertices of 16 B) so that the wide scalar
+    // loads of the support scan (s_load_dwordx8/x16) never straddle their natural alignment.
+    std::vector<float4> verts;
     std::vector<DPiece> pieces((size_t)s.n_pieces);
     for (int i = 0; i < s.n_pieces; ++i) {
         const smr_piece_t &p = s.pieces[i];
         if (p.vert_begin < 0 || p.vert_count <= 0 || p.vert_begin + p.vert_count > s.n_verts) { env->err = "piece vertex range out of bounds"; return SMR_E_INVALID; }
         DPiece &q = pieces[i];
-        q.begin = p.vert_begin; q.count = p.vert_count;
+        while (verts.size() % 4) verts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+        q.begin = (int)verts.size(); q.count = p.vert_count;
+        for (int k = 0; k < p.vert_count; ++k) {
+            const double *src = s.verts + 3 * (size_t)(p.vert_begin + k);
+            verts.push_back(make_float4((float)src[0], (float)src[1], (float)src[2], 0.f));
+        }
         q.cx = (float)p.center[0]; q.cy = (float)p.center[1]; q.cz = (float)p.center[2];
         q.margin = (float)p.margin;
         // bounding data recomputed in float32 around the float32 center, slightly inflated, so culling stays conservative
         float r = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
         for (int k = 0; k < p.vert_count; ++k) {
-            const float4 &vv = verts[(size_t)p.vert_begin + k];
+            const float4 &vv = verts[(size_t)q.begin + k];
             float dx = vv.x - q.cx, dy = vv.y - q.cy, dz = vv.z - q.cz;
             r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
             hx = std::max(hx, std::fabs(dx)); hy = std::max(hy, std::fabs(dy)); hz = std::max(hz, std::fabs(dz));
         }
         q.radius = r * 1.00001f + 1e-7f; q.hx = hx + 1e-7f; q.hy = hy + 1e-7f; q.hz = hz + 1e-7f;
     }
+    for (int k = 0; k < 8; ++k) verts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));   // slack for the last unrolled load
     float4 *dverts; DPiece *dpieces;
     int rc;
     if ((rc = dev_upload(env, &dverts, verts))) return rc;

@@ -1,0 +1,111 @@
+// Host build of the DEVICE functions in safemotionsrisk_amd/csrc/smr_device.h (float32, same source), for
+// debugging GJK / range code paths without a GPU.  Test infrastructure only - never loaded by the product.
+#define SMR_HOST_EMUL 1
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <algorithm>
+#define __device__
+#define __forceinline__ inline
+#define SMR_CONST
+#define SMR_GLOBAL
+struct float4 { float x, y, z, w; };
+static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
+static inline int __popc(int x) { return __builtin_popcount(x); }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline void sincosf_(float x, float *s, float *c) { *s = std::sin(x); *c = std::cos(x); }
+#define sincosf sincosf_
+#include <math.h>
+#include "../../safemotionsrisk_amd/csrc/smr_device.h"
+using namespace smr;
+
+extern "C" {
+// distance between vertex sets A (identity frame) and B (transform R,t): float32 device GJK
+float emul_gjk(const float *va, int na, const float *vb, int nb, const float *Rb, const float *tb, float cutoff, float stop_below, int identity_a, const float *Ra, const float *ta) {
+    static float4 verts[4096];
+    for (int i = 0; i < na; ++i) verts[i] = {va[3*i], va[3*i+1], va[3*i+2], 0};
+    for (int i = 0; i < nb; ++i) verts[na+i] = {vb[3*i], vb[3*i+1], vb[3*i+2], 0};
+    DPiece A{}, B{};
+    A.begin = 0; A.count = na; B.begin = na; B.count = nb;
+    Xf XA, XB;
+    for (int i = 0; i < 9; ++i) { XB.r[i] = Rb[i]; XA.r[i] = Ra[i]; }
+    XB.t = {tb[0], tb[1], tb[2]}; XA.t = {ta[0], ta[1], ta[2]};
+    // initial direction as piece_distance: center difference
+    F3 ca{0,0,0}, cb{0,0,0};
+    for (int i = 0; i < na; ++i) { ca.x += va[3*i]/na; ca.y += va[3*i+1]/na; ca.z += va[3*i+2]/na; }
+    for (int i = 0; i < nb; ++i) { cb.x += vb[3*i]/nb; cb.y += vb[3*i+1]/nb; cb.z += vb[3*i+2]/nb; }
+    if (!identity_a) ca = apply(XA, ca);
+    cb = apply(XB, cb);
+    F3 d = ca - cb;
+    if (identity_a) return gjk_distance<true>((const float *)verts, A, XA, B, XB, d, cutoff, stop_below);
+    return gjk_distance<false>((const float *)verts, A, XA, B, XB, d, cutoff, stop_below);
+}
+void emul_safe_acc_range(float plo, float phi, float V, float A, float J, float dt, float p, float v, float a, float *lo, float *hi, int *code) {
+    JointLim L{plo, phi, V, A, J, dt};
+    safe_acc_range_joint(L, p, v, a, *lo, *hi, *code);
+}
+}
+
+// ---- whole-scene emulation: float32 tables as smr_create builds them, collide_sample on the host ----
+#include <vector>
+struct HostScene {
+    DScene d;
+    std::vector<float4> verts; std::vector<DPiece> pieces; std::vector<float> pose[2], local[2];
+};
+static void cp(float *dst, const double *src, int n) { for (int i = 0; i < n; ++i) dst[i] = (float)src[i]; }
+extern "C" void *emul_scene_create(const smr_scene_t *sp) {
+    const smr_scene_t &s = *sp;
+    HostScene *H = new HostScene();
+    DScene &d = H->d;
+    std::memset(&d, 0, sizeof d);
+    d.B = 1; d.obs_size = s.obs_size; d.episode_steps = s.episode_steps; d.updates_per_step = s.updates_per_step;
+    d.checks_per_step = s.collision_checks_per_step; d.dt = (float)s.dt;
+    cp(d.pos_lo, s.pos_lo, 7); cp(d.pos_hi, s.pos_hi, 7); cp(d.vel_max, s.vel_max, 7); cp(d.acc_max, s.acc_max, 7); cp(d.jerk_max, s.jerk_max, 7);
+    cp(d.base, s.base_xyz, 3); cp(d.ee_offset, s.ee_offset, 3);
+    for (int j = 0; j < 7; ++j) { cp(d.joint_xyz[j], s.joint_xyz[j], 3); cp(d.joint_axis[j], s.joint_axis[j], 3); }
+    H->verts.resize(s.n_verts);
+    for (int i = 0; i < s.n_verts; ++i) H->verts[i] = {(float)s.verts[3*i], (float)s.verts[3*i+1], (float)s.verts[3*i+2], 0.f};
+    H->pieces.resize(s.n_pieces);
+    for (int i = 0; i < s.n_pieces; ++i) {
+        const smr_piece_t &p = s.pieces[i]; DPiece &q = H->pieces[i];
+        q.begin = p.vert_begin; q.count = p.vert_count; q.cx = (float)p.center[0]; q.cy = (float)p.center[1]; q.cz = (float)p.center[2]; q.margin = (float)p.margin;
+        float r = 0, hx = 0, hy = 0, hz = 0;
+        for (int k = 0; k < p.vert_count; ++k) {
+            const float4 &v = H->verts[p.vert_begin + k];
+            float dx = v.x - q.cx, dy = v.y - q.cy, dz = v.z - q.cz;
+            r = std::max(r, std::sqrt(dx*dx + dy*dy + dz*dz)); hx = std::max(hx, std::fabs(dx)); hy = std::max(hy, std::fabs(dy)); hz = std::max(hz, std::fabs(dz));
+        }
+        q.radius = r * 1.00001f + 1e-7f; q.hx = hx + 1e-7f; q.hy = hy + 1e-7f; q.hz = hz + 1e-7f;
+    }
+    d.verts = H->verts.data(); d.pieces = H->pieces.data();
+    for (int l = 0; l < 8; ++l) d.link_piece[l] = s.link_piece[l];
+    d.n_static = s.n_static; for (int i = 0; i < s.n_static; ++i) d.static_piece[i] = s.static_piece[i];
+    d.static_mask = s.static_link_mask; d.static_max = (float)s.static_max_distance; d.moving_mask = s.moving_link_mask; d.contact_mask = s.contact_link_mask;
+    d.moving_max = (float)s.moving_max_distance; d.contact_dist = (float)s.contact_distance; d.n_planets = s.n_planets;
+    for (int p = 0; p < s.n_planets; ++p) {
+        const smr_planet_t &pl = s.planet[p];
+        H->pose[p].assign((size_t)pl.n_orbit * 8, 0.f); H->local[p].resize((size_t)pl.n_orbit * 2);
+        for (int i = 0; i < pl.n_orbit; ++i) { for (int c = 0; c < 7; ++c) H->pose[p][(size_t)i*8+c] = (float)pl.orbit_pose[(size_t)i*7+c];
+            H->local[p][2*(size_t)i] = (float)pl.orbit_local[2*(size_t)i]; H->local[p][2*(size_t)i+1] = (float)pl.orbit_local[2*(size_t)i+1]; }
+        DPlanet &q = d.planet[p];
+        q.piece_begin = pl.piece_begin; q.piece_count = pl.piece_count; q.n_orbit = pl.n_orbit; q.index_shift = pl.index_shift; q.coupled = pl.coupled;
+        q.orbit_pose = H->pose[p].data(); q.orbit_local = H->local[p].data();
+    }
+    d.term_moving = s.terminate_on_moving_collision; d.collision_dist = (float)s.collision_distance;
+    return H;
+}
+extern "C" void emul_distances(void *h, const float *q, const int *idx, int want_dist, int want_contact, float *out) {
+    HostScene *H = (HostScene *)h;
+    Sample r = collide_sample(H->d, q, idx, want_dist != 0, want_contact != 0);
+    out[0] = r.d_static; out[1] = r.d_moving; out[2] = r.contact ? 1.f : 0.f;
+}
+
+extern "C" int emul_simplex(float *w /*4x3 in/out*/, int n, float *v_out) {
+    F3 a{w[0],w[1],w[2]}, b{w[3],w[4],w[5]}, c{w[6],w[7],w[8]}, d{w[9],w[10],w[11]}, v{0,0,0};
+    bool inside = simplex_solve(a, b, c, d, n, v);
+    float o[12] = {a.x,a.y,a.z,b.x,b.y,b.z,c.x,c.y,c.z,d.x,d.y,d.z};
+    for (int i = 0; i < 12; ++i) w[i] = o[i];
+    v_out[0] = v.x; v_out[1] = v.y; v_out[2] = v.z;
+    return inside ? -1 : n;
+}

@@ -1,0 +1,70 @@
+"""The DEVICE functions of safemotionsrisk_amd/csrc/smr_device.h compiled for the host (float32, same source,
+tests/host_emul/emul.cpp) against the float64 oracle.  Runs without a GPU; it is how numerical problems of the
+kernels' GJK / range code are reproduced and debugged on a CPU.  Not a product path: nothing outside tests/
+loads libemul.so."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_emul", "emul.cpp")
+LIB = os.path.join(HERE, "host_emul", "libemul.so")
+
+
+@pytest.fixture(scope="module", params=["off", "fast"])
+def emul(request, built):
+    """Two builds: without and with FMA contraction (hipcc contracts by default)."""
+    lib = LIB.replace(".so", "_%s.so" % request.param)
+    flags = ["-ffp-contract=off"] if request.param == "off" else ["-ffp-contract=fast", "-mfma"]
+    dev = os.path.join(HERE, "..", "safemotionsrisk_amd", "csrc", "smr_device.h")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(SRC), os.path.getmtime(dev)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", lib, SRC] + flags)
+    E = C.CDLL(lib)
+    E.emul_scene_create.restype = C.c_void_p
+    return E
+
+
+def test_device_distances_on_host(emul, space_scene):
+    s = space_scene.struct
+    ora = O.OracleEnv(space_scene, 1)
+    H = C.c_void_p(emul.emul_scene_create(C.cast(space_scene.pointer(), C.c_void_p)))
+    rng = np.random.default_rng(0)
+    clamp = lambda x: 0.0 if x < 0.001 else x
+    worst = 0.0
+    for _ in range(1500):
+        q = rng.uniform(np.array(s.pos_lo), np.array(s.pos_hi)).astype(np.float32)
+        i0 = int(rng.integers(1200))
+        idx = np.array([i0, (i0 - 480) % 1200], dtype=np.int32)
+        out = np.zeros(3, np.float32)
+        emul.emul_distances(H, q.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), 1, 0, out.ctypes.data_as(C.c_void_p))
+        d = ora.distances(q.astype(np.float64), idx)
+        if min(abs(d[0] - 0.001), abs(d[2] - 0.001)) < 2e-5:
+            continue
+        worst = max(worst, abs(clamp(out[0]) - clamp(d[0])), abs(clamp(out[1]) - clamp(d[2])))
+        c = np.zeros(3, np.float32)
+        emul.emul_distances(H, q.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), 0, 1, c.ctypes.data_as(C.c_void_p))
+        if abs(d[2] - 0.02) > 2e-5:
+            assert c[2] == d[3]
+    assert worst < 2e-6
+
+
+def test_device_acc_range_on_host(emul, space_scene):
+    s = space_scene.struct
+    rng = np.random.default_rng(1)
+    emul.emul_safe_acc_range.argtypes = [C.c_float] * 9 + [C.c_void_p] * 3
+    worst = 0.0
+    for _ in range(3000):
+        j = int(rng.integers(7))
+        L = (s.pos_lo[j], s.pos_hi[j], s.vel_max[j], s.acc_max[j], s.jerk_max[j] * float(rng.choice([1.0, 0.5, 0.2])), 0.1)
+        p = np.float32(rng.uniform(L[0], L[1])); v = np.float32(rng.uniform(-L[2], L[2])); a = np.float32(rng.uniform(-L[3], L[3]))
+        lo, hi, code = C.c_float(), C.c_float(), C.c_int()
+        emul.emul_safe_acc_range(*[float(x) for x in L], float(p), float(v), float(a), C.byref(lo), C.byref(hi), C.byref(code))
+        olo, ohi, ocode = O.safe_acc_range_joint(*[float(x) for x in L], float(p), float(v), float(a))
+        assert code.value == ocode
+        worst = max(worst, abs(lo.value - olo) / L[3], abs(hi.value - ohi) / L[3])
+    assert worst < 2e-4
