@@ -78,7 +78,8 @@ struct DState {
     int *moving_hit;           // [B]
     unsigned *rng_draws;       // [B]
     float *a1;                 // [7][B]   plan -> collide/finish
-    float *res;                // [N][4][B] collide -> finish: contact, d_static, d_moving, -
+    float *res;                // [N][8][B] collide -> finish: contact flag of (sample k, link l)
+    float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
     int *done_list;            // [B]
     int *done_count;           // [1]
 };
@@ -542,6 +543,42 @@ __device__ inline Sample collide_sample(const DScene &S, const float q[SMR_NJ], 
                 if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
                 if (con && d <= S.contact_dist) out.contact = true;
             }
+        }
+    }
+    return out;
+}
+
+// The same queries for ONE robot link (the step path runs one lane per (env, sample, link): 8x the
+// wavefronts of collide_sample, which is what keeps the SIMDs occupied while lanes wait on each other).
+// T is the link frame; every loop bound and piece index is wave uniform.
+__device__ inline Sample collide_link(const DScene &S, int l, const Xf &T, const int idx[SMR_MAX_PLANETS], bool want_dist,
+                                      bool want_contact) {
+    Sample out;
+    out.d_static = S.static_max;
+    out.d_moving = S.moving_max + 0.002f;
+    out.contact = false;
+    const int pl = S.link_piece[l];
+    if (want_dist && ((S.static_mask >> l) & 1u)) {
+        for (int s = 0; s < S.n_static; ++s) {
+            float d = piece_distance<true>(S, S.static_piece[s], T, pl, T, out.d_static, S.collision_dist);
+            if (d <= S.static_max && d < out.d_static) out.d_static = d;
+        }
+    }
+    const bool mov = want_dist && ((S.moving_mask >> l) & 1u);
+    const bool con_link = (S.contact_mask >> l) & 1u;
+    if (!(mov || (want_contact && con_link))) return out;
+    const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
+    for (int p = 0; p < S.n_planets; ++p) {
+        const Xf XP = planet_pose(S, p, idx[p]);
+        const int pb = S.planet[p].piece_begin, pc = S.planet[p].piece_count;
+        for (int c = 0; c < pc; ++c) {
+            const bool con = want_contact && con_link && !out.contact;
+            if (!(mov || con)) continue;
+            float cutoff = mov ? fminf(out.d_moving, S.moving_max) : S.contact_dist;
+            if (con) cutoff = fmaxf(cutoff, S.contact_dist);
+            float d = piece_distance<false>(S, pb + c, XP, pl, T, cutoff, stop_moving);
+            if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
+            if (con && d <= S.contact_dist) out.contact = true;
         }
     }
     return out;

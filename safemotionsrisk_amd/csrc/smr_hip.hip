@@ -1,14 +1,15 @@
 // smr_hip.hip - kernels and C ABI of libsmr_hip.so (include/safemotions_hip.h).  gfx950 only.
 //
 // step() = three launches on the handle's stream (+ one for the envs that finished):
-//   plan    (B lanes)      A2/A4  safe acceleration range of the current state, action -> end acceleration
-//   collide (B x N lanes)  A3/A6/A7/A8/A11  sample k of the cubic: FK + GJK contact test; the last sample
-//                          also yields the table / planet minimum distances of the reward
+//   plan    (B x 7 lanes)  A2/A4  safe acceleration range of the current state, action -> end acceleration
+//   collide (B x N x 8 lanes)  A3/A6/A7/A8/A11  (sample k of the cubic, link l): FK + GJK contact test; the last
+//                          sample also yields the table / planet minimum distances of the reward
 //   finish  (B lanes)      A1/A12/A13/A15/A16  latch, state update, reward, termination, observation,
 //                          wave-aggregated append of finished envs to the reset list
 //   reset   (B lanes, only list entries work)  A17/A9  start state + planet phase by rejection sampling
-// The B x N grid of `collide` puts each collision sample on its own lane: 3x (N=3) the wavefronts of a
-// one-lane-per-env launch, which is what fills the 1024 SIMDs of the chip at B = 65 536.
+// The B x N x 8 grid of `collide` puts every (sample, link) on its own lane: 24x (N=3) the wavefronts of a
+// one-lane-per-env launch.  The GJK loops are divergent and wait on scalar loads; only many resident
+// wavefronts per SIMD keep the 1024 SIMDs of the chip busy at B = 65 536.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -24,44 +25,49 @@ namespace smr {
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
+// one lane per (env, joint): 7x the wavefronts of a lane-per-env launch (the bisection loops diverge)
 __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions) {
     const DScene &S = *Sp;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
     const int B = S.B;
-#pragma unroll 1
-    for (int j = 0; j < SMR_NJ; ++j) {
-        float lo, hi;
-        int code;
-        safe_acc_range_joint(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code);
-        float u = actions[(size_t)e * SMR_NJ + j];
-        st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
-    }
+    const int j = blockIdx.y;
+    float lo, hi;
+    int code;
+    safe_acc_range_joint(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code);
+    float u = actions[(size_t)e * SMR_NJ + j];
+    st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
 }
 
+// one lane per (env, sample k, link l); grid = (B/64, N, 8)
 __global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
     const int B = S.B, N = S.checks_per_step;
     const int k = (int)blockIdx.y + 1;                 // sample k of N, t_k = k dt / N
+    const int l = (int)blockIdx.z;                     // iiwa_link_l
     const bool final_sample = (k == N);
-    float *res = st.res + (size_t)(k - 1) * 4 * B;
-    const bool want_contact = S.term_moving && S.n_planets > 0 && st.moving_hit[e] == 0;
-    if (!final_sample && !want_contact) { res[e] = 0.f; return; }
-    const float t = S.dt * (float)k / (float)N;
-    float q[SMR_NJ];
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j)
-        q[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], final_sample ? S.dt : t, S.dt);
+    float *res = st.res + ((size_t)(k - 1) * SMR_NLINK + l) * B;
+    const bool want_contact = S.term_moving && S.n_planets > 0 && st.moving_hit[e] == 0 && ((S.contact_mask >> l) & 1u);
+    const bool want_dist = final_sample && (((S.static_mask | S.moving_mask) >> l) & 1u);
+    if (final_sample) { st.dist[(size_t)l * B + e] = S.static_max; st.dist[(size_t)(SMR_NLINK + l) * B + e] = S.moving_max + 0.002f; }
+    res[e] = 0.f;
+    if (!want_dist && !want_contact) return;
+    const float t = final_sample ? S.dt : S.dt * (float)k / (float)N;
+    Xf T = fk_base(S);
+    for (int j = 0; j < l; ++j) {                      // FK up to this link; joint values straight from the cubic
+        float qj = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
+        fk_advance(S, j, qj, T);
+    }
     int idx[SMR_MAX_PLANETS] = {0, 0};
     const int upd = S.updates_per_step / N;
 #pragma unroll
     for (int p = 0; p < SMR_MAX_PLANETS; ++p)
         if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
-    Sample r = collide_sample(S, q, idx, final_sample, want_contact);
+    Sample r = collide_link(S, l, T, idx, want_dist, want_contact);
     res[e] = r.contact ? 1.f : 0.f;
-    if (final_sample) { res[B + e] = r.d_static; res[2 * B + e] = r.d_moving; }
+    if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(SMR_NLINK + l) * B + e] = r.d_moving; }
 }
 
 __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions,
@@ -74,9 +80,13 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     const int steps = st.step_count[e] + 1;                                   // base.py:1044
     int hit = st.moving_hit[e];
     if (S.term_moving && S.n_planets > 0)                                     // ctlp.py:2631-2637
-        for (int k = 0; k < N; ++k) hit |= (st.res[(size_t)k * 4 * B + e] != 0.f) ? 1 : 0;
-    const float *resN = st.res + (size_t)(N - 1) * 4 * B;
-    float d_static = resN[B + e], d_self = S.static_max, d_moving = resN[2 * B + e];
+        for (int k = 0; k < N * SMR_NLINK; ++k) hit |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;
+    float d_static = S.static_max, d_self = S.static_max, d_moving = S.moving_max + 0.002f;
+#pragma unroll
+    for (int l = 0; l < SMR_NLINK; ++l) {                                     // minimum over links, ctlp.py:3263-3278,3294-3320
+        d_static = fminf(d_static, st.dist[(size_t)l * B + e]);
+        d_moving = fminf(d_moving, st.dist[(size_t)(SMR_NLINK + l) * B + e]);
+    }
 
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ], amax = 0.f, vrel = 0.f, arel = 0.f;
 #pragma unroll
@@ -572,7 +582,8 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.rng_draws, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)env->N * 4 * B)) || (rc = dev_alloc(env, &st.done_list, B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)env->N * SMR_NLINK * B)) || (rc = dev_alloc(env, &st.dist, 2 * SMR_NLINK * B)) ||
+        (rc = dev_alloc(env, &st.done_list, B)) ||
         (rc = dev_alloc(env, &st.done_count, 1)))
         return fail(rc);
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
@@ -689,12 +700,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (env->auto_reset) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));
     {
         LaunchTimer t(env, SMR_K_PLAN);
-        hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
+        hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
     }
     SMR_HIP(hipGetLastError());
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
-        hipLaunchKernelGGL(collide_kernel, dim3((B + 63) / 64, env->N), dim3(64), 0, env->stream, env->dscene, env->st);
+        hipLaunchKernelGGL(collide_kernel, dim3((B + 63) / 64, env->N, SMR_NLINK), dim3(64), 0, env->stream, env->dscene, env->st);
     }
     SMR_HIP(hipGetLastError());
     {
