@@ -69,7 +69,7 @@ typedef struct smr_host_state {
     int32_t *planet_idx;   /* [B][2] Planet._current_time_step_index, ctlp.py:4504               */
     int32_t *step_count;   /* [B]    _episode_length, base.py:1044                               */
     int32_t *moving_hit;   /* [B]    latched Planet._collision_detected, ctlp.py:4570-4579       */
-    uint32_t *rng_draws;   /* [B]    per-env Philox draw counter                                */
+    uint32_t *reset_count; /* [B]    resets of the env so far = Philox tag of its next reset            */
 } smr_host_state_t;
 
 int smr_abi_version(void);

@@ -45,7 +45,7 @@ def lib():
         L.smo_vel_peak_bruteforce.restype = C.c_double
         L.smo_vel_peak_bruteforce.argtypes = [C.c_double] * 7
         L.smo_philox_word.restype = C.c_uint32
-        L.smo_philox_word.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.smo_philox_word.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
 
@@ -110,18 +110,18 @@ class OracleEnv:
         B = self.B
         st = dict(q=np.zeros((B, NJ)), v=np.zeros((B, NJ)), a=np.zeros((B, NJ)),
                   planet_idx=np.zeros((B, 2), dtype=np.int32), step_count=np.zeros(B, dtype=np.int32),
-                  moving_hit=np.zeros(B, dtype=np.int32), rng_draws=np.zeros(B, dtype=np.uint32))
+                  moving_hit=np.zeros(B, dtype=np.int32), reset_count=np.zeros(B, dtype=np.uint32))
         self.L.smo_get_state(self.h, _p(st["q"]), _p(st["v"]), _p(st["a"]), _p(st["planet_idx"]),
-                             _p(st["step_count"]), _p(st["moving_hit"]), _p(st["rng_draws"]))
+                             _p(st["step_count"]), _p(st["moving_hit"]), _p(st["reset_count"]))
         return st
 
-    def set_state(self, q=None, v=None, a=None, planet_idx=None, step_count=None, moving_hit=None, rng_draws=None):
+    def set_state(self, q=None, v=None, a=None, planet_idx=None, step_count=None, moving_hit=None, reset_count=None):
         def f(x, dt, shape):
             return None if x is None else np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=dt), shape))
         B = self.B
         arrs = [f(q, np.float64, (B, NJ)), f(v, np.float64, (B, NJ)), f(a, np.float64, (B, NJ)),
                 f(planet_idx, np.int32, (B, 2)), f(step_count, np.int32, (B,)), f(moving_hit, np.int32, (B,)),
-                f(rng_draws, np.uint32, (B,))]
+                f(reset_count, np.uint32, (B,))]
         self.L.smo_set_state(self.h, *[_p(x) for x in arrs])
 
     # ---- component entry points ----
@@ -162,8 +162,8 @@ def safe_acc_range_joint(plo, phi, V, A, J, dt, p, v, a):
     return lo.value, hi.value, code.value
 
 
-def philox_word(seed, env, draw):
-    return lib().smo_philox_word(seed, env, draw)
+def philox_word(seed, env, stream, tag, draw):
+    return lib().smo_philox_word(seed, env, stream, tag, draw)
 
 
 def vel_upper_a1max(V, A, J, dt, v0, a0):

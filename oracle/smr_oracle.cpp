@@ -64,9 +64,8 @@ inline void quat_to_R(const double q[4], double R[9]) {
 }
 
 /* ------------------------------------------------------------------------------------------- *
- * RNG: Philox4x32-10 (Salmon et al., SC'11), key = seed, counter = (block, env, stream, 0).
- * Draw d of env e is word d&3 of block d>>2.  uniform01 keeps 24 bits, so the same draw is exact
- * in float32 and float64.  The reference uses numpy's global Mersenne Twister with data-dependent
+ * RNG: Philox4x32-10 (Salmon et al., SC'11), key = seed.  uniform01 keeps 24 bits, so the same draw is
+ * exact in float32 and float64.  The reference uses numpy's global Mersenne Twister with data-dependent
  * draw counts (base.py:1704-1710, ctlp.py:2030-2138); reset parity is therefore property based.
  * ------------------------------------------------------------------------------------------- */
 inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -82,21 +81,25 @@ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
     }
 }
 
+/* Stateless addressing: draw d of (env, stream, tag) = word d&3 of philox(counter = (d>>2, env, stream, tag)).
+ * tag = the env's reset counter, so every reset of every env has its own streams and the order in which
+ * the streams are consumed does not matter (the GPU kernel evaluates candidates of one stream in parallel).
+ * streams: 0 start-position attempts, 1..7 joint velocity/acceleration tries, 8 random walk, 9 planet phase,
+ * 10 sampling-mode choice. */
+enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10 };
+
 struct Rng {
     uint64_t seed;
-    uint32_t env;
-    uint32_t draws;     // persistent per-env draw counter (part of the env state)
-    uint32_t next_u32() {
-        uint32_t c[4] = {draws >> 2, env, 0u, 0u};
+    uint32_t env, tag;
+    uint32_t u32(uint32_t stream, uint32_t draw) const {
+        uint32_t c[4] = {draw >> 2, env, stream, tag};
         philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        uint32_t w = c[draws & 3u];
-        ++draws;
-        return w;
+        return c[draw & 3u];
     }
-    double uniform01() { return (double)(next_u32() >> 8) * (1.0 / 16777216.0); }
-    double uniform(double lo, double hi) { return lo + uniform01() * (hi - lo); }
-    int randint(int n) {                 // [0, n), integer arithmetic so float32 and float64 agree
-        return (int)(((uint64_t)(next_u32() >> 8) * (uint64_t)n) >> 24);
+    double uniform01(uint32_t stream, uint32_t draw) const { return (double)(u32(stream, draw) >> 8) * (1.0 / 16777216.0); }
+    double uniform(uint32_t stream, uint32_t draw, double lo, double hi) const { return lo + uniform01(stream, draw) * (hi - lo); }
+    int randint(uint32_t stream, uint32_t draw, int n) const {     /* [0, n), integer arithmetic: same in float32/64 */
+        return (int)(((uint64_t)(u32(stream, draw) >> 8) * (uint64_t)n) >> 24);
     }
 };
 
@@ -323,7 +326,7 @@ static V3 simplex_closest(V3 w[4], int &n) {
                 for (int r = c + 1; r < m; ++r) if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
                 double scale = 0;
                 for (int j = 0; j < m; ++j) scale = std::max(scale, std::fabs(M[c][j]));
-                if (std::fabs(M[piv][c]) <= 1e-14 * std::max(scale, 1e-300)) { singular = true; break; }
+                if (std::fabs(M[piv][c]) <= 1e-10 * std::max(scale, 1e-300)) { singular = true; break; }   /* (nearly) flat */
                 if (piv != c) for (int j = 0; j <= m; ++j) std::swap(M[piv][j], M[c][j]);
                 for (int r = 0; r < m; ++r) {
                     if (r == c) continue;
@@ -340,8 +343,12 @@ static V3 simplex_closest(V3 w[4], int &n) {
         for (int i = 0; i < k; ++i) if (lam[i] < -1e-12) inside = false;
         if (!inside) continue;
         V3 pnt = {0, 0, 0};
-        for (int i = 0; i < k; ++i) pnt = pnt + std::max(lam[i], 0.0) * w[idx[i]];
+        double wmax = 0;
+        for (int i = 0; i < k; ++i) { pnt = pnt + std::max(lam[i], 0.0) * w[idx[i]]; wmax = std::max(wmax, dot(w[idx[i]], w[idx[i]])); }
         double d2 = dot(pnt, pnt);
+        /* a tetrahedron only "contains the origin" if its barycentric combination really reproduces it
+         * (guards against garbage weights of a nearly flat tetrahedron) */
+        if (k == 4 && d2 > 1e-16 * wmax) continue;
         if (d2 < bestd) { bestd = d2; bestp = pnt; bestmask = mask; }
     }
     V3 nw[4];
@@ -392,7 +399,7 @@ struct EnvState {
     int32_t planet_idx[SMR_MAX_PLANETS];
     int32_t step_count;
     int32_t moving_hit;        /* latched Planet._collision_detected / ball hit_robot */
-    uint32_t rng_draws;
+    uint32_t reset_count;      /* number of resets of this env = Philox tag of the next reset */
 };
 
 struct Oracle {
@@ -537,78 +544,85 @@ bool position_is_valid(const Oracle &O, const double q[SMR_NJ]) {
     return true;
 }
 
-void sample_position(const Oracle &O, Rng &rng, double q[SMR_NJ]) {
-    for (int attempt = 0; attempt < 100000; ++attempt) {
-        for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(O.S.pos_lo[j], O.S.pos_hi[j]);   /* ctlp.py:2035-2037 */
+/* next valid start position: attempt n uses draws 7n..7n+6 of stream S_POS (ctlp.py:2030-2037) */
+void sample_position(const Oracle &O, const Rng &rng, uint32_t &attempt, double q[SMR_NJ]) {
+    for (int it = 0; it < 100000; ++it) {
+        uint32_t n = attempt++;
+        for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S_POS, 7 * n + j, O.S.pos_lo[j], O.S.pos_hi[j]);
         if (position_is_valid(O, q)) return;
     }
+}
+
+bool table_free(const Oracle &O, const double q[SMR_NJ]) {                    /* ctlp.py:1605-1619 (table + self: no pairs) */
+    const smr_scene_t &S = O.S;
+    Xf link[SMR_NLINK];
+    forward_kinematics(S, q, link);
+    Xf I = identity_xf();
+    for (int s = 0; s < S.n_static; ++s)
+        for (int k = 0; k < SMR_NLINK; ++k) {
+            if (!(S.static_link_mask & (1u << k))) continue;
+            double thr = S.start_min_dist_static;
+            double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], thr + 0.005);
+            if (d <= thr + 0.005 && d < thr) return false;
+        }
+    return true;
 }
 
 void reset_env(Oracle &O, int e) {
     const smr_scene_t &S = O.S;
     EnvState &st = O.st[e];
-    Rng rng = {O.seed, (uint32_t)e, st.rng_draws};
+    Rng rng = {O.seed, (uint32_t)e, st.reset_count};
+    st.reset_count += 1;
     double q[SMR_NJ], v[SMR_NJ] = {0}, a[SMR_NJ] = {0};
-    sample_position(O, rng, q);
+    uint32_t attempt = 0;
+    sample_position(O, rng, attempt, q);
     /* A17 part 2: get_starting_point_joint_pos_vel_acc, ctlp.py:1490-1654 */
-    if (S.kinematic_state_sampling_mode && rng.uniform01() < S.kinematic_state_sampling_probability) {
-        for (;;) {                                                                           /* ctlp.py:1499-1556 */
+    if (S.kinematic_state_sampling_mode && rng.uniform01(S_MODE, 0) < S.kinematic_state_sampling_probability) {
+        for (uint32_t round = 0;; ++round) {                                                  /* ctlp.py:1499-1556 */
             bool all_found = true;
-            for (int j = 0; j < SMR_NJ && all_found; ++j) {
+            for (int j = 0; j < SMR_NJ; ++j) {
                 bool found = false;
                 JointLim L = joint_lim(S, j);
-                for (int tv = 0; tv < 5 && !found; ++tv) {
-                    double vj = rng.uniform(-S.vel_max[j], S.vel_max[j]);
-                    for (int ta = 0; ta < 10 && !found; ++ta) {
-                        double aj = rng.uniform(-S.acc_max[j], S.acc_max[j]);
+                for (uint32_t tv = 0; tv < 5 && !found; ++tv) {
+                    double vj = rng.uniform(S_JOINT + j, round * 55 + tv * 11, -S.vel_max[j], S.vel_max[j]);
+                    for (uint32_t ta = 0; ta < 10 && !found; ++ta) {
+                        double aj = rng.uniform(S_JOINT + j, round * 55 + tv * 11 + 1 + ta, -S.acc_max[j], S.acc_max[j]);
                         double lo, hi;
                         int code;
                         safe_acc_range_joint(L, q[j], vj, aj, lo, hi, code);
                         if (code == 0) { found = true; v[j] = vj; a[j] = aj; }
                     }
                 }
-                if (!found) all_found = false;
+                if (!found) all_found = false;      /* the reference resamples the position and starts over */
             }
             if (all_found) break;
-            sample_position(O, rng, q);
+            sample_position(O, rng, attempt, q);
         }
     } else {                                                                                  /* ctlp.py:1558-1654 */
         double hq[3][SMR_NJ], hv[3][SMR_NJ], ha[3][SMR_NJ];   /* ring of the three latest states */
         int count = 1;
+        uint32_t w = 0;
         std::memcpy(hq[0], q, sizeof q); std::memcpy(hv[0], v, sizeof v); std::memcpy(ha[0], a, sizeof a);
         for (int walk = 0; walk < 64; ++walk) {
-            if (rng.uniform01() < S.stay_in_state_probability) break;
+            if (rng.uniform01(S_WALK, w++) < S.stay_in_state_probability) break;
             const double *cq = hq[(count - 1) % 3], *cv = hv[(count - 1) % 3], *ca = ha[(count - 1) % 3];
             double nq[SMR_NJ], nv[SMR_NJ], na[SMR_NJ];
-            double lo[SMR_NJ], hi[SMR_NJ];
             for (int j = 0; j < SMR_NJ; ++j) {
+                double lo, hi;
                 int code;
-                safe_acc_range_joint(joint_lim(S, j), cq[j], cv[j], ca[j], lo[j], hi[j], code);
-            }
-            for (int j = 0; j < SMR_NJ; ++j) {
-                double u = rng.uniform(-1.0, 1.0);
-                na[j] = lo[j] + 0.5 * (u + 1) * (hi[j] - lo[j]);
+                safe_acc_range_joint(joint_lim(S, j), cq[j], cv[j], ca[j], lo, hi, code);
+                double u = rng.uniform(S_WALK, w + j, -1.0, 1.0);
+                na[j] = lo + 0.5 * (u + 1) * (hi - lo);
                 nv[j] = interp_vel(cv[j], ca[j], na[j], S.dt, S.dt);
                 nq[j] = interp_pos(cq[j], cv[j], ca[j], na[j], S.dt, S.dt);
             }
-            /* end position collision free? (table + self only, ctlp.py:1605-1619) */
-            Xf link[SMR_NLINK];
-            forward_kinematics(S, nq, link);
-            bool free_pos = true;
-            Xf I = identity_xf();
-            for (int s = 0; s < S.n_static && free_pos; ++s)
-                for (int k = 0; k < SMR_NLINK; ++k) {
-                    if (!(S.static_link_mask & (1u << k))) continue;
-                    double thr = S.start_min_dist_static;
-                    double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], thr + 0.005);
-                    if (d <= thr + 0.005 && d < thr) { free_pos = false; break; }
-                }
-            if (free_pos) {
+            w += SMR_NJ;
+            if (table_free(O, nq)) {
                 std::memcpy(hq[count % 3], nq, sizeof nq); std::memcpy(hv[count % 3], nv, sizeof nv);
                 std::memcpy(ha[count % 3], na, sizeof na);
                 ++count;
             } else {
-                int sel = 1 + rng.randint(std::min(count, 3));       /* ctlp.py:1641-1646 */
+                int sel = 1 + rng.randint(S_WALK, w++, std::min(count, 3));       /* ctlp.py:1641-1646 */
                 count = count - sel + 1;
                 break;
             }
@@ -625,14 +639,14 @@ void reset_env(Oracle &O, int e) {
         Xf link[SMR_NLINK];
         forward_kinematics(S, q, link);
         int32_t idx[SMR_MAX_PLANETS] = {0, 0};
-        for (int attempt = 0; attempt < 100000; ++attempt) {
+        int n_indep = 0;
+        for (int p = 0; p < S.n_planets; ++p) n_indep += S.planet[p].coupled ? 0 : 1;
+        for (uint32_t n = 0; n < 100000; ++n) {
+            int i = 0;
             for (int p = 0; p < S.n_planets; ++p) {
-                if (S.planet[p].coupled) {
-                    int n = S.planet[p].n_orbit;
-                    idx[p] = ((idx[0] + S.planet[p].index_shift) % n + n) % n;
-                } else {
-                    idx[p] = rng.randint(S.planet[p].n_orbit);
-                }
+                int no = S.planet[p].n_orbit;
+                if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % no + no) % no;
+                else idx[p] = rng.randint(S_PLANET, n * n_indep + (i++), no);
             }
             if (!moving_contact(O, link, idx)) break;
         }
@@ -642,7 +656,6 @@ void reset_env(Oracle &O, int e) {
         if (S.terminate_on_moving_collision && moving_contact(O, link, idx)) st.moving_hit = 1;
         for (int p = 0; p < S.n_planets; ++p) st.planet_idx[p] = idx[p];
     }
-    st.rng_draws = rng.draws;
 }
 
 /* info columns written by step (mirrors the product's SMR_INFO_* layout) */
@@ -813,7 +826,7 @@ void smo_step(void *h, const double *actions, float *obs, double *reward, uint8_
 }
 
 void smo_get_state(void *h, double *q, double *v, double *a, int32_t *planet_idx, int32_t *step_count,
-                   int32_t *moving_hit, uint32_t *rng_draws) {
+                   int32_t *moving_hit, uint32_t *reset_count) {
     Oracle &O = *(Oracle *)h;
     for (int e = 0; e < O.B; ++e) {
         const EnvState &s = O.st[e];
@@ -825,12 +838,12 @@ void smo_get_state(void *h, double *q, double *v, double *a, int32_t *planet_idx
         if (planet_idx) for (int p = 0; p < SMR_MAX_PLANETS; ++p) planet_idx[e * SMR_MAX_PLANETS + p] = s.planet_idx[p];
         if (step_count) step_count[e] = s.step_count;
         if (moving_hit) moving_hit[e] = s.moving_hit;
-        if (rng_draws) rng_draws[e] = s.rng_draws;
+        if (reset_count) reset_count[e] = s.reset_count;
     }
 }
 
 void smo_set_state(void *h, const double *q, const double *v, const double *a, const int32_t *planet_idx,
-                   const int32_t *step_count, const int32_t *moving_hit, const uint32_t *rng_draws) {
+                   const int32_t *step_count, const int32_t *moving_hit, const uint32_t *reset_count) {
     Oracle &O = *(Oracle *)h;
     for (int e = 0; e < O.B; ++e) {
         EnvState &s = O.st[e];
@@ -842,7 +855,7 @@ void smo_set_state(void *h, const double *q, const double *v, const double *a, c
         if (planet_idx) for (int p = 0; p < SMR_MAX_PLANETS; ++p) s.planet_idx[p] = planet_idx[e * SMR_MAX_PLANETS + p];
         if (step_count) s.step_count = step_count[e];
         if (moving_hit) s.moving_hit = moving_hit[e];
-        if (rng_draws) s.rng_draws = rng_draws[e];
+        if (reset_count) s.reset_count = reset_count[e];
     }
 }
 
@@ -915,9 +928,9 @@ int32_t smo_position_is_valid(void *h, const double *q) { return position_is_val
 void smo_count_work(int32_t enable) { g_count_work = enable != 0; g_support_calls = 0; }
 int64_t smo_support_vertex_visits(void) { return g_support_calls; }
 
-uint32_t smo_philox_word(uint64_t seed, uint32_t env, uint32_t draw) {
-    Rng r = {seed, env, draw};
-    return r.next_u32();
+uint32_t smo_philox_word(uint64_t seed, uint32_t env, uint32_t stream, uint32_t tag, uint32_t draw) {
+    Rng r = {seed, env, tag};
+    return r.u32(stream, draw);
 }
 
 }  // extern "C"

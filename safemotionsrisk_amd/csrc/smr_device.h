@@ -46,6 +46,7 @@ struct DScene {
     int B, obs_size, episode_steps, updates_per_step, checks_per_step, auto_reset;
     float dt;
     float pos_lo[SMR_NJ], pos_hi[SMR_NJ], vel_max[SMR_NJ], acc_max[SMR_NJ], jerk_max[SMR_NJ];
+    float pos_lo_res[SMR_NJ], pos_hi_res[SMR_NJ], vel_max_res[SMR_NJ];   // float64 limit minus its float32 image
     float base[3], joint_xyz[SMR_NJ][3], joint_axis[SMR_NJ][3], ee_offset[3];
     const float4 *verts;
     const DPiece *pieces;
@@ -76,7 +77,7 @@ struct DState {
     int *planet_idx;           // [2][B]
     int *step_count;           // [B]
     int *moving_hit;           // [B]
-    unsigned *rng_draws;       // [B]
+    unsigned *reset_count;     // [B]  number of resets of the env = Philox tag of its next reset
     float *a1;                 // [7][B]   plan -> collide/finish
     float *res;                // [N][8][B] collide -> finish: contact flag of (sample k, link l)
     float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
@@ -108,13 +109,18 @@ __device__ __forceinline__ F3 rot_t(const Xf &X, F3 v) {
 __device__ __forceinline__ F3 apply(const Xf &X, F3 v) { return rot(X, v) + X.t; }
 
 // ---------------------------------------------------------------------------------------------
-// RNG: Philox4x32-10, counter = (draw >> 2, env, 0, 0), key = seed; draw d uses word d & 3.
-// 24-bit uniforms are exact in float32.  (Reference: numpy global RNG, base.py:1704-1710.)
+// RNG: Philox4x32-10.  Stateless addressing: draw d of (env, stream, tag) is word d&3 of
+// philox(counter = (d>>2, env, stream, tag), key = seed); tag = the env's reset counter.  Streams are
+// independent, so the lanes of a group can evaluate candidates of one stream in parallel and still pick
+// "the first valid one" exactly like a sequential loop.  24-bit uniforms are exact in float32.
+// (Reference: numpy's global RNG, base.py:1704-1710.)
 // ---------------------------------------------------------------------------------------------
+enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10 };
+
 struct Rng {
-    unsigned k0, k1, env, draws;
-    __device__ unsigned next_u32() {
-        unsigned c0 = draws >> 2, c1 = env, c2 = 0u, c3 = 0u, a = k0, b = k1;
+    unsigned k0, k1, env, tag;
+    __device__ unsigned u32(unsigned stream, unsigned draw) const {
+        unsigned c0 = draw >> 2, c1 = env, c2 = stream, c3 = tag, a = k0, b = k1;
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
             unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -123,13 +129,14 @@ struct Rng {
             c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
             a += 0x9E3779B9u; b += 0xBB67AE85u;
         }
-        unsigned sel = draws & 3u;
-        ++draws;
+        unsigned sel = draw & 3u;
         return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
     }
-    __device__ float uniform01() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
-    __device__ float uniform(float lo, float hi) { return fmaf(uniform01(), hi - lo, lo); }
-    __device__ int randint(int n) { return (int)(((unsigned long long)(next_u32() >> 8) * (unsigned long long)n) >> 24); }
+    __device__ float uniform01(unsigned stream, unsigned draw) const { return (float)(u32(stream, draw) >> 8) * (1.0f / 16777216.0f); }
+    __device__ float uniform(unsigned stream, unsigned draw, float lo, float hi) const { return fmaf(uniform01(stream, draw), hi - lo, lo); }
+    __device__ int randint(unsigned stream, unsigned draw, int n) const {
+        return (int)(((unsigned long long)(u32(stream, draw) >> 8) * (unsigned long long)n) >> 24);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -148,7 +155,7 @@ __device__ __forceinline__ float interp_vel(float v0, float a0, float a1, float 
 // profile; see DESIGN.md "safe acceleration range".  Accelerations are piecewise linear with knots
 // every dt, |a| <= A, knot-to-knot change <= D = J dt.
 // ---------------------------------------------------------------------------------------------
-struct JointLim { float plo, phi, V, A, J, dt; };
+struct JointLim { float plo, phi, V, A, J, dt, plo_res, phi_res, V_res; };   // *_res: float64 limit - float32 image
 
 constexpr float kNoBound = 3.0e38f;
 
@@ -160,7 +167,7 @@ constexpr float kNoBound = 3.0e38f;
 // joint rides on the limit (V - v0 is exact for v0 near V).
 __device__ __forceinline__ float vel_upper_a1max(float v0, float a0, float V, float tol, const JointLim &L) {
     const float dt = L.dt, D = L.J * dt;
-    const float head = (V - v0) + tol;
+    const float head = (V - v0) + (tol + L.V_res);
     const float c = head - 0.5f * a0 * dt;
     if (c >= 0.f) {
         float x = L.J * (-0.5f * dt + sqrtf(0.25f * dt * dt + 2.0f * c / L.J));
@@ -195,36 +202,55 @@ __device__ __forceinline__ float seg_dmax(float v0, float a0, float a1, float dt
     return m;
 }
 
-// Does the joint stay below the position limit if, after a0 -> a1, it always takes the lowest acceleration
-// that the lower velocity limit still allows?  Works on displacements relative to the current position
-// (gap = limit - p0), so float32 resolves the few-micrometre margins that decide the bound near a limit.
-__device__ inline bool pos_upper_ok(float gap, float v0, float a0, float a1, float Vtol, const JointLim &L) {
-    if (seg_dmax(v0, a0, a1, L.dt) > gap) return false;
+// Margin (gap - largest displacement) of the profile "after a0 -> a1 always take the lowest acceleration the
+// lower velocity limit still allows", followed until the joint moves down again.  >= 0: the position limit
+// holds.  Works on displacements relative to the current position (gap = limit - p0), so float32 resolves the
+// few-micrometre margins that decide the bound near a limit.  Continuous and decreasing in a1.
+__device__ inline float pos_margin(float gap, float v0, float a0, float a1, float Vtol, const JointLim &L) {
+    float dmax = seg_dmax(v0, a0, a1, L.dt);
     float d = seg_disp(v0, a0, a1, L.dt, L.dt);
     float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1;
     const float D = L.J * L.dt;
     for (int it = 0; it < 4096; ++it) {
-        if (v <= 0.f && a <= 0.f) return true;
+        if (v <= 0.f && a <= 0.f) break;
+        if (dmax > gap + 1.0f) break;                           // hopeless (also bounds the loop for absurd inputs)
         float floor_v = -vel_upper_a1max(-v, -a, L.V, Vtol, L);
         float an = fmaxf(fmaxf(a - D, -L.A), fminf(floor_v, fminf(a + D, L.A)));
-        if (d + seg_dmax(v, a, an, L.dt) > gap) return false;
+        dmax = fmaxf(dmax, d + seg_dmax(v, a, an, L.dt));
         d += seg_disp(v, a, an, L.dt, L.dt);
         v += 0.5f * (a + an) * L.dt;
         a = an;
     }
-    return false;
+    return gap - dmax;
 }
 
-constexpr int kBisectIters = 30;
+__device__ __forceinline__ bool pos_upper_ok(float gap, float v0, float a0, float a1, float Vtol, const JointLim &L) {
+    return pos_margin(gap, v0, a0, a1, Vtol, L) >= 0.f;
+}
 
-// largest a1 in [lo, hi] accepted by the (monotone) position test
+constexpr int kRootIters = 48;
+
+// largest a1 in [lo, hi] with pos_margin >= 0 (the margin decreases with a1): regula falsi (Illinois) steps,
+// with a bisection step whenever the previous step failed to halve the bracket - the margin is flat where the
+// first segment decides and steep where the braking phase does, and pure regula falsi creeps along such a kink.
+// The answer is taken from the feasible end.  (The float64 oracle bisects.)
 __device__ inline float pos_upper_end(float gap, float v, float a, float Vtol, const JointLim &L, float lo, float hi, bool &infeasible) {
     infeasible = false;
-    if (pos_upper_ok(gap, v, a, hi, Vtol, L)) return hi;
-    if (!pos_upper_ok(gap, v, a, lo, Vtol, L)) { infeasible = true; return lo; }
-    for (int it = 0; it < kBisectIters; ++it) {
-        float mid = 0.5f * (lo + hi);
-        if (pos_upper_ok(gap, v, a, mid, Vtol, L)) lo = mid; else hi = mid;
+    float fhi = pos_margin(gap, v, a, hi, Vtol, L);
+    if (fhi >= 0.f) return hi;
+    float flo = pos_margin(gap, v, a, lo, Vtol, L);
+    if (flo < 0.f) { infeasible = true; return lo; }
+    const float xtol = 2e-7f * L.A;
+    int side = 0;
+    bool bisect = false;
+    for (int it = 0; it < kRootIters && hi - lo > xtol; ++it) {
+        const float w = hi - lo;
+        float x = (flo * hi - fhi * lo) / (flo - fhi);          // flo >= 0 > fhi
+        if (bisect || !(x > lo && x < hi)) x = 0.5f * (lo + hi);
+        float fx = pos_margin(gap, v, a, x, Vtol, L);
+        if (fx >= 0.f) { lo = x; flo = fx; if (side == 1) fhi *= 0.5f; side = 1; }
+        else { hi = x; fhi = fx; if (side == -1) flo *= 0.5f; side = -1; }
+        bisect = (hi - lo) > 0.5f * w;
     }
     return lo;
 }
@@ -243,7 +269,8 @@ __device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v,
     float vlo = fmaxf(blo, lv), vhi = fminf(bhi, uv);
     if (vlo > vhi) { code |= 4; vlo = vhi = 0.5f * (vlo + vhi); }
     bool inf;
-    const float gap_hi = L.phi - p, gap_lo = p - L.plo;       // exact for p near the limit (Sterbenz)
+    // exact for p near the limit (Sterbenz) + the part of the float64 limit that float32 cannot hold
+    const float gap_hi = (L.phi - p) + L.phi_res, gap_lo = (p - L.plo) - L.plo_res;
     float up = pos_upper_end(gap_hi + ptol, v, a, vtol, L, vlo, vhi, inf);
     if (inf && !pos_upper_ok(gap_hi + prep, v, a, vlo, vtol, L)) code |= 2;
     float lp = -pos_upper_end(gap_lo + ptol, -v, -a, vtol, L, -vhi, -vlo, inf);
@@ -258,7 +285,7 @@ __device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v,
 }
 
 __device__ __forceinline__ JointLim joint_lim(const DScene &S, int j) {
-    return {S.pos_lo[j], S.pos_hi[j], S.vel_max[j], S.acc_max[j], S.jerk_max[j], S.dt};
+    return {S.pos_lo[j], S.pos_hi[j], S.vel_max[j], S.acc_max[j], S.jerk_max[j], S.dt, S.pos_lo_res[j], S.pos_hi_res[j], S.vel_max_res[j]};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -584,16 +611,9 @@ __device__ inline Sample collide_link(const DScene &S, int l, const Xf &T, const
     return out;
 }
 
-// A15: observation row (obs.py:313-351), clipped to [-1, 1]
-__device__ inline void write_observation(const DScene &S, const float q[SMR_NJ], const float v[SMR_NJ],
-                                         const float a[SMR_NJ], const int idx[SMR_MAX_PLANETS], float *row) {
+// A15: planet part of the observation (obs.py:262-292)
+__device__ inline void write_planet_observation(const DScene &S, const int idx[SMR_MAX_PLANETS], float *row) {
     int o = 0;
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (q[j] - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) row[o++] = fminf(1.f, fmaxf(-1.f, v[j] / S.vel_max[j]));
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) row[o++] = fminf(1.f, fmaxf(-1.f, a[j] / S.acc_max[j]));
     for (int p = 0; p < S.obs_num_planets; ++p) {
         const int i = idx[p];
         if (S.obs_planet_size == 1) {
@@ -609,6 +629,18 @@ __device__ inline void write_observation(const DScene &S, const float q[SMR_NJ],
                 row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (pose[c] - S.planet_obs_min[c]) / (S.planet_obs_max[c] - S.planet_obs_min[c])));
         }
     }
+}
+
+// A15: observation row (obs.py:313-351), clipped to [-1, 1]
+__device__ inline void write_observation(const DScene &S, const float q[SMR_NJ], const float v[SMR_NJ],
+                                         const float a[SMR_NJ], const int idx[SMR_MAX_PLANETS], float *row) {
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) row[j] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (q[j] - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) row[SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, v[j] / S.vel_max[j]));
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) row[2 * SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, a[j] / S.acc_max[j]));
+    write_planet_observation(S, idx, row + 3 * SMR_NJ);
 }
 
 }  // namespace smr

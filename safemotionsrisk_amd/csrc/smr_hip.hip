@@ -186,124 +186,153 @@ __device__ inline bool position_is_valid(const DScene &S, const float q[SMR_NJ])
     return ok;
 }
 
-__device__ inline void sample_position(const DScene &S, Rng &rng, float q[SMR_NJ]) {
-    for (int attempt = 0; attempt < 100000; ++attempt) {
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S.pos_lo[j], S.pos_hi[j]);   // ctlp.py:2035-2037
-        if (position_is_valid(S, q)) return;
+// table clearance of a configuration (ctlp.py:1605-1619; self-collision: no pairs for one iiwa)
+__device__ inline bool table_free(const DScene &S, const float q[SMR_NJ]) {
+    Xf T = fk_base(S), I = T;
+    bool free_pos = true;
+    for (int l = 0; l < SMR_NLINK; ++l) {
+        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
+        if (free_pos && ((S.static_mask >> l) & 1u))
+            for (int s = 0; s < S.n_static; ++s) {
+                float thr = S.start_min_static;
+                float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, 0.f);
+                if (d <= thr + 0.005f && d < thr) free_pos = false;
+            }
     }
+    return free_pos;
 }
 
-constexpr int kResetLaneStride = 16;
+constexpr int kResetGroupStride = 4;   // every 4th 8-lane group works: 2 resets per wavefront
 
-// env.reset() for the envs in list[0..count): obs.py:144-149 -> base.py:913-1022
+// env.reset() for the envs in list[0..count): obs.py:144-149 -> base.py:913-1022.
+// One reset is worked by a GROUP of 8 adjacent lanes: they evaluate 8 candidate start positions / 8 candidate
+// planet phases at once and take the first valid one (ballot + ffs = the sequential "first valid" of
+// ctlp.py:2030-2138,4477-4490), and lanes 0..6 handle one joint each for the velocity/acceleration tries
+// and the random walk (ctlp.py:1499-1654).  Rejection sampling is a chain of data-dependent loops: latency,
+// not lane count, bounds this kernel, so only every group_stride-th group takes an entry.
 __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
-                                                   const int *__restrict__ count_ptr, int count_fixed, int lane_stride,
+                                                   const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                    float *__restrict__ obs) {
     const DScene &S = *Sp;
-    // Rejection sampling is a chain of data-dependent loops: lanes of one wave wait for each other, and the
-    // few envs that finish per step would only fill a few dozen wavefronts.  Only every lane_stride-th
-    // lane takes an entry, so the entries spread over lane_stride x more wavefronts (latency, not lane
-    // count, is what bounds this kernel).  A full reset (all B envs) runs dense, lane_stride = 1.
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t % lane_stride) return;
-    const int i = t / lane_stride;
+    const int grp = t >> 3, g = t & 7;
+    if (grp % group_stride) return;
+    const int i = grp / group_stride;
     const int count = count_ptr ? *count_ptr : count_fixed;
     if (i >= count) return;
     const int e = list ? list[i] : i;
     const int B = S.B;
-    Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, st.rng_draws[e]};
-    float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
+    const int gbase = (threadIdx.x & 63) & ~7;
+    auto gballot = [&](bool pred) -> unsigned { return (unsigned)((__ballot(pred) >> gbase) & 0xFFull); };
+    const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, st.reset_count[e]};
+
+    // ---- start position: 8 attempts per round, first valid wins (stream S_POS, attempt n = draws 7n..7n+6)
+    float q[SMR_NJ];
+    unsigned attempt = 0;
+    auto next_position = [&]() {
+        for (int round = 0; round < 12500; ++round) {
+            const unsigned n = attempt + (unsigned)g;
 #pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) { v[j] = 0.f; a[j] = 0.f; }
-    sample_position(S, rng, q);
-    // A17 part 2: get_starting_point_joint_pos_vel_acc, ctlp.py:1490-1654
-    if (S.kin_mode && rng.uniform01() < S.kin_prob) {
-        for (;;) {                                                                         // ctlp.py:1499-1556
-            bool all_found = true;
-#pragma unroll 1
-            for (int j = 0; j < SMR_NJ; ++j) {
-                if (!all_found) break;
-                bool found = false;
-                JointLim L = joint_lim(S, j);
-                for (int tv = 0; tv < 5 && !found; ++tv) {
-                    float vj = rng.uniform(-L.V, L.V);
-                    for (int ta = 0; ta < 10 && !found; ++ta) {
-                        float aj = rng.uniform(-L.A, L.A);
-                        float lo, hi;
-                        int code;
-                        safe_acc_range_joint(L, q[j], vj, aj, lo, hi, code);
-                        if (code == 0) { found = true; v[j] = vj; a[j] = aj; }
-                    }
-                }
-                if (!found) all_found = false;
+            for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S_POS, 7u * n + j, S.pos_lo[j], S.pos_hi[j]);   // ctlp.py:2035-2037
+            const unsigned m = gballot(position_is_valid(S, q));
+            if (m) {
+                const int f = __ffs((int)m) - 1;
+#pragma unroll
+                for (int j = 0; j < SMR_NJ; ++j) q[j] = __shfl(q[j], gbase + f);
+                attempt += (unsigned)f + 1u;
+                return;
             }
-            if (all_found) break;
-            sample_position(S, rng, q);
+            attempt += 8u;
         }
-    } else {                                                                               // ctlp.py:1558-1654
-        // random walk of safe actions; ring of the three latest states
-        float hq[3][SMR_NJ], hv[3][SMR_NJ], ha[3][SMR_NJ];
-        int cnt = 1;
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) { hq[0][j] = q[j]; hv[0][j] = 0.f; ha[0][j] = 0.f; }
-        for (int walk = 0; walk < 64; ++walk) {
-            if (rng.uniform01() < S.stay_prob) break;
-            const int cur = (cnt - 1) % 3, nxt = cnt % 3;
-            float nq[SMR_NJ], nv[SMR_NJ], na[SMR_NJ], lo[SMR_NJ], hi[SMR_NJ];
-#pragma unroll 1
-            for (int j = 0; j < SMR_NJ; ++j) {
-                int code;
-                safe_acc_range_joint(joint_lim(S, j), hq[cur][j], hv[cur][j], ha[cur][j], lo[j], hi[j], code);
-            }
-#pragma unroll 1
-            for (int j = 0; j < SMR_NJ; ++j) {
-                float u = rng.uniform(-1.f, 1.f);
-                na[j] = lo[j] + 0.5f * (u + 1.f) * (hi[j] - lo[j]);
-                nv[j] = interp_vel(hv[cur][j], ha[cur][j], na[j], S.dt, S.dt);
-                nq[j] = interp_pos(hq[cur][j], hv[cur][j], ha[cur][j], na[j], S.dt, S.dt);
-            }
-            // end position collision free? table only (+ self: no pairs), ctlp.py:1605-1619
-            bool free_pos = true;
-            {
-                Xf T = fk_base(S), I = T;
-                for (int l = 0; l < SMR_NLINK; ++l) {
-                    if (l > 0) fk_advance(S, l - 1, nq[l - 1], T);
-                    if (free_pos && ((S.static_mask >> l) & 1u))
-                        for (int s = 0; s < S.n_static; ++s) {
-                            float thr = S.start_min_static;
-                            float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, 0.f);
-                            if (d <= thr + 0.005f && d < thr) free_pos = false;
-                        }
+    };
+    next_position();
+
+    // ---- joint velocity / acceleration.  After this block lane j (< 7) holds joint j in (qj, vj, aj).
+    float vj = 0.f, aj = 0.f, qj = 0.f;
+    const int jj = g < SMR_NJ ? g : 0;
+    const JointLim L = joint_lim(S, jj);
+    if (S.kin_mode && rng.uniform01(S_MODE, 0) < S.kin_prob) {                          // ctlp.py:1494-1556
+        for (unsigned round = 0;; ++round) {
+            bool found = (g >= SMR_NJ);
+            const float qme = q[jj];
+            for (unsigned tv = 0; tv < 5 && !found; ++tv) {
+                const float vt = rng.uniform(S_JOINT + jj, round * 55u + tv * 11u, -L.V, L.V);
+                for (unsigned ta = 0; ta < 10 && !found; ++ta) {
+                    const float at = rng.uniform(S_JOINT + jj, round * 55u + tv * 11u + 1u + ta, -L.A, L.A);
+                    float lo, hi;
+                    int code;
+                    safe_acc_range_joint(L, qme, vt, at, lo, hi, code);
+                    if (code == 0) { found = true; vj = vt; aj = at; }
                 }
             }
-            if (free_pos) {
-                for (int j = 0; j < SMR_NJ; ++j) { hq[nxt][j] = nq[j]; hv[nxt][j] = nv[j]; ha[nxt][j] = na[j]; }
+            if (gballot(found) == 0xFFu) break;
+            next_position();                                                            // ctlp.py:1547-1556
+        }
+        qj = q[jj];
+    } else {                                                                            // ctlp.py:1558-1654
+        // random walk of safe actions; each lane keeps the ring of the three latest states of ITS joint
+        float hq0 = q[jj], hq1 = 0.f, hq2 = 0.f, hv0 = 0.f, hv1 = 0.f, hv2 = 0.f, ha0 = 0.f, ha1 = 0.f, ha2 = 0.f;
+        int cnt = 1;
+        unsigned w = 0;
+        for (int walk = 0; walk < 64; ++walk) {
+            if (rng.uniform01(S_WALK, w++) < S.stay_prob) break;
+            const int cur = (cnt - 1) % 3, nxt = cnt % 3;
+            const float cq = cur == 0 ? hq0 : cur == 1 ? hq1 : hq2, cv = cur == 0 ? hv0 : cur == 1 ? hv1 : hv2,
+                        ca = cur == 0 ? ha0 : cur == 1 ? ha1 : ha2;
+            float lo, hi;
+            int code;
+            safe_acc_range_joint(L, cq, cv, ca, lo, hi, code);
+            const float u = rng.uniform(S_WALK, w + (unsigned)jj, -1.f, 1.f);
+            w += SMR_NJ;
+            const float na = lo + 0.5f * (u + 1.f) * (hi - lo);
+            const float nv = interp_vel(cv, ca, na, S.dt, S.dt), nq = interp_pos(cq, cv, ca, na, S.dt, S.dt);
+            float nqv[SMR_NJ];
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) nqv[j] = __shfl(nq, gbase + j);
+            if (table_free(S, nqv)) {
+                if (nxt == 0) { hq0 = nq; hv0 = nv; ha0 = na; } else if (nxt == 1) { hq1 = nq; hv1 = nv; ha1 = na; } else { hq2 = nq; hv2 = nv; ha2 = na; }
                 ++cnt;
             } else {
-                int sel = 1 + rng.randint(cnt < 3 ? cnt : 3);                              // ctlp.py:1641-1646
+                const int sel = 1 + rng.randint(S_WALK, w++, cnt < 3 ? cnt : 3);        // ctlp.py:1641-1646
                 cnt = cnt - sel + 1;
                 break;
             }
         }
         const int cur = (cnt - 1) % 3;
-        for (int j = 0; j < SMR_NJ; ++j) { q[j] = hq[cur][j]; v[j] = hv[cur][j]; a[j] = ha[cur][j]; }
+        qj = cur == 0 ? hq0 : cur == 1 ? hq1 : hq2;
+        vj = cur == 0 ? hv0 : cur == 1 ? hv1 : hv2;
+        aj = cur == 0 ? ha0 : cur == 1 ? ha1 : ha2;
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) q[j] = __shfl(qj, gbase + j);
     }
 
+    // ---- planet phase: 8 candidate phases per round, first contact-free one wins (ctlp.py:4470-4501)
     int idx[SMR_MAX_PLANETS] = {0, 0};
     int hit = 0;
     if (S.n_planets > 0) {
-        // Planet.reset: random phase until contact free, ctlp.py:4470-4501
-        for (int attempt = 0; attempt < 100000; ++attempt) {
+        int n_indep = 0;
+#pragma unroll
+        for (int p = 0; p < SMR_MAX_PLANETS; ++p) n_indep += (p < S.n_planets && !S.planet[p].coupled) ? 1 : 0;
+        unsigned base = 0;
+        for (int round = 0; round < 12500; ++round) {
+            const unsigned n = base + (unsigned)g;
+            int k = 0;
 #pragma unroll
             for (int p = 0; p < SMR_MAX_PLANETS; ++p) {
                 if (p >= S.n_planets) continue;
-                const int n = S.planet[p].n_orbit;
-                if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % n + n) % n;
-                else idx[p] = rng.randint(n);
+                const int no = S.planet[p].n_orbit;
+                if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % no + no) % no;
+                else idx[p] = rng.randint(S_PLANET, n * (unsigned)n_indep + (unsigned)(k++), no);
             }
-            Sample r = collide_sample(S, q, idx, false, true);
-            if (!r.contact) break;
+            const Sample r = collide_sample(S, q, idx, false, true);
+            const unsigned m = gballot(!r.contact);
+            if (m) {
+                const int f = __ffs((int)m) - 1;
+                idx[0] = __shfl(idx[0], gbase + f);
+                idx[1] = __shfl(idx[1], gbase + f);
+                break;
+            }
+            base += 8u;
         }
         // obstacle_wrapper.update(update_after_reset=True): one planet update + contact check,
         // base.py:980-985, ctlp.py:2626-2637
@@ -311,18 +340,28 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (idx[p] + 1) % S.planet[p].n_orbit;
         if (S.term_moving) {
-            Sample r = collide_sample(S, q, idx, false, true);
+            const Sample r = collide_sample(S, q, idx, false, true);
             hit = r.contact ? 1 : 0;
         }
     }
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) { st.q[j * B + e] = q[j]; st.v[j * B + e] = v[j]; st.a[j * B + e] = a[j]; }
-    st.planet_idx[e] = idx[0];
-    st.planet_idx[B + e] = idx[1];
-    st.step_count[e] = 0;
-    st.moving_hit[e] = hit;
-    st.rng_draws[e] = rng.draws;
-    if (obs) write_observation(S, q, v, a, idx, obs + (size_t)e * S.obs_size);
+
+    // ---- write back: lane j < 7 owns joint j, lane 7 the scalars
+    float *row = obs ? obs + (size_t)e * S.obs_size : nullptr;
+    if (g < SMR_NJ) {
+        st.q[g * B + e] = qj; st.v[g * B + e] = vj; st.a[g * B + e] = aj;
+        if (row) {
+            row[g] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (qj - L.plo) / (L.phi - L.plo)));
+            row[SMR_NJ + g] = fminf(1.f, fmaxf(-1.f, vj / L.V));
+            row[2 * SMR_NJ + g] = fminf(1.f, fmaxf(-1.f, aj / L.A));
+        }
+    } else {
+        st.planet_idx[e] = idx[0];
+        st.planet_idx[B + e] = idx[1];
+        st.step_count[e] = 0;
+        st.moving_hit[e] = hit;
+        st.reset_count[e] = rng.tag + 1u;
+        if (row) write_planet_observation(S, idx, row + 3 * SMR_NJ);
+    }
 }
 
 __global__ void mask_to_list_kernel(const uint8_t *__restrict__ mask, int B, int *__restrict__ list, int *__restrict__ count) {
@@ -444,6 +483,11 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     d.checks_per_step = s.collision_checks_per_step; d.auto_reset = s.auto_reset; d.dt = (float)s.dt;
     copy3(d.pos_lo, s.pos_lo, SMR_NJ); copy3(d.pos_hi, s.pos_hi, SMR_NJ); copy3(d.vel_max, s.vel_max, SMR_NJ);
     copy3(d.acc_max, s.acc_max, SMR_NJ); copy3(d.jerk_max, s.jerk_max, SMR_NJ);
+    for (int j = 0; j < SMR_NJ; ++j) {
+        d.pos_lo_res[j] = (float)(s.pos_lo[j] - (double)d.pos_lo[j]);
+        d.pos_hi_res[j] = (float)(s.pos_hi[j] - (double)d.pos_hi[j]);
+        d.vel_max_res[j] = (float)(s.vel_max[j] - (double)d.vel_max[j]);
+    }
     copy3(d.base, s.base_xyz); copy3(d.ee_offset, s.ee_offset);
     for (int j = 0; j < SMR_NJ; ++j) { copy3(d.joint_xyz[j], s.joint_xyz[j]); copy3(d.joint_axis[j], s.joint_axis[j]); }
 
@@ -581,14 +625,14 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     DState &st = env->st;
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
-        (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.rng_draws, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
+        (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
         (rc = dev_alloc(env, &st.res, (size_t)env->N * SMR_NLINK * B)) || (rc = dev_alloc(env, &st.dist, 2 * SMR_NLINK * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) ||
         (rc = dev_alloc(env, &st.done_count, 1)))
         return fail(rc);
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
-               e7 = hipMemset(st.rng_draws, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
+               e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     if (hipDeviceSynchronize() != hipSuccess) { env->err = "hipDeviceSynchronize failed"; return fail(SMR_E_HIP); }
     *out = env;
@@ -666,8 +710,8 @@ static int launch_reset_list(smr_env *env, float *obs_dev) {
     // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
     LaunchTimer t(env, SMR_K_RESET);
     const int B = env->B;
-    hipLaunchKernelGGL(reset_kernel, dim3(((size_t)B * kResetLaneStride + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
-                       env->st.done_list, env->st.done_count, 0, kResetLaneStride, obs_dev);
+    hipLaunchKernelGGL(reset_kernel, dim3(((size_t)B * 8 * kResetGroupStride + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+                       env->st.done_list, env->st.done_count, 0, kResetGroupStride, obs_dev);
     SMR_HIP(hipGetLastError());
     return SMR_OK;
 }
@@ -680,7 +724,7 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     const int B = env->B;
     if (!mask_dev) {
         LaunchTimer t(env, SMR_K_RESET);
-        hipLaunchKernelGGL(reset_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+        hipLaunchKernelGGL(reset_kernel, dim3(((size_t)B * 8 + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
                            (const int *)nullptr, (const int *)nullptr, B, 1, obs_dev);
         SMR_HIP(hipGetLastError());
         return SMR_OK;
@@ -740,7 +784,7 @@ int smr_get_state(smr_env_t *env, const smr_host_state_t *h) {
     int rc;
     if ((rc = state_get(env, h->q, env->st.q, 7)) || (rc = state_get(env, h->v, env->st.v, 7)) || (rc = state_get(env, h->a, env->st.a, 7)) ||
         (rc = state_get(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_get(env, h->step_count, env->st.step_count, 1)) ||
-        (rc = state_get(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_get(env, h->rng_draws, env->st.rng_draws, 1)))
+        (rc = state_get(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_get(env, h->reset_count, env->st.reset_count, 1)))
         return rc;
     return SMR_OK;
 }
@@ -758,7 +802,7 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     int rc;
     if ((rc = state_set(env, h->q, env->st.q, 7)) || (rc = state_set(env, h->v, env->st.v, 7)) || (rc = state_set(env, h->a, env->st.a, 7)) ||
         (rc = state_set(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_set(env, h->step_count, env->st.step_count, 1)) ||
-        (rc = state_set(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_set(env, h->rng_draws, env->st.rng_draws, 1)))
+        (rc = state_set(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_set(env, h->reset_count, env->st.reset_count, 1)))
         return rc;
     SMR_HIP(hipDeviceSynchronize());
     return SMR_OK;

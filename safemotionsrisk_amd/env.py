@@ -133,8 +133,8 @@ class VecSafeMotionsEnv:
         B = self.num_envs
         st = dict(q=np.zeros((B, NJ), np.float32), v=np.zeros((B, NJ), np.float32), a=np.zeros((B, NJ), np.float32),
                   planet_idx=np.zeros((B, 2), np.int32), step_count=np.zeros(B, np.int32),
-                  moving_hit=np.zeros(B, np.int32), rng_draws=np.zeros(B, np.uint32))
-        hs = _lib.HostState(*[st[k].ctypes.data for k in ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "rng_draws")])
+                  moving_hit=np.zeros(B, np.int32), reset_count=np.zeros(B, np.uint32))
+        hs = _lib.HostState(*[st[k].ctypes.data for k in ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "reset_count")])
         _lib.check(self._L, self._h, self._L.smr_get_state(self._h, C.byref(hs)), "smr_get_state")
         return st
 
@@ -142,9 +142,9 @@ class VecSafeMotionsEnv:
         B = self.num_envs
         spec = dict(q=(np.float32, (B, NJ)), v=(np.float32, (B, NJ)), a=(np.float32, (B, NJ)),
                     planet_idx=(np.int32, (B, 2)), step_count=(np.int32, (B,)), moving_hit=(np.int32, (B,)),
-                    rng_draws=(np.uint32, (B,)))
+                    reset_count=(np.uint32, (B,)))
         keep, ptrs = [], []
-        for k in ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "rng_draws"):
+        for k in ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "reset_count"):
             if kw.get(k) is None:
                 ptrs.append(None)
             else:

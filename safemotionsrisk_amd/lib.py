@@ -30,7 +30,7 @@ EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "
 
 class HostState(C.Structure):
     _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("a", C.c_void_p), ("planet_idx", C.c_void_p),
-                ("step_count", C.c_void_p), ("moving_hit", C.c_void_p), ("rng_draws", C.c_void_p)]
+                ("step_count", C.c_void_p), ("moving_hit", C.c_void_p), ("reset_count", C.c_void_p)]
 
 
 def _sources():

@@ -2,7 +2,7 @@ import sys; sys.path.insert(0,'.')
 import numpy as np, torch
 from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
 from oracle.oracle import OracleEnv
-KEYS=("q", "v", "a", "planet_idx", "step_count", "moving_hit", "rng_draws")
+KEYS=("q", "v", "a", "planet_idx", "step_count", "moving_hit", "reset_count")
 B,T=4096,12
 env=VecSafeMotionsEnv(B, seed=5, auto_reset=False, **SPACE_ENV_CONFIG); env.reset()
 ora=OracleEnv(env.scene,B,seed=5,num_threads=16)
@@ -12,21 +12,28 @@ for t in range(T):
     act=rng.uniform(-1,1,(B,7)).astype(np.float32)
     obs,rew,done,info=env.step(torch.from_numpy(act).cuda())
     o_obs,o_rew,o_done,o_reason,o_info=ora.step(act.astype(np.float64))
-    rew=rew.cpu().numpy(); vals=info['values'].cpu().numpy(); done=done.cpu().numpy()
+    obs=obs.cpu().numpy(); rew=rew.cpu().numpy(); vals=info['values'].cpu().numpy(); done=done.cpu().numpy()
     good=(done==o_done)
-    err=np.abs(rew-o_rew)*good
-    e=int(np.argmax(err))
-    print('t',t,'max rew err',err.max(),'env',e,'gpu info',vals[e,:3],'ora info',o_info[e,:3], 'mismatch', (~good).sum())
-    if err.max()>2e-3:
-        st1=env.get_state()
-        q=st1['q'][e].astype(np.float64); idx=st1['planet_idx'][e]
-        print('  q',st1['q'][e].tolist(),'idx',idx.tolist())
-        print('  oracle distances at gpu state', ora.distances(q, idx), 'gpu test_distances', env.test_distances(st1['q'][e:e+1], idx[None]))
-        best=None
-        for link in range(3,8):
-            for p in range(2):
-                for c in range(24 if p==0 else 1):
-                    d=ora.link_planet_piece_distance(q,link,p,c,int(idx[p]))
-                    if best is None or d<best[0]: best=(d,link,p,c)
-        print('  closest pair (oracle)',best)
+    err=np.abs(obs-o_obs)*good[:,None]
+    e,c=np.unravel_index(np.argmax(err),err.shape)
+    print('t',t,'obs err pos/vel/acc/planet',err[:,:7].max(),err[:,7:14].max(),err[:,14:21].max(),err[:,21:].max(),'rew err',(np.abs(rew-o_rew)*good).max(),'mismatch',(~good).sum())
+    if err.max()>1e-4:
+        j=c%7
+        print('  env',e,'col',c,'gpu',obs[e,c],'ora',o_obs[e,c],'state p,v,a',st['q'][e,j],st['v'][e,j],st['a'][e,j],'action',act[e,j])
+        l,h,cd=OracleEnv(env.scene,1).safe_acc_range(st['q'][e].astype(np.float64),st['v'][e].astype(np.float64),st['a'][e].astype(np.float64))
+        gl,gh,gc=env.test_safe_acc_range(st['q'][e:e+1],st['v'][e:e+1],st['a'][e:e+1])
+        print('  oracle range',l[j],h[j],cd[j],'gpu',gl[0,j],gh[0,j],gc[0,j])
+    reason=info['termination_reason'].cpu().numpy()
+    for e in np.nonzero((done!=o_done)|(reason!=o_reason))[0]:
+        st1=env.get_state(); o1=OracleEnv(env.scene,1)
+        print('  MISMATCH env',e,'gpu done/reason',done[e],reason[e],'ora',o_done[e],o_reason[e],'gpu info',vals[e,:3],'ora info',o_info[e,:3],'hit pre',st['moving_hit'][e],'hit post',st1['moving_hit'][e])
+        print('   obs gpu',obs[e,:21].round(5).tolist()); print('   obs ora',o_obs[e,:21].round(5).tolist()); print('   pre q',st['q'][e].tolist(),'v',st['v'][e].tolist(),'a',st['a'][e].tolist(),'act',act[e].tolist())
+        l,h,cd=o1.safe_acc_range(st['q'][e].astype(np.float64),st['v'][e].astype(np.float64),st['a'][e].astype(np.float64)); gl,gh,gc=env.test_safe_acc_range(st['q'][e:e+1],st['v'][e:e+1],st['a'][e:e+1]); print('   ora range',l.tolist(),h.tolist(),cd.tolist()); print('   gpu range',gl[0].tolist(),gh[0].tolist(),gc[0].tolist())
+        N=3; dt=0.1
+        for k in range(1,N+1):
+            tk=dt*k/N
+            q0,v0,a0,a1=[x[e].astype(np.float64) for x in (st['q'],st['v'],st['a'],st1['a'])]
+            qk=q0+v0*tk+0.5*a0*tk**2+(a1-a0)/dt*tk**3/6
+            idx=(st['planet_idx'][e]+k*8)%1200
+            print('   k',k,'oracle distances',o1.distances(qk,idx),'gpu',env.test_distances(qk[None].astype(np.float32),idx[None]))
     if done.any(): env.reset(mask=torch.from_numpy(done).cuda())

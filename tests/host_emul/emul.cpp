@@ -41,8 +41,9 @@ float emul_gjk(const float *va, int na, const float *vb, int nb, const float *Rb
     if (identity_a) return gjk_distance<true>((const float *)verts, A, XA, B, XB, d, cutoff, stop_below);
     return gjk_distance<false>((const float *)verts, A, XA, B, XB, d, cutoff, stop_below);
 }
-void emul_safe_acc_range(float plo, float phi, float V, float A, float J, float dt, float p, float v, float a, float *lo, float *hi, int *code) {
-    JointLim L{plo, phi, V, A, J, dt};
+void emul_safe_acc_range(double plo, double phi, double V, double A, double J, double dt, float p, float v, float a, float *lo, float *hi, int *code) {
+    JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f};
+    L.plo_res = (float)(plo - (double)L.plo); L.phi_res = (float)(phi - (double)L.phi); L.V_res = (float)(V - (double)L.V);
     safe_acc_range_joint(L, p, v, a, *lo, *hi, *code);
 }
 }
@@ -108,4 +109,9 @@ extern "C" int emul_simplex(float *w /*4x3 in/out*/, int n, float *v_out) {
     for (int i = 0; i < 12; ++i) w[i] = o[i];
     v_out[0] = v.x; v_out[1] = v.y; v_out[2] = v.z;
     return inside ? -1 : n;
+}
+extern "C" float emul_pos_margin(double plo, double phi, double V, double A, double J, double dt, float gap, float v, float a, float a1) {
+    JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f};
+    L.V_res = (float)(V - (double)L.V);
+    return pos_margin(gap, v, a, a1, 1e-5f * L.V, L);
 }

@@ -1,11 +1,10 @@
 """Parity tests proper: the HIP path (through the C-ABI) against the float64 oracle and the committed golden
 vectors.  Run on the GPU box: python -m pytest tests -m gpu.
 
-Tolerances (float32 kernels vs float64 oracle, one step from an injected state):
-  FK positions 2e-6 m; distances 2e-5 m; acceleration range 2e-4 of acc_max for random states;
-  obs: position columns 2e-5, velocity 3e-4, acceleration 1e-3 (the end of the safe range is ill conditioned
-  while a joint rides on a limit: the limit is reached a few ms into the step and d(peak)/d(a1) ~ 5e-6 m per
-  rad/s^2, so a float32 ulp of position moves the bound by ~1e-3 of acc_max), planet columns 1e-5; reward 2e-3;
+Tolerances (float32 kernels vs float64 oracle, one step from an injected float32 state):
+  FK positions 2e-6 m; distances 5e-6 m; acceleration range 2e-5 of acc_max (also while a joint rides on a
+  limit: the kernels carry the float64 residual of every limit and work on displacements relative to it);
+  obs: position columns 2e-6, velocity 1e-5, acceleration 2e-5, planet columns 1e-6; reward 5e-5;
   done / termination reason / collision flags: exact, except envs whose oracle distance lies within
   2e-5 m of a decision threshold (0.001 m collision, 0.02 m contact), which are excluded and counted.
 """
@@ -17,9 +16,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "space_step.npz")
-STATE_KEYS = ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "rng_draws")
+STATE_KEYS = ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "reset_count")
 TIE = 2e-5
-OBS_TOL = np.concatenate([np.full(7, 2e-5), np.full(7, 3e-4), np.full(7, 1e-3), np.full(2, 1e-5)])
+OBS_TOL = np.concatenate([np.full(7, 2e-6), np.full(7, 1e-5), np.full(7, 2e-5), np.full(2, 1e-6)])
 
 
 def _env(B, **kw):
@@ -58,13 +57,13 @@ def test_components_against_golden(built):
     # refining a distance as soon as the collision is certain, so values are compared after that clamp
     clamp = lambda x: np.where(x < 0.001, 0.0, x)
     near = (np.abs(gd[:, 0] - 0.001) < TIE) | (np.abs(gd[:, 2] - 0.001) < TIE)
-    assert np.abs(clamp(d[:, 0]) - clamp(gd[:, 0]))[~near].max() < 2e-5     # static (table)
-    assert np.abs(clamp(d[:, 2]) - clamp(gd[:, 2]))[~near].max() < 2e-5     # moving (planets)
+    assert np.abs(clamp(d[:, 0]) - clamp(gd[:, 0]))[~near].max() < 5e-6     # static (table)
+    assert np.abs(clamp(d[:, 2]) - clamp(gd[:, 2]))[~near].max() < 5e-6     # moving (planets)
     safe = np.abs(gd[:, 2] - 0.02) > TIE
     assert np.array_equal(d[safe, 3], gd[safe, 3])                      # contact flags
     lo, hi, code = env.test_safe_acc_range(g["comp_p"], g["comp_v"], g["comp_a"])
     A = np.array(env.scene.struct.acc_max)
-    assert np.abs((lo - g["comp_lo"]) / A).max() < 2e-4 and np.abs((hi - g["comp_hi"]) / A).max() < 2e-4
+    assert np.abs((lo - g["comp_lo"]) / A).max() < 2e-5 and np.abs((hi - g["comp_hi"]) / A).max() < 2e-5
     assert np.array_equal(code, g["comp_code"])
     env.close()
 
@@ -90,12 +89,12 @@ def test_step_against_golden(built):
         ok = ~tie
         assert np.array_equal(done[ok], g["done"][t][ok]) and np.array_equal(reason[ok], g["reason"][t][ok])
         assert (np.abs(obs[ok] - g["obs"][t][ok]) < OBS_TOL).all()
-        assert np.abs(rew[ok] - g["reward"][t][ok]).max() < 2e-3
-        assert np.abs(vals[ok, :3] - g["info"][t][ok, :3]).max() < 2e-5
+        assert np.abs(rew[ok] - g["reward"][t][ok]).max() < 5e-5
+        assert np.abs(vals[ok, :3] - g["info"][t][ok, :3]).max() < 5e-6
         gs = g["state"][t]
         A = np.array(env.scene.struct.acc_max)
-        assert np.abs(st["q"] - gs[:, :7]).max() < 3e-5 and np.abs(st["v"] - gs[:, 7:14]).max() < 1e-3
-        assert np.abs((st["a"] - gs[:, 14:]) / A).max() < 1e-3
+        assert np.abs(st["q"] - gs[:, :7]).max() < 2e-6 and np.abs(st["v"] - gs[:, 7:14]).max() < 2e-5
+        assert np.abs((st["a"] - gs[:, 14:]) / A).max() < 2e-5
         # golden protocol: continue from the float32 image of the ORACLE state
         env.set_state(q=gs[:, :7].astype(np.float32), v=gs[:, 7:14].astype(np.float32), a=gs[:, 14:].astype(np.float32),
                       step_count=np.where(g["done"][t], 0, st["step_count"]), moving_hit=np.where(g["done"][t], 0, st["moving_hit"]))
@@ -126,11 +125,20 @@ def test_rollout_against_oracle_with_state_injection(built):
         if bad.any():
             st1 = env.get_state()
             tie = _threshold_ties(ora, {k: st1[k][bad] for k in ("q", "planet_idx")})
+            # ... or a contact sample inside the step sits on the 0.02 m contact threshold
+            N, dt = int(env.scene.struct.collision_checks_per_step), float(env.scene.struct.dt)
+            for n, e in enumerate(np.nonzero(bad)[0]):
+                for k in range(1, N):
+                    tk = dt * k / N
+                    q0, v0, a0, a1 = [x[e].astype(np.float64) for x in (st["q"], st["v"], st["a"], st1["a"])]
+                    qk = q0 + v0 * tk + 0.5 * a0 * tk ** 2 + (a1 - a0) / dt * tk ** 3 / 6
+                    idx = (st["planet_idx"][e] + k * (24 // N)) % 1200
+                    tie[n] |= abs(ora.distances(qk, idx)[2] - 0.02) < TIE
             excluded += int(tie.sum())
             mism += int((~tie).sum())
         good = ~bad
         assert (np.abs(obs[good] - o_obs[good]) < OBS_TOL).all()
-        assert np.abs(rew[good] - o_rew[good]).max() < 2e-3
+        assert np.abs(rew[good] - o_rew[good]).max() < 5e-5
         dones += int(o_done.sum())
         # envs that finished are re-sampled on the GPU so the rollout keeps all lanes busy
         if done.any():
@@ -168,11 +176,14 @@ def test_reset_properties_and_oracle_agreement(built):
     ora_b = OracleEnv(env.scene, B, seed=21, num_threads=16)
     ora_b.reset()
     ost = ora_b.get_state()
-    same = (ost["rng_draws"] == st["rng_draws"]) & (ost["planet_idx"] == st["planet_idx"]).all(axis=1)
+    same = (ost["planet_idx"] == st["planet_idx"]).all(axis=1) & (np.abs(ost["q"] - st["q"]).max(axis=1) < 1e-3)
+    assert (ost["reset_count"] == 1).all() and (st["reset_count"] == 1).all()
     assert same.mean() > 0.97
-    assert np.abs(st["q"][same] - ost["q"][same]).max() < 1e-5
+    # kinematic-sampling envs agree to float32 rounding; random-walk envs accumulate it over up to 64 walk steps
+    assert np.abs(st["q"][same] - ost["q"][same]).max() < 2e-4
+    assert np.median(np.abs(st["q"][same] - ost["q"][same]).max(axis=1)) < 1e-6
     A = np.array(s.acc_max)
-    assert np.abs((st["a"][same] - ost["a"][same]) / A).max() < 5e-4
+    assert np.abs((st["a"][same] - ost["a"][same]) / A).max() < 2e-3
     # planet phases are uniform over the orbit (chi-square on 12 bins, very loose)
     hist = np.bincount(st["planet_idx"][:, 0] // 100, minlength=12)
     assert hist.min() > 0.6 * B / 12

@@ -56,7 +56,7 @@ def test_device_distances_on_host(emul, space_scene):
 def test_device_acc_range_on_host(emul, space_scene):
     s = space_scene.struct
     rng = np.random.default_rng(1)
-    emul.emul_safe_acc_range.argtypes = [C.c_float] * 9 + [C.c_void_p] * 3
+    emul.emul_safe_acc_range.argtypes = [C.c_double] * 6 + [C.c_float] * 3 + [C.c_void_p] * 3
     worst = 0.0
     for _ in range(3000):
         j = int(rng.integers(7))
@@ -67,4 +67,4 @@ def test_device_acc_range_on_host(emul, space_scene):
         olo, ohi, ocode = O.safe_acc_range_joint(*[float(x) for x in L], float(p), float(v), float(a))
         assert code.value == ocode
         worst = max(worst, abs(lo.value - olo) / L[3], abs(hi.value - ohi) / L[3])
-    assert worst < 2e-4
+    assert worst < 1e-5

@@ -146,3 +146,23 @@ def test_planet_distance_against_qp(built, space_scene):
         B = verts[pp.vert_begin:pp.vert_begin + pp.vert_count] @ quaternion_to_matrix(pose[3:]).T + pose[:3]
         d = ora.link_planet_piece_distance(q, link, planet, piece, idx)
         assert d == pytest.approx(qp_distance(A, B) - 0.002, abs=2e-6)
+
+
+def test_gjk_regression_flat_tetrahedron(built, space_scene):
+    """A configuration on which an earlier oracle reported a false intersection (garbage barycentric weights of
+    a nearly flat tetrahedron in the sub-simplex search); found by the GPU parity run.  Checked against the QP."""
+    ora = O.OracleEnv(space_scene, 1)
+    s = space_scene.struct
+    q = np.array([-0.76993687, 2.00844896, -0.88387338, 0.19455521, 0.41319991, -0.18207604, -2.29981527])
+    tb = space_scene.pieces[s.static_piece[0]]
+    table = space_scene.verts[tb.vert_begin:tb.vert_begin + tb.vert_count]
+    for dq in (0.0, 1e-9, -1e-9, 3e-8):
+        pos, rot = ora.fk(q + dq)
+        pc = space_scene.pieces[s.link_piece[7]]
+        link = space_scene.verts[pc.vert_begin:pc.vert_begin + pc.vert_count] @ rot[7].T + pos[7]
+        d = O.gjk(table, I3, Z3, link, I3, Z3)
+        assert d == pytest.approx(0.0063, abs=2e-4)
+    pos, rot = ora.fk(q)
+    link = space_scene.verts[pc.vert_begin:pc.vert_begin + pc.vert_count] @ rot[7].T + pos[7]
+    assert O.gjk(table, I3, Z3, link, I3, Z3) == pytest.approx(qp_distance(table, link), abs=2e-6)
+    assert ora.distances(q, [0, 720])[0] == pytest.approx(0.003914, abs=2e-5)

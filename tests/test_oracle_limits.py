@@ -131,4 +131,4 @@ def test_violation_codes(built):
 
 def test_philox_known_answer(built):
     """Random123 known-answer test for philox4x32-10 (counter 0, key 0)."""
-    assert [O.philox_word(0, 0, d) for d in range(4)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert [O.philox_word(0, 0, 0, 0, d) for d in range(4)] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
