@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 1
+#define SMR_ABI_VERSION 2
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
@@ -56,7 +56,8 @@ extern "C" {
 #define SMR_K_COLLIDE 1   /* A3/A6/A7/A8/A11: cubic sample, FK, GJK distances, contacts  */
 #define SMR_K_FINISH 2    /* A1/A12/A13/A15/A16: state update, reward, termination, obs  */
 #define SMR_K_RESET 3     /* A17/A9: start-state and planet-phase sampling               */
-#define SMR_K_COUNT 4
+#define SMR_K_SPAWN 4     /* A10: a new ball for the envs whose ball was retired         */
+#define SMR_K_COUNT 5
 
 typedef struct smr_env smr_env_t;   /* opaque */
 
@@ -70,6 +71,11 @@ typedef struct smr_host_state {
     int32_t *step_count;   /* [B]    _episode_length, base.py:1044                               */
     int32_t *moving_hit;   /* [B]    latched Planet._collision_detected, ctlp.py:4570-4579       */
     uint32_t *reset_count; /* [B]    resets of the env so far = Philox tag of its next reset            */
+    float *ball;           /* [B][10] ball launch point, launch velocity, initial euler angles, spin rate
+                              (Ball._base_pos, _initial_speed_vector, _initial_orn_euler, _angular_velocity_vector[1],
+                              ctlp.py:4027-4059) */
+    int32_t *ball_i;       /* [B][5] _position_update_step_counter, _max_time_update_step_counter, obstacle_hit_time,
+                              active flag, balls spawned so far (ctlp.py:4076,4101,1903-1915) */
 } smr_host_state_t;
 
 int smr_abi_version(void);
@@ -119,6 +125,10 @@ int smr_test_safe_acc_range(smr_env_t *env, const float *p_host, const float *v_
 /* A7/A8/A11: out [n][4] = d_static, d_self, d_moving (no latch), contact flag; planet_idx [n][2] */
 int smr_test_distances(smr_env_t *env, const float *q_host, const int32_t *planet_idx_host, int32_t n,
                        float *out);
+/* ball scene: the same four values against a ball given by ball_host [n][10] (layout of smr_host_state_t.ball)
+ * after k_host[n] updates */
+int smr_test_ball_distances(smr_env_t *env, const float *q_host, const float *ball_host, const int32_t *k_host,
+                            int32_t n, float *out);
 
 #ifdef __cplusplus
 }

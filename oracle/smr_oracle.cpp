@@ -85,8 +85,9 @@ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
  * tag = the env's reset counter, so every reset of every env has its own streams and the order in which
  * the streams are consumed does not matter (the GPU kernel evaluates candidates of one stream in parallel).
  * streams: 0 start-position attempts, 1..7 joint velocity/acceleration tries, 8 random walk, 9 planet phase,
- * 10 sampling-mode choice. */
-enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10 };
+ * 10 sampling-mode choice; ball streams (tag = the env's ball spawn counter): 11 release point + launch-angle choice,
+ * 12 target robot poses, 13 spin rate and initial time step. */
+enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10, S_BALL_RELEASE = 11, S_BALL_POSE = 12, S_BALL_MISC = 13 };
 
 struct Rng {
     uint64_t seed;
@@ -400,6 +401,10 @@ struct EnvState {
     int32_t step_count;
     int32_t moving_hit;        /* latched Planet._collision_detected / ball hit_robot */
     uint32_t reset_count;      /* number of resets of this env = Philox tag of the next reset */
+    /* ball (A10): launch state, orientation, update counters (Ball._position_update_step_counter etc.) */
+    double ball_p0[3], ball_v0[3], ball_e0[3], ball_omega;
+    int32_t ball_k, ball_kmax, ball_khit, ball_active;
+    uint32_t ball_spawns;      /* balls spawned so far = Philox tag of the next ball */
 };
 
 struct Oracle {
@@ -413,6 +418,8 @@ struct Oracle {
     std::string err;
     int num_threads;
 };
+
+Xf ball_pose(const Oracle &O, const EnvState &st, int k, double *vel_out);
 
 inline Hull piece_hull(const Oracle &O, int piece, const Xf &X) {
     const smr_piece_t &P = O.pieces[piece];
@@ -520,28 +527,40 @@ void observation(const Oracle &O, const EnvState &e, float *obs) {
             }
         }
     }
+    if (S.use_ball) {                                        /* get_moving_object_observation, ctlp.py:2364-2377 */
+        double vel[3];
+        Xf Xb = ball_pose(O, e, e.ball_k, vel);
+        double pos[3] = {Xb.t.x, Xb.t.y, Xb.t.z};
+        for (int c = 0; c < 3; ++c) obs[o++] = (float)(-1 + 2 * (pos[c] - S.ball_obs_pos_min[c]) / (S.ball_obs_pos_max[c] - S.ball_obs_pos_min[c]));
+        for (int c = 0; c < 3; ++c) obs[o++] = (float)(-1 + 2 * (vel[c] - S.ball_obs_vel_min[c]) / (S.ball_obs_vel_max[c] - S.ball_obs_vel_min[c]));
+    }
     for (int i = 0; i < o; ++i) obs[i] = std::min(1.0f, std::max(-1.0f, obs[i]));
 }
 
 /* A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138 (gravity-torque check via one
- * physics step omitted: kinematic restatement). */
-bool position_is_valid(const Oracle &O, const double q[SMR_NJ]) {
+ * physics step omitted: kinematic restatement).  box / thr: cartesian range of the end-effector point and
+ * minimum table distance (start states: ctlp.py:172-183,1468-1477; ball targets: ctlp.py:191-229,1725-1726). */
+bool pose_is_valid(const Oracle &O, const double q[SMR_NJ], const double box[3][2], double thr, V3 *ee_out) {
     const smr_scene_t &S = O.S;
     Xf link[SMR_NLINK];
     forward_kinematics(S, q, link);
     V3 ee = apply(link[SMR_NLINK - 1], {S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
+    if (ee_out) *ee_out = ee;
     double e[3] = {ee.x, ee.y, ee.z};
     for (int c = 0; c < 3; ++c)
-        if (e[c] < S.start_box[c][0] || e[c] > S.start_box[c][1]) return false;          /* ctlp.py:2054-2061 */
+        if (e[c] < box[c][0] || e[c] > box[c][1]) return false;                             /* ctlp.py:2054-2061 */
     Xf I = identity_xf();
     for (int s = 0; s < S.n_static; ++s)                                                    /* ctlp.py:2140-2168 */
         for (int k = 0; k < SMR_NLINK; ++k) {
             if (!(S.static_link_mask & (1u << k))) continue;
-            double thr = S.start_min_dist_static;
             double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], thr + 0.005);
             if (d <= thr + 0.005 && d < thr) return false;
         }
     return true;
+}
+
+bool position_is_valid(const Oracle &O, const double q[SMR_NJ]) {
+    return pose_is_valid(O, q, O.S.start_box, O.S.start_min_dist_static, nullptr);
 }
 
 /* next valid start position: attempt n uses draws 7n..7n+6 of stream S_POS (ctlp.py:2030-2037) */
@@ -566,6 +585,183 @@ bool table_free(const Oracle &O, const double q[SMR_NJ]) {                    /*
             if (d <= thr + 0.005 && d < thr) return false;
         }
     return true;
+}
+
+/* ------------------------------------------------------------------------------------------- *
+ * A10: ballistic moving obstacle (Ball, ctlp.py:4001-4361; spawning: _add_moving_object ctlp.py:1723-1931).
+ * ------------------------------------------------------------------------------------------- */
+const double kGravity = 9.81;
+
+/* Ball.get_target_height_time, ctlp.py:4346-4361: time at which the ball passes target_height on its way down */
+double ball_height_time(double h0, double vz, double target, double update_dt, double *steps) {
+    double sq = vz * vz + 2 * kGravity * (h0 - target);
+    double t = std::nan("");
+    if (steps) *steps = std::nan("");
+    if (sq >= 0) {
+        t = (vz + std::sqrt(sq)) / kGravity;
+        if (t > 0) { if (steps) *steps = std::nearbyint(t / update_dt); }      /* python round(): half to even */
+        else t = std::nan("");
+    }
+    return t;
+}
+
+/* pybullet.getQuaternionFromEuler / getEulerFromQuaternion / the two helpers of ctlp.py:5389-5421 */
+void quat_from_euler(const double e[3], double q[4]) {
+    double cr = std::cos(e[0] / 2), sr = std::sin(e[0] / 2), cp = std::cos(e[1] / 2), sp = std::sin(e[1] / 2),
+           cy = std::cos(e[2] / 2), sy = std::sin(e[2] / 2);
+    q[0] = sr * cp * cy - cr * sp * sy; q[1] = cr * sp * cy + sr * cp * sy; q[2] = cr * cp * sy - sr * sp * cy;
+    q[3] = cr * cp * cy + sr * sp * sy;
+}
+void euler_from_quat(const double q[4], double e[3]) {
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double sarg = -2 * (x * z - w * y);
+    if (sarg <= -0.99999) { e[1] = -0.5 * M_PI; e[0] = 0; e[2] = 2 * std::atan2(x, -y); }
+    else if (sarg >= 0.99999) { e[1] = 0.5 * M_PI; e[0] = 0; e[2] = 2 * std::atan2(-x, y); }
+    else {
+        e[0] = std::atan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z);
+        e[1] = std::asin(sarg);
+        e[2] = std::atan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z);
+    }
+}
+void ball_initial_euler(const double dir[3], double e[3]) {
+    /* rotation taking +z to dir (ctlp.py:5389-5397), then the quaternion of its TRANSPOSE (ctlp.py:4031-4034) */
+    double v[3] = {-dir[1], dir[0], 0.0};                 /* z x dir */
+    double c = dir[2], s2 = v[0] * v[0] + v[1] * v[1];
+    double K[3][3] = {{0, -v[2], v[1]}, {v[2], 0, -v[0]}, {-v[1], v[0], 0}};
+    double R[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double kk = 0;
+            for (int k = 0; k < 3; ++k) kk += K[i][k] * K[k][j];
+            R[i][j] = (i == j ? 1.0 : 0.0) + K[i][j] + kk * ((1 - c) / s2);
+        }
+    double m[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = R[j][i];
+    double t, q[4];
+    if (m[2][2] < 0) {                                   /* ctlp.py:5400-5421 */
+        if (m[0][0] > m[1][1]) { t = 1 + m[0][0] - m[1][1] - m[2][2]; q[0] = t; q[1] = m[0][1] + m[1][0]; q[2] = m[2][0] + m[0][2]; q[3] = m[1][2] - m[2][1]; }
+        else { t = 1 - m[0][0] + m[1][1] - m[2][2]; q[0] = m[0][1] + m[1][0]; q[1] = t; q[2] = m[1][2] + m[2][1]; q[3] = m[2][0] - m[0][2]; }
+    } else {
+        if (m[0][0] < -m[1][1]) { t = 1 - m[0][0] - m[1][1] + m[2][2]; q[0] = m[2][0] + m[0][2]; q[1] = m[1][2] + m[2][1]; q[2] = t; q[3] = m[0][1] - m[1][0]; }
+        else { t = 1 + m[0][0] + m[1][1] + m[2][2]; q[0] = m[1][2] - m[2][1]; q[1] = m[2][0] - m[0][2]; q[2] = m[0][1] - m[1][0]; q[3] = t; }
+    }
+    for (int i = 0; i < 4; ++i) q[i] *= 0.5 / std::sqrt(t);
+    euler_from_quat(q, e);
+}
+
+/* pose of the ball after k updates: Ball.update, ctlp.py:4103-4126 */
+Xf ball_pose(const Oracle &O, const EnvState &st, int k, double *vel_out) {
+    double t = k * (O.S.dt / O.S.updates_per_step);
+    Xf X;
+    X.t = {st.ball_p0[0] + st.ball_v0[0] * t, st.ball_p0[1] + st.ball_v0[1] * t,
+           st.ball_p0[2] + st.ball_v0[2] * t - 0.5 * kGravity * t * t};
+    double e[3] = {st.ball_e0[0], st.ball_e0[1] + t * st.ball_omega, st.ball_e0[2]}, q[4];
+    quat_from_euler(e, q);
+    quat_to_R(q, X.R);
+    if (vel_out) { vel_out[0] = st.ball_v0[0]; vel_out[1] = st.ball_v0[1]; vel_out[2] = st.ball_v0[2] - kGravity * t; }
+    return X;
+}
+
+bool ball_contact(const Oracle &O, const Xf link[SMR_NLINK], const Xf &Xb) {        /* Ball.check_if_object_is_colliding */
+    const smr_scene_t &S = O.S;
+    for (int k = 0; k < SMR_NLINK; ++k) {
+        if (!(S.contact_link_mask & (1u << k))) continue;
+        double d = piece_distance(O, S.ball_piece, Xb, S.link_piece[k], link[k], S.contact_distance);
+        if (d <= S.contact_distance) return true;
+    }
+    return false;
+}
+
+double ball_min_distance(const Oracle &O, const Xf link[SMR_NLINK], const Xf &Xb) {   /* ctlp.py:3258-3280 */
+    const smr_scene_t &S = O.S;
+    double dmin = S.moving_max_distance + 0.002;
+    for (int k = 0; k < SMR_NLINK; ++k) {
+        if (!(S.moving_link_mask & (1u << k))) continue;
+        double d = piece_distance(O, S.ball_piece, Xb, S.link_piece[k], link[k], S.moving_max_distance);
+        if (d <= S.moving_max_distance && d < dmin) { dmin = d; if (dmin <= 0.0) return 0.0; }
+    }
+    return dmin;
+}
+
+/* _add_moving_object, ctlp.py:1723-1931 (sphere release, aim at a random collision-free robot pose) */
+void spawn_ball(Oracle &O, int e) {
+    const smr_scene_t &S = O.S;
+    EnvState &st = O.st[e];
+    Rng rng = {O.seed, (uint32_t)e, st.ball_spawns};
+    st.ball_spawns += 1;
+    const double udt = S.dt / S.updates_per_step, v = S.ball_speed;
+    double rel[3] = {0, 0, 0}, vel[3] = {0, 0, 1};
+    uint32_t pose_attempt = 0;
+    for (uint32_t n = 0; n < 25000; ++n) {
+        /* _get_moving_object_release_point, ctlp.py:1943-1952 */
+        double h = rng.uniform(S_BALL_RELEASE, 3 * n, S.ball_sphere_height[0], S.ball_sphere_height[1]);
+        double r = std::sqrt(S.ball_sphere_radius * S.ball_sphere_radius - h * h);
+        double ang = rng.uniform(S_BALL_RELEASE, 3 * n + 1, S.ball_sphere_angle[0], S.ball_sphere_angle[1]);
+        rel[0] = S.ball_sphere_center[0] + r * std::cos(ang); rel[1] = S.ball_sphere_center[1] + r * std::sin(ang);
+        rel[2] = S.ball_sphere_center[2] + h;
+        /* target = end-effector point of the next valid random robot pose, ctlp.py:1782-1790 */
+        V3 target = {0, 0, 0};
+        for (int it = 0; it < 25000; ++it) {
+            uint32_t m = pose_attempt++;
+            double q[SMR_NJ];
+            for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S_BALL_POSE, 7 * m + j, S.pos_lo[j], S.pos_hi[j]);
+            if (pose_is_valid(O, q, S.ball_target_box, S.ball_target_min_dist_static, &target)) break;
+        }
+        double dx = target.x - rel[0], dy = target.y - rel[1], dh = target.z - rel[2];
+        double dxy = std::sqrt(dx * dx + dy * dy);
+        double sq = v * v * v * v - kGravity * (kGravity * dxy * dxy + 2 * dh * v * v);      /* ctlp.py:1797 */
+        bool valid = sq >= 0;
+        if (valid) {
+            bool high = rng.uniform01(S_BALL_RELEASE, 3 * n + 2) <= S.ball_high_angle_prob;
+            double theta = std::atan((v * v + (high ? 1.0 : -1.0) * std::sqrt(sq)) / (kGravity * dxy));
+            vel[2] = v * std::sin(theta);
+            vel[0] = v * std::cos(theta) * dx / dxy; vel[1] = v * std::cos(theta) * dy / dxy;
+            if (S.ball_check_invalid_target) {                                               /* ctlp.py:1813-1848 */
+                double tt = ball_height_time(rel[2], vel[2], S.ball_invalid_max[2] + S.ball_radius, udt, nullptr);
+                double tb = ball_height_time(rel[2], vel[2], S.ball_invalid_min[2] + S.ball_radius, udt, nullptr);
+                auto inside = [&](double t) {
+                    if (std::isnan(t)) return false;
+                    double x = rel[0] + vel[0] * t, y = rel[1] + vel[1] * t;
+                    return S.ball_invalid_min[0] <= x && x <= S.ball_invalid_max[0] && S.ball_invalid_min[1] <= y && y <= S.ball_invalid_max[1];
+                };
+                if (inside(tt) || inside(tb)) valid = false;
+            }
+        }
+        if (valid) break;
+    }
+    for (int c = 0; c < 3; ++c) { st.ball_p0[c] = rel[c]; st.ball_v0[c] = vel[c]; }
+    st.ball_omega = rng.uniform(S_BALL_MISC, 0, 0.0, 2 * M_PI);                               /* ctlp.py:4056-4057 */
+    double nv = std::sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+    double dir[3] = {vel[0] / nv, vel[1] / nv, vel[2] / nv};
+    ball_initial_euler(dir, st.ball_e0);
+    /* Ball.get_final_ball_position, ctlp.py:4303-4344: exit of the box final_min..final_max */
+    double tf = std::nan("");
+    for (int i = 0; i < 2; ++i) {
+        int a = (i + 1) % 3, b = (i + 2) % 3;
+        if (vel[i] == 0) continue;
+        for (int j = 0; j < 2; ++j) {
+            double lim = j == 0 ? S.ball_final_min[i] : S.ball_final_max[i];
+            double tt = (lim - rel[i]) / vel[i];
+            double pa = rel[a] + vel[a] * tt, pb = rel[b] + vel[b] * tt;      /* straight line, as the reference */
+            if (S.ball_final_min[a] <= pa && pa <= S.ball_final_max[a] && S.ball_final_min[b] <= pb && pb <= S.ball_final_max[b])
+                if (std::isnan(tf) || tt > tf) tf = tt;
+        }
+    }
+    double tmin = ball_height_time(rel[2], vel[2], S.ball_final_min[2], udt, nullptr);
+    if (!std::isnan(tmin) && (std::isnan(tf) || tmin < tf)) tf = tmin;
+    st.ball_kmax = std::isnan(tf) ? 0 : (int32_t)std::floor(tf / udt);                         /* ctlp.py:4101 */
+    /* obstacle hit: table top if the landing point is on the table, else the ground plane, ctlp.py:1889-1917 */
+    double steps;
+    double tt = ball_height_time(rel[2], vel[2], S.ball_radius, udt, &steps);
+    bool on_table = false;
+    if (S.n_static > 0 && !std::isnan(tt)) {
+        double x = rel[0] + vel[0] * tt, y = rel[1] + vel[1] * tt;
+        on_table = -S.table_half_xy[0] <= x && x <= S.table_half_xy[0] && -S.table_half_xy[1] <= y && y <= S.table_half_xy[1];
+    }
+    if (!on_table) ball_height_time(rel[2], vel[2], S.plane_z + S.ball_radius, udt, &steps);
+    st.ball_khit = std::isnan(steps) ? INT32_MAX : (int32_t)steps - 1;
+    st.ball_k = 0;
+    st.ball_active = 1;
 }
 
 void reset_env(Oracle &O, int e) {
@@ -634,6 +830,22 @@ void reset_env(Oracle &O, int e) {
     st.step_count = 0;
     st.moving_hit = 0;
     st.planet_idx[0] = st.planet_idx[1] = 0;
+    if (S.use_ball) {                                                                       /* ctlp.py:1052-1111 */
+        spawn_ball(O, e);
+        if (S.ball_random_initial_position) {
+            Rng brng = {O.seed, (uint32_t)e, st.ball_spawns - 1};
+            int kcap = st.ball_kmax;
+            if (st.ball_khit < kcap) kcap = st.ball_khit;
+            int max_ts = kcap / S.updates_per_step;
+            if (max_ts < 0) max_ts = 0;
+            Xf link[SMR_NLINK];
+            forward_kinematics(S, q, link);
+            for (uint32_t m = 0; m < 100000; ++m) {
+                st.ball_k = brng.randint(S_BALL_MISC, 1 + m, max_ts + 1) * S.updates_per_step;
+                if (!ball_contact(O, link, ball_pose(O, st, st.ball_k, nullptr))) break;
+            }
+        }
+    }
     if (S.n_planets > 0) {
         /* Planet.reset: random phase until contact free, ctlp.py:4470-4501 */
         Xf link[SMR_NLINK];
@@ -682,15 +894,27 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
     int N = S.collision_checks_per_step;
     int upd = S.updates_per_step / N;
     Xf link[SMR_NLINK];
+    /* ball: update at which it is retired for having passed the robot or hit table/ground, ctlp.py:2836-2848 */
+    const bool ball_active0 = S.use_ball && st.ball_active;
+    int u_end = S.updates_per_step + 1;
+    if (ball_active0)
+        for (int u = 1; u <= S.updates_per_step; ++u)
+            if (st.ball_k + u > st.ball_kmax || st.ball_k + u >= st.ball_khit) { u_end = u; break; }
+    bool ball_hit = false;
     for (int k = 1; k <= N; ++k) {
         double t = S.dt * k / N, qk[SMR_NJ];
         for (int j = 0; j < SMR_NJ; ++j) qk[j] = interp_pos(st.q[j], st.v[j], st.a[j], a1[j], t, S.dt);
         int32_t idx[SMR_MAX_PLANETS];
         for (int p = 0; p < S.n_planets; ++p) idx[p] = (st.planet_idx[p] + k * upd) % S.planet[p].n_orbit;
-        if (k < N && (st.moving_hit || !S.terminate_on_moving_collision || S.n_planets == 0)) continue;
+        const bool planet_check = S.terminate_on_moving_collision && S.n_planets > 0 && !st.moving_hit;
+        const bool ball_check = ball_active0 && !ball_hit && k * upd < u_end;
+        if (k < N && !planet_check && !ball_check) continue;
         forward_kinematics(S, qk, link);
-        if (S.terminate_on_moving_collision && S.n_planets > 0 && !st.moving_hit && moving_contact(O, link, idx))
-            st.moving_hit = 1;
+        if (planet_check && moving_contact(O, link, idx)) st.moving_hit = 1;
+        if (ball_check) {                                                     /* ctlp.py:2849-2861 */
+            Xf Xb = ball_pose(O, st, st.ball_k + k * upd, nullptr);
+            if (std::sqrt(Xb.t.x * Xb.t.x + Xb.t.y * Xb.t.y) < S.ball_active_xy_radius && ball_contact(O, link, Xb)) ball_hit = true;
+        }
     }
 
     /* process_step_outcome: new start state = last setpoint, base.py:1179-1181 */
@@ -712,7 +936,19 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
     if (S.self_max_reward != 0) { double r = std::min(1.0, d_self / S.self_max_reward_distance); r_self = r * r; }
     if (S.static_max_reward != 0) { double r = std::min(1.0, d_static / S.static_max_reward_distance); r_static = r * r; }
     double d_moving;
-    if (st.moving_hit) d_moving = 0.0;                                       /* ctlp.py:3229-3234 */
+    bool ball_retired = false;
+    if (S.use_ball) {                                                        /* ctlp.py:3217-3256 */
+        d_moving = S.moving_max_distance + 0.002;
+        if (ball_active0) {
+            if (ball_hit) { d_moving = 0.0; ball_retired = true; }           /* final state hit_robot, ctlp.py:3224-3227 */
+            else if (u_end <= S.updates_per_step) ball_retired = true;       /* missed the robot / hit an obstacle */
+            else {
+                st.ball_k += S.updates_per_step;
+                d_moving = ball_min_distance(O, link, ball_pose(O, st, st.ball_k, nullptr));
+            }
+            if (ball_retired) st.ball_active = 0;
+        }
+    } else if (st.moving_hit) d_moving = 0.0;                                /* ctlp.py:3229-3234 */
     else d_moving = (S.n_planets > 0) ? min_distance_moving(O, link, st.planet_idx) : S.moving_max_distance + 0.002;
     if (d_moving < S.collision_distance) { d_moving = 0; col_moving = true; }
     { double r = std::min(1.0, d_moving / S.moving_max_reward_distance); r_moving = r * r; }
@@ -764,6 +1000,7 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         info[INFO_R_STATIC] = r_static; info[INFO_R_MOVING] = r_moving; info[INFO_EPISODE_LENGTH] = st.step_count;
     }
     if (d && S.auto_reset) reset_env(O, e);
+    else if (S.use_ball && !st.ball_active) spawn_ball(O, e);   /* get_moving_object_observation, ctlp.py:2354-2360 */
     observation(O, st, obs);
 }
 
@@ -826,7 +1063,7 @@ void smo_step(void *h, const double *actions, float *obs, double *reward, uint8_
 }
 
 void smo_get_state(void *h, double *q, double *v, double *a, int32_t *planet_idx, int32_t *step_count,
-                   int32_t *moving_hit, uint32_t *reset_count) {
+                   int32_t *moving_hit, uint32_t *reset_count, double *ball /*[B][10]*/, int32_t *ball_i /*[B][5]*/) {
     Oracle &O = *(Oracle *)h;
     for (int e = 0; e < O.B; ++e) {
         const EnvState &s = O.st[e];
@@ -839,11 +1076,21 @@ void smo_get_state(void *h, double *q, double *v, double *a, int32_t *planet_idx
         if (step_count) step_count[e] = s.step_count;
         if (moving_hit) moving_hit[e] = s.moving_hit;
         if (reset_count) reset_count[e] = s.reset_count;
+        if (ball) {
+            double *b = ball + 10 * (size_t)e;
+            for (int c = 0; c < 3; ++c) { b[c] = s.ball_p0[c]; b[3 + c] = s.ball_v0[c]; b[6 + c] = s.ball_e0[c]; }
+            b[9] = s.ball_omega;
+        }
+        if (ball_i) {
+            int32_t *b = ball_i + 5 * (size_t)e;
+            b[0] = s.ball_k; b[1] = s.ball_kmax; b[2] = s.ball_khit; b[3] = s.ball_active; b[4] = (int32_t)s.ball_spawns;
+        }
     }
 }
 
 void smo_set_state(void *h, const double *q, const double *v, const double *a, const int32_t *planet_idx,
-                   const int32_t *step_count, const int32_t *moving_hit, const uint32_t *reset_count) {
+                   const int32_t *step_count, const int32_t *moving_hit, const uint32_t *reset_count, const double *ball,
+                   const int32_t *ball_i) {
     Oracle &O = *(Oracle *)h;
     for (int e = 0; e < O.B; ++e) {
         EnvState &s = O.st[e];
@@ -856,6 +1103,15 @@ void smo_set_state(void *h, const double *q, const double *v, const double *a, c
         if (step_count) s.step_count = step_count[e];
         if (moving_hit) s.moving_hit = moving_hit[e];
         if (reset_count) s.reset_count = reset_count[e];
+        if (ball) {
+            const double *b = ball + 10 * (size_t)e;
+            for (int c = 0; c < 3; ++c) { s.ball_p0[c] = b[c]; s.ball_v0[c] = b[3 + c]; s.ball_e0[c] = b[6 + c]; }
+            s.ball_omega = b[9];
+        }
+        if (ball_i) {
+            const int32_t *b = ball_i + 5 * (size_t)e;
+            s.ball_k = b[0]; s.ball_kmax = b[1]; s.ball_khit = b[2]; s.ball_active = b[3]; s.ball_spawns = (uint32_t)b[4];
+        }
     }
 }
 
@@ -921,6 +1177,21 @@ double smo_link_planet_piece_distance(void *h, const double *q, int32_t k, int32
     Xf link[SMR_NLINK];
     forward_kinematics(O.S, q, link);
     return piece_distance(O, O.S.planet[p].piece_begin + piece, planet_pose(O, p, idx), O.S.link_piece[k], link[k], 1e30);
+}
+
+/* ball scene: {d_static, d_self, d_moving, contact} for joint vector q and a ball given by (p0,v0,e0,omega) after k updates */
+void smo_ball_distances(void *h, const double *q, const double *ball, int32_t k, double *out) {
+    Oracle &O = *(Oracle *)h;
+    EnvState st;
+    std::memset(&st, 0, sizeof st);
+    for (int c = 0; c < 3; ++c) { st.ball_p0[c] = ball[c]; st.ball_v0[c] = ball[3 + c]; st.ball_e0[c] = ball[6 + c]; }
+    st.ball_omega = ball[9];
+    Xf link[SMR_NLINK];
+    forward_kinematics(O.S, q, link);
+    min_distance_static_self(O, link, out[0], out[1]);
+    Xf Xb = ball_pose(O, st, k, nullptr);
+    out[2] = ball_min_distance(O, link, Xb);
+    out[3] = ball_contact(O, link, Xb) ? 1.0 : 0.0;
 }
 
 int32_t smo_position_is_valid(void *h, const double *q) { return position_is_valid(*(Oracle *)h, q) ? 1 : 0; }

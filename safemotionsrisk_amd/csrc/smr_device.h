@@ -59,6 +59,14 @@ struct DScene {
     int n_planets, obs_planet_size, obs_num_planets;
     DPlanet planet[SMR_MAX_PLANETS];
     float planet_obs_min[3], planet_obs_max[3];
+    // ball (A10)
+    int use_ball, ball_piece, ball_check_invalid, ball_random_initial;
+    float ball_radius, ball_active_xy_radius;
+    float ball_obs_pos_min[3], ball_obs_pos_max[3], ball_obs_vel_min[3], ball_obs_vel_max[3];
+    float ball_target_box[3][2], ball_target_min_static;
+    double ball_speed, ball_center[3], ball_sphere_radius, ball_height[2], ball_angle[2], ball_high_prob;   // spawn math runs in float64
+    double ball_invalid_min[3], ball_invalid_max[3], ball_final_min[3], ball_final_max[3], plane_z, table_half_xy[2];
+    double dt64;
     int punish_action, term_self, term_static, term_moving;
     float action_thr, action_max_pun;
     float self_max_reward, self_max_dist, static_max_reward, static_max_dist, moving_max_reward, moving_max_dist;
@@ -83,6 +91,10 @@ struct DState {
     float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
     int *done_list;            // [B]
     int *done_count;           // [1]
+    float *ball;               // [10][B] launch point p0, launch velocity v0, initial euler angles e0, spin rate
+    int *ball_i;               // [5][B]  update counter k, k_max (passed the robot), k_hit (table/ground), active, spawn counter
+    int *spawn_list;           // [B]  envs whose ball was retired in this step
+    int *spawn_count;          // [1]
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -115,7 +127,7 @@ __device__ __forceinline__ F3 apply(const Xf &X, F3 v) { return rot(X, v) + X.t;
 // "the first valid one" exactly like a sequential loop.  24-bit uniforms are exact in float32.
 // (Reference: numpy's global RNG, base.py:1704-1710.)
 // ---------------------------------------------------------------------------------------------
-enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10 };
+enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10, S_BALL_RELEASE = 11, S_BALL_POSE = 12, S_BALL_MISC = 13 };
 
 struct Rng {
     unsigned k0, k1, env, tag;
@@ -134,6 +146,8 @@ struct Rng {
     }
     __device__ float uniform01(unsigned stream, unsigned draw) const { return (float)(u32(stream, draw) >> 8) * (1.0f / 16777216.0f); }
     __device__ float uniform(unsigned stream, unsigned draw, float lo, float hi) const { return fmaf(uniform01(stream, draw), hi - lo, lo); }
+    __device__ double uniform01d(unsigned stream, unsigned draw) const { return (double)(u32(stream, draw) >> 8) * (1.0 / 16777216.0); }
+    __device__ double uniformd(unsigned stream, unsigned draw, double lo, double hi) const { return lo + uniform01d(stream, draw) * (hi - lo); }
     __device__ int randint(unsigned stream, unsigned draw, int n) const {
         return (int)(((unsigned long long)(u32(stream, draw) >> 8) * (unsigned long long)n) >> 24);
     }
@@ -575,26 +589,74 @@ __device__ inline Sample collide_sample(const DScene &S, const float q[SMR_NJ], 
     return out;
 }
 
+// ---------------------------------------------------------------------------------------------
+// A10: ball.  Pose after k updates (Ball.update, ctlp.py:4103-4126): ballistic position, orientation from
+// euler angles e0 + t (0, omega, 0) (pybullet.getQuaternionFromEuler).
+// ---------------------------------------------------------------------------------------------
+struct BallState { float p0[3], v0[3], e0[3], omega; };
+
+__device__ __forceinline__ BallState load_ball(const DState &st, int B, int e) {
+    BallState b;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { b.p0[c] = st.ball[c * B + e]; b.v0[c] = st.ball[(3 + c) * B + e]; b.e0[c] = st.ball[(6 + c) * B + e]; }
+    b.omega = st.ball[9 * B + e];
+    return b;
+}
+
+__device__ inline Xf ball_pose(const DScene &S, const BallState &b, int k, float vel[3]) {
+    const float t = (float)k * (S.dt / (float)S.updates_per_step);
+    Xf X;
+    X.t = {b.p0[0] + b.v0[0] * t, b.p0[1] + b.v0[1] * t, b.p0[2] + b.v0[2] * t - 0.5f * 9.81f * t * t};
+    float sr, cr, sp, cp, sy, cy;
+    sincosf(0.5f * b.e0[0], &sr, &cr);
+    sincosf(0.5f * (b.e0[1] + t * b.omega), &sp, &cp);
+    sincosf(0.5f * b.e0[2], &sy, &cy);
+    float row[7] = {0.f, 0.f, 0.f, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+    float x = row[3], y = row[4], z = row[5], w = row[6];
+    X.r[0] = 1.f - 2.f * (y * y + z * z); X.r[1] = 2.f * (x * y - z * w);       X.r[2] = 2.f * (x * z + y * w);
+    X.r[3] = 2.f * (x * y + z * w);       X.r[4] = 1.f - 2.f * (x * x + z * z); X.r[5] = 2.f * (y * z - x * w);
+    X.r[6] = 2.f * (x * z - y * w);       X.r[7] = 2.f * (y * z + x * w);       X.r[8] = 1.f - 2.f * (x * x + y * y);
+    if (vel) { vel[0] = b.v0[0]; vel[1] = b.v0[1]; vel[2] = b.v0[2] - 9.81f * t; }
+    return X;
+}
+
+// first update u in 1..updates_per_step at which the ball is retired for having passed the robot or reached
+// the table / ground (ctlp.py:2836-2848, 4196-4211); updates_per_step + 1 if it survives the step
+__device__ __forceinline__ int ball_retire_update(const DScene &S, int k, int kmax, int khit) {
+    int u1 = kmax - k + 1, u2 = khit - k;              // k + u > kmax  |  k + u >= khit
+    int u = u1 < u2 ? u1 : u2;
+    if (u < 1) u = 1;
+    return u > S.updates_per_step ? S.updates_per_step + 1 : u;
+}
+
 // The same queries for ONE robot link (the step path runs one lane per (env, sample, link): 8x the
 // wavefronts of collide_sample, which is what keeps the SIMDs occupied while lanes wait on each other).
 // T is the link frame; every loop bound and piece index is wave uniform.
-__device__ inline Sample collide_link(const DScene &S, int l, const Xf &T, const int idx[SMR_MAX_PLANETS], bool want_dist,
-                                      bool want_contact) {
+__device__ inline Sample collide_link(const DScene &S, int l, const Xf &T, const int idx[SMR_MAX_PLANETS], const Xf *XB,
+                                      bool want_static, bool want_moving, bool want_contact) {
     Sample out;
     out.d_static = S.static_max;
     out.d_moving = S.moving_max + 0.002f;
     out.contact = false;
     const int pl = S.link_piece[l];
-    if (want_dist && ((S.static_mask >> l) & 1u)) {
+    if (want_static && ((S.static_mask >> l) & 1u)) {
         for (int s = 0; s < S.n_static; ++s) {
             float d = piece_distance<true>(S, S.static_piece[s], T, pl, T, out.d_static, S.collision_dist);
             if (d <= S.static_max && d < out.d_static) out.d_static = d;
         }
     }
-    const bool mov = want_dist && ((S.moving_mask >> l) & 1u);
+    const bool mov = want_moving && ((S.moving_mask >> l) & 1u);
     const bool con_link = (S.contact_mask >> l) & 1u;
     if (!(mov || (want_contact && con_link))) return out;
     const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
+    if (S.use_ball) {                                   // one moving piece: the ball, pose XB
+        const bool con = want_contact && con_link;
+        float cutoff = mov ? S.moving_max : S.contact_dist;
+        float d = piece_distance<false>(S, S.ball_piece, *XB, pl, T, cutoff, stop_moving);
+        if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
+        if (con && d <= S.contact_dist) out.contact = true;
+        return out;
+    }
     for (int p = 0; p < S.n_planets; ++p) {
         const Xf XP = planet_pose(S, p, idx[p]);
         const int pb = S.planet[p].piece_begin, pc = S.planet[p].piece_count;
@@ -628,6 +690,18 @@ __device__ inline void write_planet_observation(const DScene &S, const int idx[S
             for (int c = 0; c < 3; ++c)
                 row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (pose[c] - S.planet_obs_min[c]) / (S.planet_obs_max[c] - S.planet_obs_min[c])));
         }
+    }
+}
+
+// A15: ball part of the observation (get_moving_object_observation, ctlp.py:2364-2377)
+__device__ inline void write_ball_observation(const DScene &S, const BallState &b, int k, float *row) {
+    float vel[3];
+    Xf X = ball_pose(S, b, k, vel);
+    float pos[3] = {X.t.x, X.t.y, X.t.z};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        row[c] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (pos[c] - S.ball_obs_pos_min[c]) / (S.ball_obs_pos_max[c] - S.ball_obs_pos_min[c])));
+        row[3 + c] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (vel[c] - S.ball_obs_vel_min[c]) / (S.ball_obs_vel_max[c] - S.ball_obs_vel_min[c])));
     }
 }
 

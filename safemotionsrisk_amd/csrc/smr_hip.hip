@@ -48,24 +48,47 @@ __global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ 
     const int k = (int)blockIdx.y + 1;                 // sample k of N, t_k = k dt / N
     const int l = (int)blockIdx.z;                     // iiwa_link_l
     const bool final_sample = (k == N);
+    const int upd = S.updates_per_step / N;
     float *res = st.res + ((size_t)(k - 1) * SMR_NLINK + l) * B;
-    const bool want_contact = S.term_moving && S.n_planets > 0 && st.moving_hit[e] == 0 && ((S.contact_mask >> l) & 1u);
-    const bool want_dist = final_sample && (((S.static_mask | S.moving_mask) >> l) & 1u);
+    const bool con_link = (S.contact_mask >> l) & 1u;
+    bool want_contact, moving_alive = true;
+    BallState ball;
+    int ball_k = 0;
+    if (S.use_ball) {
+        // the ball is tested at this sample only while it is in flight (ctlp.py:2836-2861): not yet retired by the
+        // update counters, and inside the 1.25 m cylinder around the robot
+        const int k0 = st.ball_i[e], active = st.ball_i[3 * B + e];
+        const int u_end = ball_retire_update(S, k0, st.ball_i[B + e], st.ball_i[2 * B + e]);
+        moving_alive = active && (k * upd < u_end);
+        ball = load_ball(st, B, e);
+        ball_k = k0 + k * upd;
+        want_contact = moving_alive && con_link;
+    } else {
+        want_contact = S.term_moving && S.n_planets > 0 && st.moving_hit[e] == 0 && con_link;
+    }
+    const bool want_static = final_sample && ((S.static_mask >> l) & 1u);
+    const bool want_moving = final_sample && moving_alive && ((S.moving_mask >> l) & 1u);
     if (final_sample) { st.dist[(size_t)l * B + e] = S.static_max; st.dist[(size_t)(SMR_NLINK + l) * B + e] = S.moving_max + 0.002f; }
     res[e] = 0.f;
-    if (!want_dist && !want_contact) return;
+    if (!want_static && !want_moving && !want_contact) return;
     const float t = final_sample ? S.dt : S.dt * (float)k / (float)N;
     Xf T = fk_base(S);
     for (int j = 0; j < l; ++j) {                      // FK up to this link; joint values straight from the cubic
         float qj = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
         fk_advance(S, j, qj, T);
     }
-    int idx[SMR_MAX_PLANETS] = {0, 0};
-    const int upd = S.updates_per_step / N;
+    Sample r;
+    if (S.use_ball) {
+        Xf XB = ball_pose(S, ball, ball_k, nullptr);
+        const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
+        r = collide_link(S, l, T, nullptr, &XB, want_static, want_moving, want_contact && near);
+    } else {
+        int idx[SMR_MAX_PLANETS] = {0, 0};
 #pragma unroll
-    for (int p = 0; p < SMR_MAX_PLANETS; ++p)
-        if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
-    Sample r = collide_link(S, l, T, idx, want_dist, want_contact);
+        for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+            if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
+        r = collide_link(S, l, T, idx, nullptr, want_static, want_moving, want_contact);
+    }
     res[e] = r.contact ? 1.f : 0.f;
     if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(SMR_NLINK + l) * B + e] = r.d_moving; }
 }
@@ -79,8 +102,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     const int B = S.B, N = S.checks_per_step;
     const int steps = st.step_count[e] + 1;                                   // base.py:1044
     int hit = st.moving_hit[e];
-    if (S.term_moving && S.n_planets > 0)                                     // ctlp.py:2631-2637
-        for (int k = 0; k < N * SMR_NLINK; ++k) hit |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;
+    int contact = 0;
+    for (int k = 0; k < N * SMR_NLINK; ++k) contact |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;
+    if (S.term_moving && S.n_planets > 0) hit |= contact;                     // ctlp.py:2631-2637
     float d_static = S.static_max, d_self = S.static_max, d_moving = S.moving_max + 0.002f;
 #pragma unroll
     for (int l = 0; l < SMR_NLINK; ++l) {                                     // minimum over links, ctlp.py:3263-3278,3294-3320
@@ -109,7 +133,26 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     if (d_static < S.collision_dist) { d_static = 0.f; col_static = true; }
     if (d_self < S.collision_dist) { d_self = 0.f; col_self = true; }
     if (hit) d_moving = 0.f;                                                  // ctlp.py:3229-3234
-    if (S.n_planets == 0) d_moving = S.moving_max + 0.002f;
+    if (S.n_planets == 0 && !S.use_ball) d_moving = S.moving_max + 0.002f;
+    // ball bookkeeping (ctlp.py:2823-2861, 3217-3228): hit robot -> distance 0 and a new ball; passed the robot or
+    // reached table/ground -> a new ball; otherwise 24 more updates
+    BallState ball;
+    int ball_k = 0, ball_active = 0;
+    bool ball_respawn = false;
+    if (S.use_ball) {
+        ball = load_ball(st, B, e);
+        ball_k = st.ball_i[e];
+        ball_active = st.ball_i[3 * B + e];
+        if (ball_active) {
+            const int u_end = ball_retire_update(S, ball_k, st.ball_i[B + e], st.ball_i[2 * B + e]);
+            if (contact) { d_moving = 0.f; ball_active = 0; }
+            else if (u_end <= S.updates_per_step) { d_moving = S.moving_max + 0.002f; ball_active = 0; }
+            else ball_k += S.updates_per_step;
+        } else {
+            d_moving = S.moving_max + 0.002f;
+        }
+        ball_respawn = !ball_active;
+    }
     if (d_moving < S.collision_dist) { d_moving = 0.f; col_moving = true; }
     float r_self = 0.f, r_static = 0.f, r_moving;
     if (S.self_max_reward != 0.f) { float r = fminf(1.f, d_self / S.self_max_dist); r_self = r * r; }
@@ -157,33 +200,231 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     st.step_count[e] = steps;
     st.moving_hit[e] = hit;
 
+    if (S.use_ball) { st.ball_i[e] = ball_k; st.ball_i[3 * B + e] = ball_active; }
     if (d && S.auto_reset) {
         int slot = atomicAdd(st.done_count, 1);          // hipcc folds this into one atomic per wave
         st.done_list[slot] = e;
     } else {
-        write_observation(S, q, v, a, idx, obs + (size_t)e * S.obs_size);
+        float *row = obs + (size_t)e * S.obs_size;
+        write_observation(S, q, v, a, idx, row);
+        if (S.use_ball) {
+            if (ball_respawn) st.spawn_list[atomicAdd(st.spawn_count, 1)] = e;    // ball columns written by spawn_kernel
+            else write_ball_observation(S, ball, ball_k, row + 3 * SMR_NJ);
+        }
     }
 }
 
-// A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138, for one candidate q.
-// (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is outside the kinematic path.)
-__device__ inline bool position_is_valid(const DScene &S, const float q[SMR_NJ]) {
+// A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138, for one candidate q.  box / thr: cartesian
+// range of the end-effector point and minimum table distance (start states ctlp.py:172-183,1468-1477; ball
+// targets ctlp.py:191-229,1725-1726).  (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is outside
+// the kinematic path.)
+__device__ inline bool pose_is_valid(const DScene &S, const float q[SMR_NJ], const float box[3][2], float thr) {
     Xf T = fk_base(S), I = T;
     bool ok = true;
     for (int l = 0; l < SMR_NLINK; ++l) {
         if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
         if (ok && ((S.static_mask >> l) & 1u)) {
             for (int s = 0; s < S.n_static; ++s) {                                        // ctlp.py:2140-2168
-                float thr = S.start_min_static;
                 float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, 0.f);
                 if (d <= thr + 0.005f && d < thr) ok = false;
             }
         }
     }
     F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});                // ctlp.py:2051-2061
-    if (ee.x < S.start_box[0][0] || ee.x > S.start_box[0][1] || ee.y < S.start_box[1][0] || ee.y > S.start_box[1][1] ||
-        ee.z < S.start_box[2][0] || ee.z > S.start_box[2][1]) ok = false;
+    if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) ok = false;
     return ok;
+}
+
+__device__ inline bool position_is_valid(const DScene &S, const float q[SMR_NJ]) { return pose_is_valid(S, q, S.start_box, S.start_min_static); }
+
+// end-effector point in float64 (the ball is aimed at it; its launch arithmetic runs in float64 so that the
+// integer update counters derived from it agree with the oracle)
+__device__ inline void ee_point_f64(const DScene &S, const float q[SMR_NJ], double ee[3]) {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {S.base[0], S.base[1], S.base[2]};
+    for (int k = 0; k < SMR_NJ; ++k) {
+        double o[3] = {S.joint_xyz[k][0], S.joint_xyz[k][1], S.joint_xyz[k][2]};
+        for (int i = 0; i < 3; ++i) t[i] += R[3 * i] * o[0] + R[3 * i + 1] * o[1] + R[3 * i + 2] * o[2];
+        double ax = S.joint_axis[k][0], ay = S.joint_axis[k][1], az = S.joint_axis[k][2];
+        double c = cos((double)q[k]), s = sin((double)q[k]), C = 1 - c;
+        double J[9] = {c + ax * ax * C, ax * ay * C - az * s, ax * az * C + ay * s, ay * ax * C + az * s, c + ay * ay * C, ay * az * C - ax * s,
+                       az * ax * C - ay * s, az * ay * C + ax * s, c + az * az * C};
+        double n[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) n[3 * i + j] = R[3 * i] * J[j] + R[3 * i + 1] * J[3 + j] + R[3 * i + 2] * J[6 + j];
+        for (int i = 0; i < 9; ++i) R[i] = n[i];
+    }
+    for (int i = 0; i < 3; ++i) ee[i] = t[i] + R[3 * i] * S.ee_offset[0] + R[3 * i + 1] * S.ee_offset[1] + R[3 * i + 2] * S.ee_offset[2];
+}
+
+// Ball.get_target_height_time, ctlp.py:4346-4361
+__device__ inline double ball_height_time(double h0, double vz, double target, double udt, double *steps) {
+    const double g = 9.81;
+    double sq = vz * vz + 2 * g * (h0 - target), t = nan("");
+    if (steps) *steps = nan("");
+    if (sq >= 0) {
+        t = (vz + sqrt(sq)) / g;
+        if (t > 0) { if (steps) *steps = nearbyint(t / udt); }
+        else t = nan("");
+    }
+    return t;
+}
+
+struct BallSpawn { float p0[3], v0[3], e0[3], omega; int kmax, khit; };
+
+// _add_moving_object, ctlp.py:1723-1931, by a group of 8 lanes: 8 candidate target poses per round, first valid
+// one wins; the scalar launch arithmetic is computed redundantly by all lanes, in float64.
+__device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, int g, int gbase) {
+    auto gballot = [&](bool pred) -> unsigned { return (unsigned)((__ballot(pred) >> gbase) & 0xFFull); };
+    const double udt = S.dt64 / S.updates_per_step, v = S.ball_speed, grav = 9.81;
+    double rel[3] = {0, 0, 0}, vel[3] = {0, 0, 1};
+    unsigned pose_attempt = 0;
+    for (unsigned n = 0; n < 25000u; ++n) {
+        const double h = rng.uniformd(S_BALL_RELEASE, 3u * n, S.ball_height[0], S.ball_height[1]);       // ctlp.py:1943-1952
+        const double r = sqrt(S.ball_sphere_radius * S.ball_sphere_radius - h * h);
+        const double ang = rng.uniformd(S_BALL_RELEASE, 3u * n + 1u, S.ball_angle[0], S.ball_angle[1]);
+        rel[0] = S.ball_center[0] + r * cos(ang); rel[1] = S.ball_center[1] + r * sin(ang); rel[2] = S.ball_center[2] + h;
+        double target[3] = {0, 0, 0};
+        for (int round = 0; round < 3125; ++round) {                                                        // ctlp.py:1782-1790
+            const unsigned m = pose_attempt + (unsigned)g;
+            float q[SMR_NJ];
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S_BALL_POSE, 7u * m + j, S.pos_lo[j], S.pos_hi[j]);
+            const unsigned mask = gballot(pose_is_valid(S, q, S.ball_target_box, S.ball_target_min_static));
+            if (mask) {
+                const int f = __ffs((int)mask) - 1;
+#pragma unroll
+                for (int j = 0; j < SMR_NJ; ++j) q[j] = __shfl(q[j], gbase + f);
+                ee_point_f64(S, q, target);
+                pose_attempt += (unsigned)f + 1u;
+                break;
+            }
+            pose_attempt += 8u;
+        }
+        const double dx = target[0] - rel[0], dy = target[1] - rel[1], dh = target[2] - rel[2];
+        const double dxy = sqrt(dx * dx + dy * dy);
+        const double sq = v * v * v * v - grav * (grav * dxy * dxy + 2 * dh * v * v);                      // ctlp.py:1797
+        bool valid = sq >= 0;
+        if (valid) {
+            const bool high = rng.uniform01d(S_BALL_RELEASE, 3u * n + 2u) <= S.ball_high_prob;
+            const double theta = atan((v * v + (high ? 1.0 : -1.0) * sqrt(sq)) / (grav * dxy));
+            vel[2] = v * sin(theta);
+            vel[0] = v * cos(theta) * dx / dxy; vel[1] = v * cos(theta) * dy / dxy;
+            if (S.ball_check_invalid) {                                                                     // ctlp.py:1813-1848
+                const double tt = ball_height_time(rel[2], vel[2], S.ball_invalid_max[2] + (double)S.ball_radius, udt, nullptr);
+                const double tb = ball_height_time(rel[2], vel[2], S.ball_invalid_min[2] + (double)S.ball_radius, udt, nullptr);
+                bool in_top = false, in_bot = false;
+                if (tt == tt) { double x = rel[0] + vel[0] * tt, y = rel[1] + vel[1] * tt;
+                    in_top = S.ball_invalid_min[0] <= x && x <= S.ball_invalid_max[0] && S.ball_invalid_min[1] <= y && y <= S.ball_invalid_max[1]; }
+                if (tb == tb) { double x = rel[0] + vel[0] * tb, y = rel[1] + vel[1] * tb;
+                    in_bot = S.ball_invalid_min[0] <= x && x <= S.ball_invalid_max[0] && S.ball_invalid_min[1] <= y && y <= S.ball_invalid_max[1]; }
+                if (in_top || in_bot) valid = false;
+            }
+        }
+        if (valid) break;
+    }
+    BallSpawn out;
+    for (int c = 0; c < 3; ++c) { out.p0[c] = (float)rel[c]; out.v0[c] = (float)vel[c]; }
+    out.omega = (float)rng.uniformd(S_BALL_MISC, 0u, 0.0, 2.0 * 3.14159265358979323846);                   // ctlp.py:4056-4057
+    // initial orientation: rotation z -> direction, quaternion of its transpose, euler angles (ctlp.py:4029-4034,5389-5421)
+    {
+        const double nv = sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+        const double d0 = vel[0] / nv, d1 = vel[1] / nv, d2 = vel[2] / nv;
+        const double vx = -d1, vy = d0, c = d2, s2 = vx * vx + vy * vy;
+        const double K[3][3] = {{0, 0, vy}, {0, 0, -vx}, {-vy, vx, 0}};
+        double m[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double kk = 0;
+                for (int k = 0; k < 3; ++k) kk += K[i][k] * K[k][j];
+                m[j][i] = (i == j ? 1.0 : 0.0) + K[i][j] + kk * ((1 - c) / s2);       // transposed
+            }
+        double t, q[4];
+        if (m[2][2] < 0) {
+            if (m[0][0] > m[1][1]) { t = 1 + m[0][0] - m[1][1] - m[2][2]; q[0] = t; q[1] = m[0][1] + m[1][0]; q[2] = m[2][0] + m[0][2]; q[3] = m[1][2] - m[2][1]; }
+            else { t = 1 - m[0][0] + m[1][1] - m[2][2]; q[0] = m[0][1] + m[1][0]; q[1] = t; q[2] = m[1][2] + m[2][1]; q[3] = m[2][0] - m[0][2]; }
+        } else {
+            if (m[0][0] < -m[1][1]) { t = 1 - m[0][0] - m[1][1] + m[2][2]; q[0] = m[2][0] + m[0][2]; q[1] = m[1][2] + m[2][1]; q[2] = t; q[3] = m[0][1] - m[1][0]; }
+            else { t = 1 + m[0][0] + m[1][1] + m[2][2]; q[0] = m[1][2] - m[2][1]; q[1] = m[2][0] - m[0][2]; q[2] = m[0][1] - m[1][0]; q[3] = t; }
+        }
+        const double sc = 0.5 / sqrt(t);
+        const double x = q[0] * sc, y = q[1] * sc, z = q[2] * sc, w = q[3] * sc;
+        const double sarg = -2 * (x * z - w * y);                                          // pybullet.getEulerFromQuaternion
+        double e0, e1, e2;
+        if (sarg <= -0.99999) { e1 = -0.5 * 3.14159265358979323846; e0 = 0; e2 = 2 * atan2(x, -y); }
+        else if (sarg >= 0.99999) { e1 = 0.5 * 3.14159265358979323846; e0 = 0; e2 = 2 * atan2(-x, y); }
+        else { e0 = atan2(2 * (y * z + w * x), w * w - x * x - y * y + z * z); e1 = asin(sarg); e2 = atan2(2 * (x * y + w * z), w * w + x * x - y * y - z * z); }
+        out.e0[0] = (float)e0; out.e0[1] = (float)e1; out.e0[2] = (float)e2;
+    }
+    // Ball.get_final_ball_position, ctlp.py:4303-4344
+    double tf = nan("");
+    for (int i = 0; i < 2; ++i) {
+        const int a = (i + 1) % 3, b = (i + 2) % 3;
+        if (vel[i] == 0) continue;
+        for (int j = 0; j < 2; ++j) {
+            const double lim = j == 0 ? S.ball_final_min[i] : S.ball_final_max[i];
+            const double tt = (lim - rel[i]) / vel[i];
+            const double pa = rel[a] + vel[a] * tt, pb = rel[b] + vel[b] * tt;
+            if (S.ball_final_min[a] <= pa && pa <= S.ball_final_max[a] && S.ball_final_min[b] <= pb && pb <= S.ball_final_max[b])
+                if (!(tf == tf) || tt > tf) tf = tt;
+        }
+    }
+    const double tmin = ball_height_time(rel[2], vel[2], S.ball_final_min[2], udt, nullptr);
+    if (tmin == tmin && (!(tf == tf) || tmin < tf)) tf = tmin;
+    out.kmax = (tf == tf) ? (int)floor(tf / udt) : 0;                                                      // ctlp.py:4101
+    double steps;
+    const double tt = ball_height_time(rel[2], vel[2], (double)S.ball_radius, udt, &steps);               // ctlp.py:1889-1917
+    bool on_table = false;
+    if (S.n_static > 0 && tt == tt) {
+        const double x = rel[0] + vel[0] * tt, y = rel[1] + vel[1] * tt;
+        on_table = -S.table_half_xy[0] <= x && x <= S.table_half_xy[0] && -S.table_half_xy[1] <= y && y <= S.table_half_xy[1];
+    }
+    if (!on_table) ball_height_time(rel[2], vel[2], S.plane_z + (double)S.ball_radius, udt, &steps);
+    out.khit = (steps == steps) ? (int)steps - 1 : 0x7fffffff;
+    return out;
+}
+
+__device__ inline void store_ball(const DState &st, int B, int e, const BallSpawn &b, int k, unsigned spawns) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { st.ball[c * B + e] = b.p0[c]; st.ball[(3 + c) * B + e] = b.v0[c]; st.ball[(6 + c) * B + e] = b.e0[c]; }
+    st.ball[9 * B + e] = b.omega;
+    st.ball_i[e] = k; st.ball_i[B + e] = b.kmax; st.ball_i[2 * B + e] = b.khit; st.ball_i[3 * B + e] = 1; st.ball_i[4 * B + e] = (int)spawns;
+}
+
+// is the ball (pose XB) within Bullet's contact distance of any robot link? (Ball.check_if_object_is_colliding, ctlp.py:4186-4194)
+__device__ inline bool ball_contact_all_links(const DScene &S, const float q[SMR_NJ], const Xf &XB) {
+    Xf T = fk_base(S);
+    bool contact = false;
+    for (int l = 0; l < SMR_NLINK; ++l) {
+        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
+        if (!contact && ((S.contact_mask >> l) & 1u)) {
+            float d = piece_distance<false>(S, S.ball_piece, XB, S.link_piece[l], T, S.contact_dist, S.contact_dist);
+            if (d <= S.contact_dist) contact = true;
+        }
+    }
+    return contact;
+}
+
+// a new ball for the envs whose ball was retired in this step (get_moving_object_observation, ctlp.py:2354-2360)
+__global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp, DState st, int group_stride, float *__restrict__ obs) {
+    const DScene &S = *Sp;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int grp = t >> 3, g = t & 7;
+    if (grp % group_stride) return;
+    const int i = grp / group_stride;
+    if (i >= *st.spawn_count) return;
+    const int e = st.spawn_list[i];
+    const int B = S.B;
+    const int gbase = (threadIdx.x & 63) & ~7;
+    const unsigned spawns = (unsigned)st.ball_i[4 * B + e];
+    const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
+    const BallSpawn b = spawn_ball_group(S, rng, g, gbase);
+    if (g == 0) {
+        store_ball(st, B, e, b, 0, spawns + 1u);
+        BallState bs;
+        for (int c = 0; c < 3; ++c) { bs.p0[c] = b.p0[c]; bs.v0[c] = b.v0[c]; bs.e0[c] = b.e0[c]; }
+        bs.omega = b.omega;
+        if (obs) write_ball_observation(S, bs, 0, obs + (size_t)e * S.obs_size + 3 * SMR_NJ);
+    }
 }
 
 // table clearance of a configuration (ctlp.py:1605-1619; self-collision: no pairs for one iiwa)
@@ -345,6 +586,32 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         }
     }
 
+    // ---- ball: spawn + random initial time step, 8 candidate steps per round (ctlp.py:1052-1111)
+    BallSpawn bsp;
+    int ball_k0 = 0;
+    unsigned ball_spawns = 0;
+    if (S.use_ball) {
+        ball_spawns = (unsigned)st.ball_i[4 * B + e];
+        const Rng brng = {S.seed_lo, S.seed_hi, (unsigned)e, ball_spawns};
+        bsp = spawn_ball_group(S, brng, g, gbase);
+        if (S.ball_random_initial) {
+            BallState bs;
+            for (int c = 0; c < 3; ++c) { bs.p0[c] = bsp.p0[c]; bs.v0[c] = bsp.v0[c]; bs.e0[c] = bsp.e0[c]; }
+            bs.omega = bsp.omega;
+            int kcap = bsp.kmax < bsp.khit ? bsp.kmax : bsp.khit;
+            int max_ts = kcap / S.updates_per_step;
+            if (max_ts < 0) max_ts = 0;
+            unsigned base = 0;
+            for (int round = 0; round < 12500; ++round) {
+                const int kc = brng.randint(S_BALL_MISC, 1u + base + (unsigned)g, max_ts + 1) * S.updates_per_step;
+                const Xf XB = ball_pose(S, bs, kc, nullptr);
+                const unsigned m = gballot(!ball_contact_all_links(S, q, XB));
+                if (m) { ball_k0 = __shfl(kc, gbase + __ffs((int)m) - 1); break; }
+                base += 8u;
+            }
+        }
+    }
+
     // ---- write back: lane j < 7 owns joint j, lane 7 the scalars
     float *row = obs ? obs + (size_t)e * S.obs_size : nullptr;
     if (g < SMR_NJ) {
@@ -361,6 +628,13 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         st.moving_hit[e] = hit;
         st.reset_count[e] = rng.tag + 1u;
         if (row) write_planet_observation(S, idx, row + 3 * SMR_NJ);
+        if (S.use_ball) {
+            store_ball(st, B, e, bsp, ball_k0, ball_spawns + 1u);
+            BallState bs;
+            for (int c = 0; c < 3; ++c) { bs.p0[c] = bsp.p0[c]; bs.v0[c] = bsp.v0[c]; bs.e0[c] = bsp.e0[c]; }
+            bs.omega = bsp.omega;
+            if (row) write_ball_observation(S, bs, ball_k0, row + 3 * SMR_NJ);
+        }
     }
 }
 
@@ -379,6 +653,7 @@ __global__ void observe_kernel(const DScene *__restrict__ Sp, DState st, float *
     for (int j = 0; j < SMR_NJ; ++j) { q[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; a[j] = st.a[j * B + e]; }
     int idx[SMR_MAX_PLANETS] = {st.planet_idx[e], st.planet_idx[B + e]};
     write_observation(S, q, v, a, idx, obs + (size_t)e * S.obs_size);
+    if (S.use_ball) write_ball_observation(S, load_ball(st, B, e), st.ball_i[e], obs + (size_t)e * S.obs_size + 3 * SMR_NJ);
 }
 
 // ---- component kernels for the parity tests ----
@@ -419,6 +694,27 @@ __global__ void test_distances_kernel(const DScene *__restrict__ Sp, const float
     out[4 * i] = d.d_static; out[4 * i + 1] = S.static_max; out[4 * i + 2] = d.d_moving; out[4 * i + 3] = c.contact ? 1.f : 0.f;
 }
 
+__global__ void test_ball_distances_kernel(const DScene *__restrict__ Sp, const float *__restrict__ q, const float *__restrict__ ball,
+                                           const int *__restrict__ kk, int n, float *__restrict__ out) {
+    const DScene &S = *Sp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BallState b;
+    for (int c = 0; c < 3; ++c) { b.p0[c] = ball[10 * i + c]; b.v0[c] = ball[10 * i + 3 + c]; b.e0[c] = ball[10 * i + 6 + c]; }
+    b.omega = ball[10 * i + 9];
+    const Xf XB = ball_pose(S, b, kk[i], nullptr);
+    float dst = S.static_max, dmv = S.moving_max + 0.002f;
+    bool contact = false;
+    Xf T = fk_base(S);
+    for (int l = 0; l < SMR_NLINK; ++l) {
+        if (l > 0) fk_advance(S, l - 1, q[i * SMR_NJ + l - 1], T);
+        Sample d = collide_link(S, l, T, nullptr, &XB, true, true, false);
+        Sample c = collide_link(S, l, T, nullptr, &XB, false, false, true);
+        dst = fminf(dst, d.d_static); dmv = fminf(dmv, d.d_moving); contact = contact || c.contact;
+    }
+    out[4 * i] = dst; out[4 * i + 1] = S.static_max; out[4 * i + 2] = dmv; out[4 * i + 3] = contact ? 1.f : 0.f;
+}
+
 }  // namespace smr
 
 // ---------------------------------------------------------------------------------------------
@@ -442,8 +738,8 @@ struct smr_env {
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[SMR_K_COUNT] = {0, 0, 0, 0};
-    int64_t prof_n[SMR_K_COUNT] = {0, 0, 0, 0};
+    double prof_ms[SMR_K_COUNT] = {};
+    int64_t prof_n[SMR_K_COUNT] = {};
 };
 
 static thread_local std::string g_create_error;
@@ -551,6 +847,23 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
         q.orbit_pose = dpose; q.orbit_local = dlocal;
     }
     copy3(d.planet_obs_min, s.planet_obs_pos_min); copy3(d.planet_obs_max, s.planet_obs_pos_max);
+    d.use_ball = s.use_ball; d.dt64 = s.dt;
+    if (s.use_ball) {
+        if (!piece_ok(s.ball_piece)) { env->err = "bad ball_piece"; return SMR_E_INVALID; }
+        d.ball_piece = s.ball_piece; d.ball_check_invalid = s.ball_check_invalid_target; d.ball_random_initial = s.ball_random_initial_position;
+        d.ball_radius = (float)s.ball_radius; d.ball_active_xy_radius = (float)s.ball_active_xy_radius;
+        copy3(d.ball_obs_pos_min, s.ball_obs_pos_min); copy3(d.ball_obs_pos_max, s.ball_obs_pos_max);
+        copy3(d.ball_obs_vel_min, s.ball_obs_vel_min); copy3(d.ball_obs_vel_max, s.ball_obs_vel_max);
+        for (int c = 0; c < 3; ++c) {
+            d.ball_target_box[c][0] = (float)s.ball_target_box[c][0]; d.ball_target_box[c][1] = (float)s.ball_target_box[c][1];
+            d.ball_center[c] = s.ball_sphere_center[c]; d.ball_invalid_min[c] = s.ball_invalid_min[c]; d.ball_invalid_max[c] = s.ball_invalid_max[c];
+            d.ball_final_min[c] = s.ball_final_min[c]; d.ball_final_max[c] = s.ball_final_max[c];
+        }
+        d.ball_target_min_static = (float)s.ball_target_min_dist_static; d.ball_speed = s.ball_speed; d.ball_sphere_radius = s.ball_sphere_radius;
+        d.ball_height[0] = s.ball_sphere_height[0]; d.ball_height[1] = s.ball_sphere_height[1];
+        d.ball_angle[0] = s.ball_sphere_angle[0]; d.ball_angle[1] = s.ball_sphere_angle[1]; d.ball_high_prob = s.ball_high_angle_prob;
+        d.plane_z = s.plane_z; d.table_half_xy[0] = s.table_half_xy[0]; d.table_half_xy[1] = s.table_half_xy[1];
+    }
     d.punish_action = s.punish_action; d.term_self = s.terminate_on_self_collision; d.term_static = s.terminate_on_static_collision;
     d.term_moving = s.terminate_on_moving_collision;
     d.action_thr = (float)s.action_punishment_min_threshold; d.action_max_pun = (float)s.action_max_punishment;
@@ -578,9 +891,9 @@ static int check_scene(const smr_scene_t *s, int32_t num_envs, std::string &err)
     if (s->collision_checks_per_step <= 0 || s->updates_per_step <= 0 || s->updates_per_step % s->collision_checks_per_step) {
         err = "collision_checks_per_step must divide updates_per_step"; return SMR_E_INVALID;
     }
-    if (s->use_ball) { err = "ball scene not available in this build"; return SMR_E_INVALID; }
+    if (s->use_ball && s->n_planets > 0) { err = "ball and planets in one scene are not supported"; return SMR_E_INVALID; }
     if (!s->verts || !s->pieces || s->n_verts <= 0 || s->n_pieces <= 0) { err = "scene has no geometry"; return SMR_E_INVALID; }
-    int expect = 3 * SMR_NJ + s->obs_num_planets * s->obs_planet_size_per_planet;
+    int expect = 3 * SMR_NJ + s->obs_num_planets * s->obs_planet_size_per_planet + (s->use_ball ? 6 : 0);
     if (s->obs_size != expect) { err = "obs_size does not match the scene"; return SMR_E_INVALID; }
     if (!(s->dt > 0) || s->episode_steps <= 0) { err = "bad time parameters"; return SMR_E_INVALID; }
     return SMR_OK;
@@ -627,9 +940,10 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
         (rc = dev_alloc(env, &st.res, (size_t)env->N * SMR_NLINK * B)) || (rc = dev_alloc(env, &st.dist, 2 * SMR_NLINK * B)) ||
-        (rc = dev_alloc(env, &st.done_list, B)) ||
-        (rc = dev_alloc(env, &st.done_count, 1)))
+        (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
+        (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &st.spawn_list, B)) || (rc = dev_alloc(env, &st.spawn_count, 1)))
         return fail(rc);
+    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(st.spawn_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
@@ -742,6 +1056,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipSetDevice(env->device));
     const int B = env->B;
     if (env->auto_reset) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));
+    if (env->hscene.use_ball) SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
     {
         LaunchTimer t(env, SMR_K_PLAN);
         hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
@@ -758,6 +1073,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
                            reward_dev, done_dev, reason_dev, info_dev);
     }
     SMR_HIP(hipGetLastError());
+    if (env->hscene.use_ball) {
+        LaunchTimer t(env, SMR_K_SPAWN);
+        hipLaunchKernelGGL(spawn_kernel, dim3(((size_t)B * 8 * kResetGroupStride + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+                           kResetGroupStride, obs_dev);
+        SMR_HIP(hipGetLastError());
+    }
     if (env->auto_reset) return launch_reset_list(env, obs_dev);
     return SMR_OK;
 }
@@ -784,7 +1105,8 @@ int smr_get_state(smr_env_t *env, const smr_host_state_t *h) {
     int rc;
     if ((rc = state_get(env, h->q, env->st.q, 7)) || (rc = state_get(env, h->v, env->st.v, 7)) || (rc = state_get(env, h->a, env->st.a, 7)) ||
         (rc = state_get(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_get(env, h->step_count, env->st.step_count, 1)) ||
-        (rc = state_get(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_get(env, h->reset_count, env->st.reset_count, 1)))
+        (rc = state_get(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_get(env, h->reset_count, env->st.reset_count, 1)) ||
+        (rc = state_get(env, h->ball, env->st.ball, 10)) || (rc = state_get(env, h->ball_i, env->st.ball_i, 5)))
         return rc;
     return SMR_OK;
 }
@@ -802,7 +1124,8 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     int rc;
     if ((rc = state_set(env, h->q, env->st.q, 7)) || (rc = state_set(env, h->v, env->st.v, 7)) || (rc = state_set(env, h->a, env->st.a, 7)) ||
         (rc = state_set(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_set(env, h->step_count, env->st.step_count, 1)) ||
-        (rc = state_set(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_set(env, h->reset_count, env->st.reset_count, 1)))
+        (rc = state_set(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_set(env, h->reset_count, env->st.reset_count, 1)) ||
+        (rc = state_set(env, h->ball, env->st.ball, 10)) || (rc = state_set(env, h->ball_i, env->st.ball_i, 5)))
         return rc;
     SMR_HIP(hipDeviceSynchronize());
     return SMR_OK;
@@ -874,6 +1197,21 @@ int smr_test_distances(smr_env_t *env, const float *q_host, const int32_t *plane
     int *idx = t.up(planet_idx_host, (size_t)n * 2);
     if (!q || !o || !idx) { env->err = "smr_test_distances: allocation failed"; return SMR_E_HIP; }
     hipLaunchKernelGGL(test_distances_kernel, dim3((n + 63) / 64), dim3(64), 0, env->stream, env->dscene, q, idx, n, o);
+    SMR_HIP(hipGetLastError());
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    SMR_HIP(hipMemcpy(out, o, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_test_ball_distances(smr_env_t *env, const float *q_host, const float *ball_host, const int32_t *k_host, int32_t n, float *out) {
+    if (!env || !q_host || !ball_host || !k_host || n <= 0 || !out) return SMR_E_INVALID;
+    if (!env->hscene.use_ball) { env->err = "smr_test_ball_distances: not a ball scene"; return SMR_E_INVALID; }
+    SMR_HIP(hipSetDevice(env->device));
+    TmpBuf t{env, {}};
+    float *q = t.up(q_host, (size_t)n * 7), *b = t.up(ball_host, (size_t)n * 10), *o = t.up<float>(nullptr, (size_t)n * 4);
+    int *k = t.up(k_host, (size_t)n);
+    if (!q || !b || !o || !k) { env->err = "smr_test_ball_distances: allocation failed"; return SMR_E_HIP; }
+    hipLaunchKernelGGL(test_ball_distances_kernel, dim3((n + 63) / 64), dim3(64), 0, env->stream, env->dscene, q, b, k, n, o);
     SMR_HIP(hipGetLastError());
     SMR_HIP(hipStreamSynchronize(env->stream));
     SMR_HIP(hipMemcpy(out, o, (size_t)n * 16, hipMemcpyDeviceToHost));

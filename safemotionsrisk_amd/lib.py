@@ -16,21 +16,22 @@ LIB_PATH = os.path.join(_PKG, "libsmr_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 INFO_N = 8
-K_COUNT = 4
-KERNEL_NAMES = ("plan", "collide", "finish", "reset")
+K_COUNT = 5
+KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn")
 
 #: every symbol include/safemotions_hip.h declares
 EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "smr_last_error", "smr_num_envs",
            "smr_obs_size", "smr_reset", "smr_step", "smr_observe", "smr_get_state", "smr_set_state",
            "smr_synchronize", "smr_set_profiling", "smr_get_profile", "smr_test_fk", "smr_test_safe_acc_range",
-           "smr_test_distances")
+           "smr_test_distances", "smr_test_ball_distances")
 
 
 class HostState(C.Structure):
     _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("a", C.c_void_p), ("planet_idx", C.c_void_p),
-                ("step_count", C.c_void_p), ("moving_hit", C.c_void_p), ("reset_count", C.c_void_p)]
+                ("step_count", C.c_void_p), ("moving_hit", C.c_void_p), ("reset_count", C.c_void_p),
+                ("ball", C.c_void_p), ("ball_i", C.c_void_p)]
 
 
 def _sources():
@@ -83,6 +84,7 @@ def load():
     L.smr_test_safe_acc_range.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
     L.smr_test_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.smr_test_ball_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     if L.smr_abi_version() != ABI_VERSION:
         raise RuntimeError("libsmr_hip.so ABI %d != binding ABI %d" % (L.smr_abi_version(), ABI_VERSION))
     if L.smr_scene_sizeof() != C.sizeof(Scene):

@@ -273,6 +273,65 @@ def _bounding_sphere(v):
     return c, float(np.linalg.norm(v - c, axis=1).max())
 
 
+def ball_target_height_time(initial_height, initial_z_speed, target_height, g=9.81):
+    """Ball.get_target_height_time (ctlp.py:4346-4361), continuous time only."""
+    sq = initial_z_speed ** 2 + 2 * g * (initial_height - target_height)
+    if sq < 0:
+        return float("nan")
+    t = (initial_z_speed + np.sqrt(sq)) / g
+    return t if t > 0 else float("nan")
+
+
+def _build_ball(config, s, assets, add_piece):
+    """Ball scene constants: scene.py:226-257,600, ctlp.py:288-348,706-710,1723-1954."""
+    center = config.get("moving_object_sphere_center")
+    if center is None:
+        raise NotImplementedError("use_moving_objects without moving_object_sphere_center (planar release area)")
+    radius = float(config.get("moving_object_sphere_radius") or 5.0)                     # scene.py:247-249
+    h = config.get("moving_object_sphere_height_min_max") or [-0.1 * radius, 0.1 * radius]
+    ang = config.get("moving_object_sphere_angle_min_max") or [0.0, 2 * np.pi]
+    speed = float(_cfg(config, "moving_object_speed_meter_per_second"))
+    ball_radius = 0.038                                                                  # scene.py:600
+    s.use_ball = 1
+    s.ball_radius, s.ball_speed, s.ball_sphere_radius = ball_radius, speed, radius
+    s.ball_piece = add_piece(assets["ball_verts"] * (ball_radius / 0.12))               # ctlp.py:4043-4044 globalScaling
+    s.moving_link_mask = _link_mask(["iiwa_link_%d" % i for i in range(2, 8)])          # scene.py:226-228
+    for c in range(3):
+        s.ball_sphere_center[c] = center[c]
+    s.ball_sphere_height[0], s.ball_sphere_height[1] = h
+    s.ball_sphere_angle[0], s.ball_sphere_angle[1] = ang
+    s.ball_high_angle_prob = 1.0                                                         # scene.py:76
+    s.ball_check_invalid_target = int(bool(_cfg(config, "moving_object_check_invalid_target_link_point_positions")))
+    s.ball_random_initial_position = int(bool(_cfg(config, "moving_object_random_initial_position")))
+    for c, (a, b) in enumerate([[-0.4, 0.0], [-0.2, 0.2], [0.0, 0.5]]):                  # ctlp.py:706-710
+        s.ball_invalid_min[c], s.ball_invalid_max[c] = a, b
+    final = [[-1.0, 1.0], [-1.3, 1.3], [-0.3, 1.5]]                                      # ctlp.py:304-308
+    for c in range(3):
+        s.ball_final_min[c], s.ball_final_max[c] = final[c]
+    # observation ranges, ctlp.py:309-348
+    max_initial_height = center[2] + h[1]
+    t_up = speed / 9.81
+    max_height = max_initial_height + speed * t_up - 0.5 * 9.81 * t_up ** 2
+    pos_rng = [[-(center[0] + radius), center[0] + radius], [-(center[1] + radius), center[1] + radius],
+               [final[2][0], max_height]]
+    zero_t = ball_target_height_time(max_initial_height, -speed, ball_radius)
+    min_speed = -speed - 9.81 * zero_t
+    vel_rng = [[-speed, speed], [-speed, speed], [min_speed, -min_speed]]
+    for c in range(3):
+        s.ball_obs_pos_min[c], s.ball_obs_pos_max[c] = pos_rng[c]
+        s.ball_obs_vel_min[c], s.ball_obs_vel_max[c] = vel_rng[c]
+    s.ball_active_xy_radius = 1.25                                                       # ctlp.py:2830
+    tbox = {0: [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]], 1: [[-0.6, 0.6], [-0.3, 0.3], [0.1, 1]],
+            2: [[-0.4, 0.4], [-0.4, 0.4], [0.1, 1]], 3: [[-0.2, 0.8], [-0.9, 0.9], [0.3, 1.45]],
+            4: [[-0.8, 0.8], [-0.9, 0.9], [0.3, 1.45]], 5: [[-0.1, 0.8], [-0.9, 0.9], [0.3, 1.45]],
+            6: [[-0.1, 0.8], [-1.0, 1.0], [0.15, 1.65]], 7: [[-0.1, 0.75], [-0.8, 0.8], [1.0, 1.65]],
+            8: [[-1.0, 1.0], [-1.0, 1.0], [-0.7, 1.3]], 10: [[-0.1, 0.6], [-0.8, 0.8], [0.1, 1]]
+            }.get(_cfg(config, "target_point_cartesian_range_scene"), [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]])  # ctlp.py:191-229
+    for c in range(3):
+        s.ball_target_box[c][0], s.ball_target_box[c][1] = tbox[c]
+    s.ball_target_min_dist_static = float(_cfg(config, "closest_point_safety_distance")) + 0.09   # ctlp.py:1725-1726
+
+
 class SceneBundle:
     """Owns the numpy buffers the ``smr_scene_t`` points into."""
 
@@ -469,7 +528,8 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
         for c, (a, bb) in enumerate([[-0.9, 0.7], [-0.85, 0.85], [0.45, 1.2]]):          # scene.py:283-284
             s.planet_obs_pos_min[c], s.planet_obs_pos_max[c] = a, bb
     elif config.get("use_moving_objects"):
-        raise NotImplementedError("ball scene (use_moving_objects) is not wired yet")
+        _build_ball(config, s, assets, add_piece)
+        obs_size += 6                                                                    # obs.py:79-91 (one robot, sequence 0)
     else:
         s.moving_link_mask = 0
 
