@@ -1,0 +1,43 @@
+"""Generates tests/golden/ball_step.npz (ball scene, BASELINE configs[3]) from the float64 oracle; see make_golden.py."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle.oracle import OracleEnv                                  # noqa: E402
+from safemotionsrisk_amd.scene import BALL_ENV_CONFIG, build_scene   # noqa: E402
+
+
+def main():
+    B, T = 256, 8
+    scene = build_scene(BALL_ENV_CONFIG, auto_reset=False)
+    env = OracleEnv(scene, B, seed=17, num_threads=4)
+    env.reset()
+    st = env.get_state()
+    rng = np.random.default_rng(4)
+    st["step_count"] = rng.integers(0, 20, B).astype(np.int32)
+    f32 = lambda x: x.astype(np.float32)
+    out = dict(B=B, T=T, seed=17, q0=f32(st["q"]), v0=f32(st["v"]), a0=f32(st["a"]), step_count0=st["step_count"],
+               ball0=f32(st["ball"]), ball_i0=st["ball_i"])
+    env.set_state(q=out["q0"], v=out["v0"], a=out["a0"], step_count=out["step_count0"], ball=out["ball0"], ball_i=out["ball_i0"])
+    actions = rng.uniform(-1, 1, (T, B, 7)).astype(np.float32)
+    rec = {k: [] for k in ("obs", "reward", "done", "reason", "info", "state", "ball", "ball_i")}
+    for t in range(T):
+        o, r, d, rs, inf = env.step(actions[t].astype(np.float64))
+        st = env.get_state()
+        rec["obs"].append(o); rec["reward"].append(r); rec["done"].append(d); rec["reason"].append(rs); rec["info"].append(inf)
+        rec["state"].append(np.concatenate([st["q"], st["v"], st["a"]], axis=1)); rec["ball"].append(st["ball"]); rec["ball_i"].append(st["ball_i"])
+        env.set_state(q=f32(st["q"]), v=f32(st["v"]), a=f32(st["a"]), ball=f32(st["ball"]),
+                      step_count=np.where(d, 0, st["step_count"]))
+    out.update(actions=actions, **{k: np.array(v) for k, v in rec.items()})
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ball_step.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes; done", out["done"].mean(), "reasons", np.unique(out["reason"]),
+          "spawns", (out["ball_i"][-1][:, 4] - out["ball_i0"][:, 4]).sum())
+
+
+if __name__ == "__main__":
+    main()

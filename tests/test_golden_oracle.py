@@ -33,3 +33,19 @@ def test_oracle_reproduces_golden_components(built, space_scene):
         assert np.allclose(env.fk(g["comp_q"][i].astype(np.float64))[0], g["comp_fk"][i], atol=1e-14)
         lo, hi, code = env.safe_acc_range(*[g[k][i].astype(np.float64) for k in ("comp_p", "comp_v", "comp_a")])
         assert np.allclose(lo, g["comp_lo"][i]) and np.allclose(hi, g["comp_hi"][i]) and np.array_equal(code, g["comp_code"][i])
+
+
+def test_oracle_reproduces_golden_ball_vectors(built):
+    from safemotionsrisk_amd.scene import BALL_ENV_CONFIG, build_scene
+    g = np.load(os.path.join(os.path.dirname(GOLD), "ball_step.npz"))
+    B, T = int(g["B"]), int(g["T"])
+    env = OracleEnv(build_scene(BALL_ENV_CONFIG, auto_reset=False), B, seed=int(g["seed"]), num_threads=4)
+    env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], step_count=g["step_count0"], moving_hit=0, ball=g["ball0"], ball_i=g["ball_i0"])
+    f32 = lambda x: x.astype(np.float32)
+    for t in range(T):
+        o, r, d, rs, inf = env.step(g["actions"][t].astype(np.float64))
+        st = env.get_state()
+        assert np.array_equal(d, g["done"][t]) and np.array_equal(rs, g["reason"][t]) and np.array_equal(st["ball_i"], g["ball_i"][t])
+        assert np.allclose(o, g["obs"][t], atol=1e-7) and np.allclose(r, g["reward"][t], atol=1e-12)
+        env.set_state(q=f32(st["q"]), v=f32(st["v"]), a=f32(st["a"]), ball=f32(st["ball"]), step_count=np.where(d, 0, st["step_count"]))
+    assert set(np.unique(g["reason"])) >= {-1, 2, 5}

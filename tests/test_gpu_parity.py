@@ -43,7 +43,7 @@ def test_native_library_is_loaded(built):
     from safemotionsrisk_amd import lib
     L = lib.load()
     maps = open("/proc/self/maps").read()
-    assert "libsmr_hip.so" in maps and L.smr_abi_version() == 1
+    assert "libsmr_hip.so" in maps and L.smr_abi_version() == lib.ABI_VERSION
 
 
 def test_components_against_golden(built):
@@ -248,4 +248,126 @@ def test_profiling_counters(built):
     prof = env.get_profile()
     assert all(prof[k]["launches"] == 5 for k in ("plan", "collide", "finish", "reset"))
     assert prof["collide"]["ms"] > 0
+    env.close()
+
+
+# ------------------------------------------------------------------ ball scene (A10, BASELINE configs[3])
+def _ball_env(B, **kw):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from safemotionsrisk_amd import VecSafeMotionsEnv, BALL_ENV_CONFIG
+    kw.setdefault("auto_reset", False)
+    return VecSafeMotionsEnv(B, device=0, **kw, **BALL_ENV_CONFIG)
+
+
+BALL_OBS_TOL = np.concatenate([np.full(7, 2e-6), np.full(7, 1e-5), np.full(7, 2e-5), np.full(6, 5e-6)])
+
+
+def test_ball_components_against_oracle(built):
+    from oracle.oracle import OracleEnv
+    env = _ball_env(512, seed=2)
+    ora = OracleEnv(env.scene, 1)
+    rng = np.random.default_rng(0)
+    q = rng.uniform(-1.8, 1.8, (512, 7)).astype(np.float32)
+    pos, _ = env.test_fk(q)
+    ball = np.zeros((512, 10), np.float32)
+    ball[:, :3] = pos[np.arange(512), rng.integers(3, 8, 512)] + rng.normal(size=(512, 3)) * rng.choice([0.02, 0.1, 0.3], (512, 1))
+    ball[:, 3:6] = rng.normal(size=(512, 3)); ball[:, 6:9] = rng.uniform(-3, 3, (512, 3)); ball[:, 9] = rng.uniform(0, 6.28, 512)
+    k = rng.integers(0, 12, 512).astype(np.int32)
+    d = env.test_ball_distances(q, ball, k)
+    od = np.array([ora.ball_distances(q[i].astype(np.float64), ball[i].astype(np.float64), k[i]) for i in range(512)])
+    clamp = lambda x: np.where(x < 0.001, 0.0, x)
+    near = (np.abs(od[:, 0] - 0.001) < TIE) | (np.abs(od[:, 2] - 0.001) < TIE)
+    assert np.abs(clamp(d[:, 0]) - clamp(od[:, 0]))[~near].max() < 5e-6
+    assert np.abs(clamp(d[:, 2]) - clamp(od[:, 2]))[~near].max() < 5e-6
+    safe = np.abs(od[:, 2] - 0.02) > TIE
+    assert np.array_equal(d[safe, 3], od[safe, 3]) and od[:, 3].sum() > 20
+    env.close()
+
+
+def test_ball_step_against_golden(built):
+    import torch
+    g = np.load(os.path.join(os.path.dirname(GOLD), "ball_step.npz"))
+    B, T = int(g["B"]), int(g["T"])
+    env = _ball_env(B, seed=int(g["seed"]))
+    env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], step_count=g["step_count0"], moving_hit=0, ball=g["ball0"], ball_i=g["ball_i0"])
+    for t in range(T):
+        obs, rew, done, info = env.step(torch.from_numpy(g["actions"][t]).cuda())
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        reason = info["termination_reason"].cpu().numpy()
+        vals = info["values"].cpu().numpy()
+        st = env.get_state()
+        gi = g["info"][t]
+        tie = (np.abs(gi[:, 0] - 0.001) < TIE) | (np.abs(gi[:, 2] - 0.001) < TIE) | (np.abs(gi[:, 2] - 0.02) < TIE)
+        ok = ~tie
+        assert np.array_equal(done[ok], g["done"][t][ok]) and np.array_equal(reason[ok], g["reason"][t][ok])
+        assert np.array_equal(st["ball_i"][ok], g["ball_i"][t][ok])                # counters, active flag, spawn count: exact
+        assert (np.abs(obs[ok] - g["obs"][t][ok]) < BALL_OBS_TOL).all()
+        assert np.abs(rew[ok] - g["reward"][t][ok]).max() < 5e-5
+        assert np.abs(vals[ok, :3] - gi[ok, :3]).max() < 5e-6
+        assert np.abs(st["ball"] - g["ball"][t])[ok].max() < 2e-5                  # new balls: same launch state
+        gs = g["state"][t]
+        env.set_state(q=gs[:, :7].astype(np.float32), v=gs[:, 7:14].astype(np.float32), a=gs[:, 14:].astype(np.float32),
+                      ball=g["ball"][t].astype(np.float32), ball_i=g["ball_i"][t], step_count=np.where(g["done"][t], 0, st["step_count"]))
+    env.close()
+
+
+def test_ball_rollout_and_reset_against_oracle(built):
+    import torch
+    from oracle.oracle import OracleEnv
+    B, T = 4096, 16
+    env = _ball_env(B, seed=5)
+    obs0 = env.reset().cpu().numpy()
+    ora = OracleEnv(env.scene, B, seed=5, num_threads=16)
+    o_obs0 = ora.reset()
+    st, ost = env.get_state(), ora.get_state()
+    same = (np.abs(ost["q"] - st["q"]).max(axis=1) < 1e-3) & (ost["ball_i"] == st["ball_i"]).all(axis=1)
+    assert same.mean() > 0.97                                                      # same Philox streams -> same start states and balls
+    assert np.abs(ost["ball"] - st["ball"])[same].max() < 2e-5
+    keys = env.STATE_KEYS
+    rng = np.random.default_rng(9)
+    mism, spawned, hits = 0, 0, 0
+    for t in range(T):
+        st = env.get_state()
+        ora.set_state(**{k: st[k] for k in keys})
+        act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        o_obs, o_rew, o_done, o_reason, o_info = ora.step(act.astype(np.float64))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        reason = info["termination_reason"].cpu().numpy()
+        st1, ost1 = env.get_state(), ora.get_state()
+        good = (done == o_done) & (reason == o_reason) & (st1["ball_i"] == ost1["ball_i"]).all(axis=1)
+        tie = (np.abs(o_info[:, 0] - 0.001) < TIE) | (np.abs(o_info[:, 2] - 0.001) < TIE) | (np.abs(o_info[:, 2] - 0.02) < TIE)
+        mism += int((~good & ~tie).sum())
+        assert (np.abs(obs[good] - o_obs[good]) < BALL_OBS_TOL).all()
+        assert np.abs(rew[good] - o_rew[good]).max() < 5e-5
+        spawned += int((st1["ball_i"][:, 4] != st["ball_i"][:, 4]).sum())
+        hits += int((o_reason == 5).sum())
+        if done.any():
+            env.reset(mask=torch.from_numpy(done).cuda())
+    assert mism <= 2, "%d unexplained mismatches" % mism                           # contact ties inside a step are not excluded here
+    assert spawned > B and hits > 50
+    env.close()
+
+
+def test_ball_full_size_invariants(built):
+    import torch
+    B, T = 65536, 30
+    env = _ball_env(B, seed=3, auto_reset=True)
+    env.reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    reasons = set()
+    for t in range(T):
+        obs, rew, done, info = env.step(torch.rand((B, 7), device="cuda", generator=gen) * 2 - 1)
+        assert float(obs.abs().max()) <= 1.0
+        r = info["termination_reason"].cpu().numpy()
+        d = done.cpu().numpy().astype(bool)
+        assert (r[~d] == -1).all() and np.isin(r[d], [2, 4, 5]).all()
+        reasons |= set(r[d].tolist())
+        if t % 10 == 9:
+            st = env.get_state()
+            k, kmax, khit, active, spawns = st["ball_i"].T
+            assert (active == 1).all() and (k >= 0).all() and (k <= np.minimum(kmax, khit) + 24).all() and (spawns >= 1).all()
+            assert np.allclose(np.linalg.norm(st["ball"][:, 3:6], axis=1), 6.0, atol=1e-4)
+    assert {2, 4, 5} <= reasons
     env.close()
