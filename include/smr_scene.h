@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SMR_SCENE_VERSION 3
+#define SMR_SCENE_VERSION 4
 #define SMR_NJ 7          /* manipulator joints (iiwa_joint_1..7, robot.urdf)            */
 #define SMR_NLINK 8       /* rigid bodies iiwa_link_0..7; body k moves with joints 1..k    */
 #define SMR_MAX_PLANETS 2
@@ -84,6 +84,9 @@ typedef struct smr_scene {
     /* ---- geometry ---- */
     const double *verts;                /* n_verts x 3 */
     const smr_piece_t *pieces;
+    const int32_t *adj_offsets;         /* n_verts + 1: CSR over all vertices of the hull adjacency (edges of the
+                                           triangulated convex hull of each piece, safemotionsrisk_amd/assets.py) */
+    const int32_t *adj;                 /* neighbour vertex ids, LOCAL to the vertex's piece; a piece has <= 256 vertices */
     int32_t n_verts;
     int32_t n_pieces;
     int32_t link_piece[SMR_NLINK];      /* piece (link frame) of iiwa_link_k */

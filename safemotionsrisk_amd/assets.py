@@ -85,6 +85,38 @@ def hull_vertices(points):
     return pts[np.sort(hull.vertices)]
 
 
+def hull_adjacency(verts):
+    """Vertex adjacency of the convex hull of `verts` (all of them extreme points, as hull_vertices returns them):
+    CSR (offsets[n+1], neighbours) over the edges of Qhull's triangulated facets.  Those contain every edge of the
+    polytope, which is all a hill-climbing support search needs: a vertex none of whose neighbours has a larger dot
+    product with d is a maximiser of it over the whole hull."""
+    from scipy.spatial import ConvexHull
+    n = len(verts)
+    adj = [set() for _ in range(n)]
+    if n <= 4:
+        for i in range(n):
+            adj[i] = set(range(n)) - {i}
+    else:
+        hull = ConvexHull(np.asarray(verts, dtype=np.float64))
+        assert len(hull.vertices) == n, "hull_adjacency expects extreme points only"
+        for tri in hull.simplices:
+            for a in range(3):
+                adj[tri[a]].update((tri[(a + 1) % 3], tri[(a + 2) % 3]))
+    offsets = np.cumsum([0] + [len(a) for a in adj]).astype(np.int32)
+    ids = np.array([j for a in adj for j in sorted(a)], dtype=np.int16)
+    return offsets, ids
+
+
+def _family_adjacency(verts, offsets):
+    """Adjacency of every piece of a family: (adj_offsets over the family's vertex array, neighbour ids local to the piece)."""
+    offs, ids = [np.zeros(1, dtype=np.int32)], []
+    for i in range(len(offsets) - 1):
+        o, a = hull_adjacency(verts[offsets[i]:offsets[i + 1]])
+        offs.append(o[1:] + offs[-1][-1])
+        ids.append(a)
+    return np.concatenate(offs).astype(np.int32), np.concatenate(ids).astype(np.int16)
+
+
 def _floats(s):
     return [float(x) for x in s.split()]
 
@@ -189,6 +221,8 @@ def compile_assets(ref_root):
         out[key + "_verts"] = v
         out[key + "_offsets"] = offs
 
+    for key in ("link", "iss", "asteroid", "ball"):
+        out[key + "_adj_offsets"], out[key + "_adj"] = _family_adjacency(out[key + "_verts"], out[key + "_offsets"])
     out["urdf_collision_margin"] = np.array(URDF_COLLISION_MARGIN)
     return out
 

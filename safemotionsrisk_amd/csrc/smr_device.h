@@ -33,11 +33,18 @@ struct DPiece {
     float cx, cy, cz, radius;   // bounding sphere of the hull, piece frame
     float margin;
     float hx, hy, hz;           // half extents of the hull's AABB about (cx,cy,cz), piece frame
+    float in[3][3];             // three points INSIDE the hull (means of vertex subsets: all / upper / lower half along
+                                // the longest box axis): any pair of interior points bounds the hull distance from above
+    int ids_begin, ids_count;   // the piece's neighbour-id groups in DScene::ids4 (hill-climbing support)
 };
+constexpr int kPieceDwords = 21;
+constexpr int kStartBins = 4;                                // cube-map resolution of the climb start table
+constexpr int kStartCells = 6 * kStartBins * kStartBins;     // entries per piece
 
 struct DPlanet {
     int piece_begin, piece_count, n_orbit, index_shift, coupled;
     float radius_x, radius_y;
+    float bx, by, bz, bradius;  // bounding sphere of the whole planet (all pieces, margins included), planet frame
     const float *orbit_pose;    // [n_orbit][8]: pos xyz, quat xyzw, pad
     const float *orbit_local;   // [n_orbit][2]
 };
@@ -50,6 +57,9 @@ struct DScene {
     float base[3], joint_xyz[SMR_NJ][3], joint_axis[SMR_NJ][3], ee_offset[3];
     const float4 *verts;
     const DPiece *pieces;
+    const uint32_t *span;      // per vertex (indexed like verts): first neighbour-id group relative to the piece | groups << 16
+    const uint32_t *ids4;      // groups of 4 neighbour ids, one byte each, local to the piece
+    const uint8_t *start;      // kStartCells per piece: support vertex of each cube-map cell centre
     int link_piece[SMR_NLINK];
     int n_static, static_piece[SMR_MAX_STATIC];
     unsigned static_mask;
@@ -372,14 +382,85 @@ __device__ __forceinline__ F3 support(const SMR_CONST float *verts, int begin, i
     return IDENTITY ? pl : apply(X, pl);
 }
 
+// ---- support of the robot-link hull (the B side of every query) -------------------------------
+// ScanHull: the exhaustive scan above.  ClimbHull: hill climbing along the hull's edge graph - from a start vertex
+// move to the neighbour with the largest dot product until none is larger; on a convex polytope such a vertex
+// maximises the dot product over the whole hull.  Start: the previous support vertex of the same GJK run, or for
+// its first iteration the entry of a small cube map of precomputed supports.  ~20-40 vertex reads per call
+// instead of 250, per lane (the link hull lives in LDS in the step kernel, in global memory elsewhere).
+struct ScanHull {
+    const SMR_CONST float *verts; int begin, count;
+    __device__ __forceinline__ F3 support(F3 dl, int &, bool) const {
+        Xf unused;
+        return smr::support<true>(verts, begin, count, unused, dl);
+    }
+};
+
+__device__ __forceinline__ int climb_start_cell(F3 d) {
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int m; float a, b, s;
+    if (ax >= ay && ax >= az) { m = d.x < 0.f ? 1 : 0; s = ax; a = d.y; b = d.z; }
+    else if (ay >= az) { m = d.y < 0.f ? 3 : 2; s = ay; a = d.x; b = d.z; }
+    else { m = d.z < 0.f ? 5 : 4; s = az; a = d.x; b = d.y; }
+    const float k = 0.5f * (float)kStartBins / fmaxf(s, 1e-30f);
+    int ia = (int)((a + s) * k), ib = (int)((b + s) * k);
+    ia = ia < 0 ? 0 : (ia > kStartBins - 1 ? kStartBins - 1 : ia);
+    ib = ib < 0 ? 0 : (ib > kStartBins - 1 ? kStartBins - 1 : ib);
+    return (m * kStartBins + ia) * kStartBins + ib;
+}
+
+template <class FP, class UP, class BP>
+struct ClimbHull {
+    FP v;        // vertices of the piece, 4 floats each
+    UP span;     // per vertex
+    UP ids4;     // the piece's id groups
+    BP start;    // the piece's start map
+    __device__ __forceinline__ F3 support(F3 dl, int &cur, bool first) const {
+        if (first) cur = (int)start[climb_start_cell(dl)];
+        F3 pv = {v[4 * cur], v[4 * cur + 1], v[4 * cur + 2]};
+        float best = fmaf(pv.z, dl.z, fmaf(pv.y, dl.y, pv.x * dl.x));
+        for (int guard = 0; guard < 256; ++guard) {
+            const uint32_t sp = span[cur];
+            const int g0 = (int)(sp & 0xffffu), g1 = g0 + (int)(sp >> 16);
+            int nb = cur;
+            for (int g = g0; g < g1; ++g) {
+                const uint32_t four = ids4[g];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int id = (int)((four >> (8 * k)) & 255u);
+                    const F3 q = {v[4 * id], v[4 * id + 1], v[4 * id + 2]};
+                    const float sq = fmaf(q.z, dl.z, fmaf(q.y, dl.y, q.x * dl.x));
+                    if (sq > best) { best = sq; nb = id; pv = q; }
+                }
+            }
+            if (nb == cur) break;
+            cur = nb;
+        }
+        return pv;
+    }
+};
+using GlobalHull = ClimbHull<const SMR_GLOBAL float *, const SMR_GLOBAL uint32_t *, const SMR_GLOBAL uint8_t *>;
+using LocalHull = ClimbHull<const float *, const uint32_t *, const uint8_t *>;      // LDS copy (collide kernel)
+
 __device__ __forceinline__ DPiece load_piece(const DPiece *pieces, int idx) {
-    static_assert(sizeof(DPiece) == 40, "DPiece is read as 10 dwords");
-    const SMR_CONST int *w = (const SMR_CONST int *)pieces + 10 * (size_t)__builtin_amdgcn_readfirstlane(idx);
+    static_assert(sizeof(DPiece) == 4 * kPieceDwords, "DPiece is read as dwords");
+    const SMR_CONST int *w = (const SMR_CONST int *)pieces + kPieceDwords * (size_t)__builtin_amdgcn_readfirstlane(idx);
     DPiece P;
     P.begin = w[0]; P.count = w[1];
     P.cx = __int_as_float(w[2]); P.cy = __int_as_float(w[3]); P.cz = __int_as_float(w[4]); P.radius = __int_as_float(w[5]);
     P.margin = __int_as_float(w[6]); P.hx = __int_as_float(w[7]); P.hy = __int_as_float(w[8]); P.hz = __int_as_float(w[9]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) P.in[i][c] = __int_as_float(w[10 + 3 * i + c]);
+    P.ids_begin = w[19]; P.ids_count = w[20];
     return P;
+}
+
+// the link hull of piece index pi (already loaded as P) read from the global tables
+__device__ __forceinline__ GlobalHull global_hull(const DScene &S, int pi, const DPiece &P) {
+    return GlobalHull{(const SMR_GLOBAL float *)S.verts + 4 * (size_t)P.begin, (const SMR_GLOBAL uint32_t *)S.span + P.begin,
+                      (const SMR_GLOBAL uint32_t *)S.ids4 + P.ids_begin, (const SMR_GLOBAL uint8_t *)S.start + kStartCells * (size_t)pi};
 }
 
 // closest point of segment (a,b) to the origin; mask: bit0 a, bit1 b support it
@@ -473,15 +554,15 @@ __device__ inline bool simplex_solve(F3 &w0, F3 &w1, F3 &w2, F3 &w3, int &n, F3 
 // Distance between hull A (piece pa under XA; IDENTITY: XA is the identity) and hull B (piece pb under
 // XB), margins excluded.  Returns a lower bound > cutoff as soon as one is proven, and the current
 // upper bound as soon as it drops below stop_below (callers only test it against a threshold then).
-template <bool IDENTITY>
-__device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece &A, const Xf &XA, const DPiece &B,
+template <bool IDENTITY, class HB>
+__device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece &A, const Xf &XA, const HB &hb,
                                      const Xf &XB, F3 v, float cutoff, float stop_below) {
     F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
-    int n = 0;
+    int n = 0, hint = 0;
     float vv = dot(v, v);
     const float cutoff2 = cutoff * cutoff, stop2 = stop_below > 0.f ? stop_below * stop_below : 0.f;
     for (int it = 0; it < 32; ++it) {
-        F3 w = support<IDENTITY>(verts, A.begin, A.count, XA, neg(v)) - support<false>(verts, B.begin, B.count, XB, v);
+        F3 w = support<IDENTITY>(verts, A.begin, A.count, XA, neg(v)) - apply(XB, hb.support(rot_t(XB, v), hint, it == 0));
         float vw = dot(v, w);
 #ifdef SMR_HOST_EMUL_TRACE
         printf("  it %d n %d vv %.9g vw %.9g v=(%.7g %.7g %.7g) w=(%.7g %.7g %.7g)\n", it, n, vv, vw, v.x, v.y, v.z, w.x, w.y, w.z);
@@ -517,10 +598,10 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
 
 // signed distance (margins subtracted) between obstacle piece pa and link piece pb, or any value
 // > cutoff when they are farther apart than cutoff (ctlp.py:2915-2931: no closest point returned)
-template <bool IDENTITY>
-__device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, int pb, const Xf &XB, float cutoff,
-                                       float stop_below) {
-    const DPiece A = load_piece(S.pieces, pa), B = load_piece(S.pieces, pb);
+template <bool IDENTITY, class HB>
+__device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, const DPiece &B, const HB &hb, const Xf &XB,
+                                       float cutoff, float stop_below) {
+    const DPiece A = load_piece(S.pieces, pa);
     const float margins = A.margin + B.margin;
     F3 cb = apply(XB, F3{B.cx, B.cy, B.cz});
     F3 ca = IDENTITY ? F3{A.cx, A.cy, A.cz} : apply(XA, F3{A.cx, A.cy, A.cz});
@@ -533,7 +614,7 @@ __device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, in
         lb = sqrtf(dot(d, d)) - A.radius - B.radius - margins;
     }
     if (lb > cutoff) return lb;
-    return gjk_distance<IDENTITY>((const SMR_CONST float *)S.verts, A, XA, B, XB, d, cutoff + margins, stop_below + margins) - margins;
+    return gjk_distance<IDENTITY>((const SMR_CONST float *)S.verts, A, XA, hb, XB, d, cutoff + margins, stop_below + margins) - margins;
 }
 
 __device__ __forceinline__ Xf planet_pose(const DScene &S, int p, int idx) {
@@ -564,23 +645,30 @@ __device__ inline Sample collide_sample(const DScene &S, const float q[SMR_NJ], 
     for (int l = 0; l < SMR_NLINK; ++l) {
         if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
         const int pl = S.link_piece[l];
+        const DPiece LP = load_piece(S.pieces, pl);
+        const GlobalHull hull = global_hull(S, pl, LP);
         if (want_dist && ((S.static_mask >> l) & 1u)) {
             for (int s = 0; s < S.n_static; ++s) {
-                float d = piece_distance<true>(S, S.static_piece[s], I, pl, T, out.d_static, S.collision_dist);
+                float d = piece_distance<true>(S, S.static_piece[s], I, LP, hull, T, out.d_static, S.collision_dist);
                 if (d <= S.static_max && d < out.d_static) out.d_static = d;
             }
         }
         const bool mov_link = (S.moving_mask >> l) & 1u, con_link = (S.contact_mask >> l) & 1u;
         if (!(mov_link || con_link)) continue;
+        const F3 lc = apply(T, F3{LP.cx, LP.cy, LP.cz});
         for (int p = 0; p < S.n_planets; ++p) {
             const int pb = S.planet[p].piece_begin, pc = S.planet[p].piece_count;
+            // whole-planet bounding sphere against the link's: skips all of its pieces at once
+            const F3 pcen = apply(XP[p], F3{S.planet[p].bx, S.planet[p].by, S.planet[p].bz}) - lc;
+            const float plb = sqrtf(dot(pcen, pcen)) - S.planet[p].bradius - LP.radius - LP.margin;
             for (int c = 0; c < pc; ++c) {
                 const bool mov = want_dist && mov_link;
                 const bool con = want_contact && con_link && !out.contact;
                 if (!(mov || con)) continue;
+                if (plb > (mov ? fmaxf(fminf(out.d_moving, S.moving_max), con ? S.contact_dist : 0.f) : S.contact_dist)) continue;
                 float cutoff = mov ? fminf(out.d_moving, S.moving_max) : S.contact_dist;
                 if (con) cutoff = fmaxf(cutoff, S.contact_dist);
-                float d = piece_distance<false>(S, pb + c, XP[p], pl, T, cutoff, stop_moving);
+                float d = piece_distance<false>(S, pb + c, XP[p], LP, hull, T, cutoff, stop_moving);
                 if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
                 if (con && d <= S.contact_dist) out.contact = true;
             }
@@ -632,16 +720,17 @@ __device__ __forceinline__ int ball_retire_update(const DScene &S, int k, int km
 // The same queries for ONE robot link (the step path runs one lane per (env, sample, link): 8x the
 // wavefronts of collide_sample, which is what keeps the SIMDs occupied while lanes wait on each other).
 // T is the link frame; every loop bound and piece index is wave uniform.
-__device__ inline Sample collide_link(const DScene &S, int l, const Xf &T, const int idx[SMR_MAX_PLANETS], const Xf *XB,
-                                      bool want_static, bool want_moving, bool want_contact) {
+template <class HB>
+__device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, const HB &hull, const Xf &T,
+                                      const int idx[SMR_MAX_PLANETS], const Xf *XB, bool want_static, bool want_moving,
+                                      bool want_contact) {
     Sample out;
     out.d_static = S.static_max;
     out.d_moving = S.moving_max + 0.002f;
     out.contact = false;
-    const int pl = S.link_piece[l];
     if (want_static && ((S.static_mask >> l) & 1u)) {
         for (int s = 0; s < S.n_static; ++s) {
-            float d = piece_distance<true>(S, S.static_piece[s], T, pl, T, out.d_static, S.collision_dist);
+            float d = piece_distance<true>(S, S.static_piece[s], T, LP, hull, T, out.d_static, S.collision_dist);
             if (d <= S.static_max && d < out.d_static) out.d_static = d;
         }
     }
@@ -652,20 +741,47 @@ __device__ inline Sample collide_link(const DScene &S, int l, const Xf &T, const
     if (S.use_ball) {                                   // one moving piece: the ball, pose XB
         const bool con = want_contact && con_link;
         float cutoff = mov ? S.moving_max : S.contact_dist;
-        float d = piece_distance<false>(S, S.ball_piece, *XB, pl, T, cutoff, stop_moving);
+        float d = piece_distance<false>(S, S.ball_piece, *XB, LP, hull, T, cutoff, stop_moving);
         if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
         if (con && d <= S.contact_dist) out.contact = true;
         return out;
     }
+    const F3 lc = apply(T, F3{LP.cx, LP.cy, LP.cz});
+    // Upper bound on the minimum distance from interior points (3 of the link x 1 per piece): pairs that cannot
+    // beat it are culled by their bounding spheres or leave GJK after one or two iterations.  The pair that
+    // attains the minimum is never cut: its distance is <= the bound.
+    float cut_moving = S.moving_max;
+    if (mov) {
+        const F3 l0 = apply(T, F3{LP.in[0][0], LP.in[0][1], LP.in[0][2]}), l1 = apply(T, F3{LP.in[1][0], LP.in[1][1], LP.in[1][2]}),
+                 l2 = apply(T, F3{LP.in[2][0], LP.in[2][1], LP.in[2][2]});
+        float ub2 = 3.0e38f, mar = 0.f;
+        for (int p = 0; p < S.n_planets; ++p) {
+            const Xf XP = planet_pose(S, p, idx[p]);
+            const int pb = S.planet[p].piece_begin, pc = S.planet[p].piece_count;
+            for (int c = 0; c < pc; ++c) {
+                const DPiece PP = load_piece(S.pieces, pb + c);
+                const F3 m = apply(XP, F3{PP.in[0][0], PP.in[0][1], PP.in[0][2]});
+                const F3 e0 = m - l0, e1 = m - l1, e2 = m - l2;
+                ub2 = fminf(ub2, fminf(dot(e0, e0), fminf(dot(e1, e1), dot(e2, e2))));
+                mar = PP.margin;
+            }
+        }
+        cut_moving = fminf(cut_moving, (sqrtf(ub2) - LP.margin - mar) * 1.00001f + 1e-6f);
+        cut_moving = fmaxf(cut_moving, S.contact_dist);        // never below the contact threshold tested with it
+    }
     for (int p = 0; p < S.n_planets; ++p) {
         const Xf XP = planet_pose(S, p, idx[p]);
         const int pb = S.planet[p].piece_begin, pc = S.planet[p].piece_count;
+        // whole-planet bounding sphere against the link's: skips all of its pieces at once
+        const F3 pcen = apply(XP, F3{S.planet[p].bx, S.planet[p].by, S.planet[p].bz}) - lc;
+        const float plb = sqrtf(dot(pcen, pcen)) - S.planet[p].bradius - LP.radius - LP.margin;
         for (int c = 0; c < pc; ++c) {
             const bool con = want_contact && con_link && !out.contact;
             if (!(mov || con)) continue;
-            float cutoff = mov ? fminf(out.d_moving, S.moving_max) : S.contact_dist;
+            float cutoff = mov ? fminf(out.d_moving, cut_moving) : S.contact_dist;
             if (con) cutoff = fmaxf(cutoff, S.contact_dist);
-            float d = piece_distance<false>(S, pb + c, XP, pl, T, cutoff, stop_moving);
+            if (plb > cutoff) continue;
+            float d = piece_distance<false>(S, pb + c, XP, LP, hull, T, cutoff, stop_moving);
             if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
             if (con && d <= S.contact_dist) out.contact = true;
         }

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "smr_device.h"
+#include "smr_tables.h"
 
 namespace smr {
 
@@ -42,11 +43,32 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
 // one lane per (env, sample k, link l); grid = (B/64, N, 8)
 __global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
+    const int l = (int)blockIdx.z;                     // iiwa_link_l
+    // the link's hull, edge graph and start map staged in LDS: every support call of this block climbs over them
+    __shared__ float lds_v[4 * kMaxPieceVerts];
+    __shared__ uint32_t lds_span[kMaxPieceVerts];
+    __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
+    __shared__ uint32_t lds_start[kStartCells / 4];
+    const int pl = S.link_piece[l];
+    const DPiece LP = load_piece(S.pieces, pl);
+    {
+        const SMR_GLOBAL float4 *gv = (const SMR_GLOBAL float4 *)S.verts + LP.begin;
+        const SMR_GLOBAL uint32_t *gs = (const SMR_GLOBAL uint32_t *)S.span + LP.begin, *gi = (const SMR_GLOBAL uint32_t *)S.ids4 + LP.ids_begin,
+                                  *gm = (const SMR_GLOBAL uint32_t *)S.start + (kStartCells / 4) * (size_t)pl;
+        for (int i = threadIdx.x; i < LP.count; i += 64) {
+            const SMR_GLOBAL float *f = (const SMR_GLOBAL float *)(gv + i);
+            lds_v[4 * i] = f[0]; lds_v[4 * i + 1] = f[1]; lds_v[4 * i + 2] = f[2]; lds_v[4 * i + 3] = 0.f;
+            lds_span[i] = gs[i];
+        }
+        for (int i = threadIdx.x; i < LP.ids_count; i += 64) lds_ids[i] = gi[i];
+        if (threadIdx.x < kStartCells / 4) lds_start[threadIdx.x] = gm[threadIdx.x];
+    }
+    __syncthreads();
+    const LocalHull hull{lds_v, lds_span, lds_ids, (const uint8_t *)lds_start};
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
     const int B = S.B, N = S.checks_per_step;
     const int k = (int)blockIdx.y + 1;                 // sample k of N, t_k = k dt / N
-    const int l = (int)blockIdx.z;                     // iiwa_link_l
     const bool final_sample = (k == N);
     const int upd = S.updates_per_step / N;
     float *res = st.res + ((size_t)(k - 1) * SMR_NLINK + l) * B;
@@ -81,13 +103,13 @@ __global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ 
     if (S.use_ball) {
         Xf XB = ball_pose(S, ball, ball_k, nullptr);
         const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-        r = collide_link(S, l, T, nullptr, &XB, want_static, want_moving, want_contact && near);
+        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near);
     } else {
         int idx[SMR_MAX_PLANETS] = {0, 0};
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
-        r = collide_link(S, l, T, idx, nullptr, want_static, want_moving, want_contact);
+        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact);
     }
     res[e] = r.contact ? 1.f : 0.f;
     if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(SMR_NLINK + l) * B + e] = r.d_moving; }
@@ -225,7 +247,8 @@ __device__ inline bool pose_is_valid(const DScene &S, const float q[SMR_NJ], con
         if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
         if (ok && ((S.static_mask >> l) & 1u)) {
             for (int s = 0; s < S.n_static; ++s) {                                        // ctlp.py:2140-2168
-                float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, 0.f);
+                const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
+                float d = piece_distance<true>(S, S.static_piece[s], I, LP, global_hull(S, S.link_piece[l], LP), T, thr + 0.005f, 0.f);
                 if (d <= thr + 0.005f && d < thr) ok = false;
             }
         }
@@ -397,7 +420,8 @@ __device__ inline bool ball_contact_all_links(const DScene &S, const float q[SMR
     for (int l = 0; l < SMR_NLINK; ++l) {
         if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
         if (!contact && ((S.contact_mask >> l) & 1u)) {
-            float d = piece_distance<false>(S, S.ball_piece, XB, S.link_piece[l], T, S.contact_dist, S.contact_dist);
+            const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
+            float d = piece_distance<false>(S, S.ball_piece, XB, LP, global_hull(S, S.link_piece[l], LP), T, S.contact_dist, S.contact_dist);
             if (d <= S.contact_dist) contact = true;
         }
     }
@@ -436,7 +460,8 @@ __device__ inline bool table_free(const DScene &S, const float q[SMR_NJ]) {
         if (free_pos && ((S.static_mask >> l) & 1u))
             for (int s = 0; s < S.n_static; ++s) {
                 float thr = S.start_min_static;
-                float d = piece_distance<true>(S, S.static_piece[s], I, S.link_piece[l], T, thr + 0.005f, 0.f);
+                const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
+                float d = piece_distance<true>(S, S.static_piece[s], I, LP, global_hull(S, S.link_piece[l], LP), T, thr + 0.005f, 0.f);
                 if (d <= thr + 0.005f && d < thr) free_pos = false;
             }
     }
@@ -708,8 +733,10 @@ __global__ void test_ball_distances_kernel(const DScene *__restrict__ Sp, const 
     Xf T = fk_base(S);
     for (int l = 0; l < SMR_NLINK; ++l) {
         if (l > 0) fk_advance(S, l - 1, q[i * SMR_NJ + l - 1], T);
-        Sample d = collide_link(S, l, T, nullptr, &XB, true, true, false);
-        Sample c = collide_link(S, l, T, nullptr, &XB, false, false, true);
+        const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
+        const GlobalHull hull = global_hull(S, S.link_piece[l], LP);
+        Sample d = collide_link(S, l, LP, hull, T, nullptr, &XB, true, true, false);
+        Sample c = collide_link(S, l, LP, hull, T, nullptr, &XB, false, false, true);
         dst = fminf(dst, d.d_static); dmv = fminf(dmv, d.d_moving); contact = contact || c.contact;
     }
     out[4 * i] = dst; out[4 * i + 1] = S.static_max; out[4 * i + 2] = dmv; out[4 * i + 3] = contact ? 1.f : 0.f;
@@ -787,38 +814,19 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     copy3(d.base, s.base_xyz); copy3(d.ee_offset, s.ee_offset);
     for (int j = 0; j < SMR_NJ; ++j) { copy3(d.joint_xyz[j], s.joint_xyz[j]); copy3(d.joint_axis[j], s.joint_axis[j]); }
 
-    // Device vertex table: every piece starts on a 64-byte boundary (4 vertices of 16 B) so that the wide scalar
-    // loads of the support scan (s_load_dwordx8/x16) never straddle their natural alignment.
-    std::vector<float4> verts;
-    std::vector<DPiece> pieces((size_t)s.n_pieces);
-    for (int i = 0; i < s.n_pieces; ++i) {
-        const smr_piece_t &p = s.pieces[i];
-        if (p.vert_begin < 0 || p.vert_count <= 0 || p.vert_begin + p.vert_count > s.n_verts) { env->err = "piece vertex range out of bounds"; return SMR_E_INVALID; }
-        DPiece &q = pieces[i];
-        while (verts.size() % 4) verts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
-        q.begin = (int)verts.size(); q.count = p.vert_count;
-        for (int k = 0; k < p.vert_count; ++k) {
-            const double *src = s.verts + 3 * (size_t)(p.vert_begin + k);
-            verts.push_back(make_float4((float)src[0], (float)src[1], (float)src[2], 0.f));
-        }
-        q.cx = (float)p.center[0]; q.cy = (float)p.center[1]; q.cz = (float)p.center[2];
-        q.margin = (float)p.margin;
-        // bounding data recomputed in float32 around the float32 center, slightly inflated, so culling stays conservative
-        float r = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
-        for (int k = 0; k < p.vert_count; ++k) {
-            const float4 &vv = verts[(size_t)q.begin + k];
-            float dx = vv.x - q.cx, dy = vv.y - q.cy, dz = vv.z - q.cz;
-            r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
-            hx = std::max(hx, std::fabs(dx)); hy = std::max(hy, std::fabs(dy)); hz = std::max(hz, std::fabs(dz));
-        }
-        q.radius = r * 1.00001f + 1e-7f; q.hx = hx + 1e-7f; q.hy = hy + 1e-7f; q.hz = hz + 1e-7f;
+    HostGeometry G;
+    if (const char *msg = build_host_geometry(s, G)) { env->err = msg; return SMR_E_INVALID; }
+    for (int l = 0; l < SMR_NLINK; ++l) {
+        const int p = s.link_piece[l];
+        if (p >= 0 && p < s.n_pieces && G.pieces[p].ids_count > kMaxPieceIdGroups) { env->err = "link hull adjacency exceeds the LDS budget"; return SMR_E_INVALID; }
     }
-    for (int k = 0; k < 8; ++k) verts.push_back(make_float4(0.f, 0.f, 0.f, 0.f));   // slack for the last unrolled load
-    float4 *dverts; DPiece *dpieces;
+    const std::vector<DPiece> &pieces = G.pieces;
+    float4 *dverts; DPiece *dpieces; uint32_t *dspan, *dids; uint8_t *dstart;
     int rc;
-    if ((rc = dev_upload(env, &dverts, verts))) return rc;
-    if ((rc = dev_upload(env, &dpieces, pieces))) return rc;
-    d.verts = dverts; d.pieces = dpieces;
+    while (G.start.size() % 4) G.start.push_back(0);
+    if ((rc = dev_upload(env, &dverts, G.verts)) || (rc = dev_upload(env, &dpieces, G.pieces)) || (rc = dev_upload(env, &dspan, G.span)) ||
+        (rc = dev_upload(env, &dids, G.ids4)) || (rc = dev_upload(env, &dstart, G.start))) return rc;
+    d.verts = dverts; d.pieces = dpieces; d.span = dspan; d.ids4 = dids; d.start = dstart;
     auto piece_ok = [&](int p) { return p >= 0 && p < s.n_pieces; };
     for (int l = 0; l < SMR_NLINK; ++l) { if (!piece_ok(s.link_piece[l])) { env->err = "bad link_piece"; return SMR_E_INVALID; } d.link_piece[l] = s.link_piece[l]; }
     if (s.n_static < 0 || s.n_static > SMR_MAX_STATIC) { env->err = "bad n_static"; return SMR_E_INVALID; }
@@ -845,6 +853,7 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
         q.piece_begin = pl.piece_begin; q.piece_count = pl.piece_count; q.n_orbit = pl.n_orbit; q.index_shift = pl.index_shift;
         q.coupled = pl.coupled; q.radius_x = (float)pl.radius_xy[0]; q.radius_y = (float)pl.radius_xy[1];
         q.orbit_pose = dpose; q.orbit_local = dlocal;
+        planet_bounds(pieces, q);
     }
     copy3(d.planet_obs_min, s.planet_obs_pos_min); copy3(d.planet_obs_max, s.planet_obs_pos_max);
     d.use_ball = s.use_ball; d.dt64 = s.dt;

@@ -1,0 +1,129 @@
+// smr_tables.h - host side: the geometry of an smr_scene_t (float64, include/smr_scene.h) converted to the float32
+// tables the device functions of smr_device.h read.  Shared by the HIP library (smr_hip.hip uploads the vectors)
+// and by tests/host_emul (which points a DScene at them in host memory).  No HIP runtime calls in here.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "smr_device.h"
+
+namespace smr {
+
+constexpr int kMaxPieceVerts = 256;    // neighbour ids are bytes
+constexpr int kMaxPieceIdGroups = 1024; // LDS budget of the collide kernel for one link hull (groups of 4 ids)
+
+struct HostGeometry {
+    std::vector<float4> verts;     // every piece starts on a 64-byte boundary (wide scalar loads of the scan never straddle it)
+    std::vector<DPiece> pieces;
+    std::vector<uint32_t> span;    // per vertex slot (indexed like verts): first id group relative to the piece | groups << 16
+    std::vector<uint32_t> ids4;    // groups of 4 neighbour ids (one byte each, local to the piece), padded with the vertex itself
+    std::vector<uint8_t> start;    // kStartCells per piece: the support vertex of each cube-map cell centre
+};
+
+// direction of start-map cell (m, ia, ib): see climb_start() in smr_device.h
+inline void start_cell_direction(int m, int ia, int ib, double d[3]) {
+    const double a = -1.0 + (2.0 * ia + 1.0) / kStartBins, b = -1.0 + (2.0 * ib + 1.0) / kStartBins, sgn = (m & 1) ? -1.0 : 1.0;
+    if (m < 2) { d[0] = sgn; d[1] = a; d[2] = b; }
+    else if (m < 4) { d[0] = a; d[1] = sgn; d[2] = b; }
+    else { d[0] = a; d[1] = b; d[2] = sgn; }
+}
+
+// returns nullptr on success, else a message
+inline const char *build_host_geometry(const smr_scene_t &s, HostGeometry &G) {
+    if (!s.adj_offsets || !s.adj) return "scene has no hull adjacency (adj_offsets / adj)";
+    G.pieces.assign((size_t)s.n_pieces, DPiece{});
+    for (int i = 0; i < s.n_pieces; ++i) {
+        const smr_piece_t &p = s.pieces[i];
+        if (p.vert_begin < 0 || p.vert_count <= 0 || p.vert_begin + p.vert_count > s.n_verts) return "piece vertex range out of bounds";
+        if (p.vert_count > kMaxPieceVerts) return "a piece has more than 256 hull vertices";
+        DPiece &q = G.pieces[i];
+        while (G.verts.size() % 4) { G.verts.push_back(float4{0.f, 0.f, 0.f, 0.f}); G.span.push_back(0u); }
+        q.begin = (int)G.verts.size(); q.count = p.vert_count;
+        for (int k = 0; k < p.vert_count; ++k) {
+            const double *src = s.verts + 3 * (size_t)(p.vert_begin + k);
+            G.verts.push_back(float4{(float)src[0], (float)src[1], (float)src[2], 0.f});
+        }
+        q.cx = (float)p.center[0]; q.cy = (float)p.center[1]; q.cz = (float)p.center[2];
+        q.margin = (float)p.margin;
+        // bounding data recomputed in float32 around the float32 centre, slightly inflated, so culling stays conservative
+        float r = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+        for (int k = 0; k < p.vert_count; ++k) {
+            const float4 &vv = G.verts[(size_t)q.begin + k];
+            float dx = vv.x - q.cx, dy = vv.y - q.cy, dz = vv.z - q.cz;
+            r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz));
+            hx = std::max(hx, std::fabs(dx)); hy = std::max(hy, std::fabs(dy)); hz = std::max(hz, std::fabs(dz));
+        }
+        q.radius = r * 1.00001f + 1e-7f; q.hx = hx + 1e-7f; q.hy = hy + 1e-7f; q.hz = hz + 1e-7f;
+        // three interior points: mean of all vertices, and of the halves above / below the box centre along the longest box axis
+        {
+            const int ax = (q.hx >= q.hy && q.hx >= q.hz) ? 0 : (q.hy >= q.hz ? 1 : 2);
+            double m[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            int n[3] = {0, 0, 0};
+            const float cen[3] = {q.cx, q.cy, q.cz};
+            for (int k = 0; k < p.vert_count; ++k) {
+                const float4 &vv = G.verts[(size_t)q.begin + k];
+                const float xyz[3] = {vv.x, vv.y, vv.z};
+                const int half = xyz[ax] >= cen[ax] ? 1 : 2;
+                for (int c = 0; c < 3; ++c) { m[0][c] += xyz[c]; m[half][c] += xyz[c]; }
+                n[0]++; n[half]++;
+            }
+            for (int h = 0; h < 3; ++h)
+                for (int c = 0; c < 3; ++c) q.in[h][c] = (float)(n[h] ? m[h][c] / n[h] : m[0][c] / n[0]);
+        }
+        // adjacency: byte ids in groups of four
+        q.ids_begin = (int)G.ids4.size();
+        for (int k = 0; k < p.vert_count; ++k) {
+            const int a0 = s.adj_offsets[p.vert_begin + k], a1 = s.adj_offsets[p.vert_begin + k + 1];
+            if (a0 < 0 || a1 < a0) return "bad adjacency offsets";
+            const int first = (int)G.ids4.size() - q.ids_begin, groups = (a1 - a0 + 3) / 4;
+            if (first + groups > 0xffff || groups > 0xffff) return "hull adjacency too large";
+            for (int g = 0; g < groups; ++g) {
+                uint32_t word = 0;
+                for (int b = 0; b < 4; ++b) {
+                    const int a = a0 + 4 * g + b;
+                    int id = a < a1 ? s.adj[a] : k;
+                    if (id < 0 || id >= p.vert_count) return "adjacency id out of the piece";
+                    word |= (uint32_t)id << (8 * b);
+                }
+                G.ids4.push_back(word);
+            }
+            G.span.push_back((uint32_t)first | ((uint32_t)groups << 16));
+        }
+        q.ids_count = (int)G.ids4.size() - q.ids_begin;
+        // start map: exhaustive support of the cell-centre directions
+        for (int m = 0; m < 6; ++m)
+            for (int ia = 0; ia < kStartBins; ++ia)
+                for (int ib = 0; ib < kStartBins; ++ib) {
+                    double d[3];
+                    start_cell_direction(m, ia, ib, d);
+                    int best = 0; double bs = -1e300;
+                    for (int k = 0; k < p.vert_count; ++k) {
+                        const float4 &vv = G.verts[(size_t)q.begin + k];
+                        const double sv = vv.x * d[0] + vv.y * d[1] + vv.z * d[2];
+                        if (sv > bs) { bs = sv; best = k; }
+                    }
+                    G.start.push_back((uint8_t)best);
+                }
+    }
+    for (int k = 0; k < 8; ++k) { G.verts.push_back(float4{0.f, 0.f, 0.f, 0.f}); G.span.push_back(0u); }   // slack for the last unrolled load
+    G.ids4.push_back(0u);
+    return nullptr;
+}
+
+// bounding sphere of a whole planet: centre = mean of the piece centres, radius covers every piece sphere + margin
+inline void planet_bounds(const std::vector<DPiece> &pieces, DPlanet &q) {
+    double cx = 0, cy = 0, cz = 0;
+    for (int c = 0; c < q.piece_count; ++c) { const DPiece &pp = pieces[q.piece_begin + c]; cx += pp.cx; cy += pp.cy; cz += pp.cz; }
+    q.bx = (float)(cx / q.piece_count); q.by = (float)(cy / q.piece_count); q.bz = (float)(cz / q.piece_count);
+    float br = 0.f;
+    for (int c = 0; c < q.piece_count; ++c) {
+        const DPiece &pp = pieces[q.piece_begin + c];
+        float dx = pp.cx - q.bx, dy = pp.cy - q.by, dz = pp.cz - q.bz;
+        br = std::max(br, std::sqrt(dx * dx + dy * dy + dz * dz) + pp.radius + pp.margin);
+    }
+    q.bradius = br * 1.00001f + 1e-6f;
+}
+
+}  // namespace smr

@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-SCENE_VERSION = 3
+SCENE_VERSION = 4
 NJ = 7
 NLINK = 8
 MAX_PLANETS = 2
@@ -56,6 +56,7 @@ class Scene(C.Structure):
         ("pos_lo", _D7), ("pos_hi", _D7), ("vel_max", _D7), ("acc_max", _D7), ("jerk_max", _D7),
         ("base_xyz", _D3), ("joint_xyz", _D3 * NJ), ("joint_axis", _D3 * NJ), ("ee_offset", _D3),
         ("verts", C.POINTER(C.c_double)), ("pieces", C.POINTER(Piece)),
+        ("adj_offsets", C.POINTER(C.c_int32)), ("adj", C.POINTER(C.c_int32)),
         ("n_verts", C.c_int32), ("n_pieces", C.c_int32), ("link_piece", C.c_int32 * NLINK),
         ("n_static", C.c_int32), ("static_piece", C.c_int32 * MAX_STATIC), ("static_link_mask", C.c_uint32),
         ("static_max_distance", C.c_double),
@@ -294,7 +295,7 @@ def _build_ball(config, s, assets, add_piece):
     ball_radius = 0.038                                                                  # scene.py:600
     s.use_ball = 1
     s.ball_radius, s.ball_speed, s.ball_sphere_radius = ball_radius, speed, radius
-    s.ball_piece = add_piece(assets["ball_verts"] * (ball_radius / 0.12))               # ctlp.py:4043-4044 globalScaling
+    s.ball_piece = add_piece(assets["ball_verts"] * (ball_radius / 0.12), _piece_adj(assets, "ball", 0))               # ctlp.py:4043-4044 globalScaling
     s.moving_link_mask = _link_mask(["iiwa_link_%d" % i for i in range(2, 8)])          # scene.py:226-228
     for c in range(3):
         s.ball_sphere_center[c] = center[c]
@@ -330,6 +331,13 @@ def _build_ball(config, s, assets, add_piece):
     for c in range(3):
         s.ball_target_box[c][0], s.ball_target_box[c][1] = tbox[c]
     s.ball_target_min_dist_static = float(_cfg(config, "closest_point_safety_distance")) + 0.09   # ctlp.py:1725-1726
+
+
+def _piece_adj(assets, family, i):
+    """(offsets relative to the piece, neighbour ids) of piece i of an asset family (assets.hull_adjacency)."""
+    vo = assets[family + "_offsets"]
+    ao = assets[family + "_adj_offsets"][vo[i]:vo[i + 1] + 1]
+    return (ao - ao[0]).astype(np.int32), assets[family + "_adj"][ao[0]:ao[-1]].astype(np.int32)
 
 
 class SceneBundle:
@@ -415,16 +423,19 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     margin = float(assets["urdf_collision_margin"])
     vert_blocks, pieces = [], []
 
-    def add_piece(v):
+    adj_blocks = []
+
+    def add_piece(v, adj):
         begin = sum(len(x) for x in vert_blocks)
         vert_blocks.append(np.asarray(v, dtype=np.float64))
+        adj_blocks.append(adj)
         c, r = _bounding_sphere(vert_blocks[-1])
         pieces.append((begin, len(v), c, r, margin))
         return len(pieces) - 1
 
     lo = assets["link_offsets"]
     for k in range(NLINK):
-        s.link_piece[k] = add_piece(assets["link_verts"][lo[k]:lo[k + 1]])
+        s.link_piece[k] = add_piece(assets["link_verts"][lo[k]:lo[k + 1]], _piece_adj(assets, "link", k))
 
     closest_point_active = ["iiwa_link_%d" % i for i in range(2, 8)]                    # ctlp.py:579-581
     s.n_static = 0
@@ -433,7 +444,9 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
         # table: Bullet box of half extents h has the implicit core h - margin plus the margin
         half = 0.5 * assets["table_box_size"] - margin
         corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
-        s.static_piece[0] = add_piece(assets["table_box_center"] + corners * half)
+        # corner i = sign bits (x, y, z) of i: the box edges join corners that differ in one bit
+        box_adj = (np.arange(0, 25, 3, dtype=np.int32), np.array([i ^ b for i in range(8) for b in (1, 2, 4)], dtype=np.int32))
+        s.static_piece[0] = add_piece(assets["table_box_center"] + corners * half, box_adj)
         s.n_static = 1
         observed = ["iiwa_link_%d" % i for i in range(1, 8)]                            # ctlp.py:2419-2434
         s.static_link_mask = _link_mask([n for n in observed if n in closest_point_active])
@@ -480,7 +493,7 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
                               euler=config.get("planet_one_euler_angles") if config.get("planet_one_euler_angles")
                               is not None else [0.35, 0, 0],
                               period=one_period, rotations=1, default_orn=quaternion_from_euler([0, 0, -np.pi / 2]),
-                              verts=assets["iss_verts"] * 0.6, offsets=assets["iss_offsets"], time_shift=None))
+                              verts=assets["iss_verts"] * 0.6, offsets=assets["iss_offsets"], family="iss", time_shift=None))
         if two_center is not None:                                                       # ctlp.py:751-776
             time_shift = config.get("planet_two_time_shift") if one_center is not None else None  # scene.py:276
             period2 = one_period if time_shift is not None else (config.get("planet_two_period") or 5.0)
@@ -489,7 +502,7 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
                               euler=config.get("planet_two_euler_angles") if config.get("planet_two_euler_angles")
                               is not None else [-0.35, 0, 0],
                               period=period2, rotations=4, default_orn=np.array([0.0, 0.0, 0.0, 1.0]),
-                              verts=assets["asteroid_verts"], offsets=assets["asteroid_offsets"],
+                              verts=assets["asteroid_verts"], offsets=assets["asteroid_offsets"], family="asteroid",
                               time_shift=time_shift))
         if len(specs) > MAX_PLANETS:
             raise ValueError("too many planets")
@@ -500,7 +513,7 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
             pl = s.planet[p]
             first = None
             for i in range(len(sp["offsets"]) - 1):
-                idx = add_piece(sp["verts"][sp["offsets"][i]:sp["offsets"][i + 1]])
+                idx = add_piece(sp["verts"][sp["offsets"][i]:sp["offsets"][i + 1]], _piece_adj(assets, sp["family"], i))
                 first = idx if first is None else first
             pl.piece_begin, pl.piece_count = first, len(sp["offsets"]) - 1
             pl.n_orbit = len(pose)
@@ -579,5 +592,16 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     s.verts = b.verts.ctypes.data_as(C.POINTER(C.c_double))
     s.pieces = C.cast(arr, C.POINTER(Piece))
     s.n_verts = len(b.verts)
+    # hull adjacency (CSR over all vertices, neighbour ids local to the piece): the support search of the HIP
+    # library climbs along it instead of scanning the hull
+    offs, ids = [np.zeros(1, dtype=np.int32)], []
+    for o, a in adj_blocks:
+        offs.append(np.asarray(o[1:], dtype=np.int32) + offs[-1][-1])
+        ids.append(np.asarray(a, dtype=np.int32))
+    b.adj_offsets = np.ascontiguousarray(np.concatenate(offs), dtype=np.int32)
+    b.adj = np.ascontiguousarray(np.concatenate(ids), dtype=np.int32)
+    assert len(b.adj_offsets) == s.n_verts + 1
+    s.adj_offsets = b.adj_offsets.ctypes.data_as(C.POINTER(C.c_int32))
+    s.adj = b.adj.ctypes.data_as(C.POINTER(C.c_int32))
     s.n_pieces = len(pieces)
     return b

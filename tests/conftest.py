@@ -23,3 +23,9 @@ def built():
 def space_scene(built):
     from safemotionsrisk_amd.scene import build_scene, SPACE_ENV_CONFIG
     return build_scene(SPACE_ENV_CONFIG, auto_reset=False)
+
+
+@pytest.fixture(scope="session")
+def ball_scene(built):
+    from safemotionsrisk_amd.scene import build_scene, BALL_ENV_CONFIG
+    return build_scene(BALL_ENV_CONFIG, auto_reset=False)

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdio>
 #include <algorithm>
 #define __device__
 #define __forceinline__ inline
@@ -17,7 +18,9 @@ static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); ret
 static inline void sincosf_(float x, float *s, float *c) { *s = std::sin(x); *c = std::cos(x); }
 #define sincosf sincosf_
 #include <math.h>
+#include "../../include/smr_scene.h"
 #include "../../safemotionsrisk_amd/csrc/smr_device.h"
+#include "../../safemotionsrisk_amd/csrc/smr_tables.h"
 using namespace smr;
 
 extern "C" {
@@ -38,8 +41,9 @@ float emul_gjk(const float *va, int na, const float *vb, int nb, const float *Rb
     if (!identity_a) ca = apply(XA, ca);
     cb = apply(XB, cb);
     F3 d = ca - cb;
-    if (identity_a) return gjk_distance<true>((const float *)verts, A, XA, B, XB, d, cutoff, stop_below);
-    return gjk_distance<false>((const float *)verts, A, XA, B, XB, d, cutoff, stop_below);
+    const ScanHull hb{(const float *)verts, B.begin, B.count};
+    if (identity_a) return gjk_distance<true>((const float *)verts, A, XA, hb, XB, d, cutoff, stop_below);
+    return gjk_distance<false>((const float *)verts, A, XA, hb, XB, d, cutoff, stop_below);
 }
 void emul_safe_acc_range(double plo, double phi, double V, double A, double J, double dt, float p, float v, float a, float *lo, float *hi, int *code) {
     JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f};
@@ -52,7 +56,7 @@ void emul_safe_acc_range(double plo, double phi, double V, double A, double J, d
 #include <vector>
 struct HostScene {
     DScene d;
-    std::vector<float4> verts; std::vector<DPiece> pieces; std::vector<float> pose[2], local[2];
+    HostGeometry G; std::vector<float> pose[2], local[2];
 };
 static void cp(float *dst, const double *src, int n) { for (int i = 0; i < n; ++i) dst[i] = (float)src[i]; }
 extern "C" void *emul_scene_create(const smr_scene_t *sp) {
@@ -65,21 +69,8 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
     cp(d.pos_lo, s.pos_lo, 7); cp(d.pos_hi, s.pos_hi, 7); cp(d.vel_max, s.vel_max, 7); cp(d.acc_max, s.acc_max, 7); cp(d.jerk_max, s.jerk_max, 7);
     cp(d.base, s.base_xyz, 3); cp(d.ee_offset, s.ee_offset, 3);
     for (int j = 0; j < 7; ++j) { cp(d.joint_xyz[j], s.joint_xyz[j], 3); cp(d.joint_axis[j], s.joint_axis[j], 3); }
-    H->verts.resize(s.n_verts);
-    for (int i = 0; i < s.n_verts; ++i) H->verts[i] = {(float)s.verts[3*i], (float)s.verts[3*i+1], (float)s.verts[3*i+2], 0.f};
-    H->pieces.resize(s.n_pieces);
-    for (int i = 0; i < s.n_pieces; ++i) {
-        const smr_piece_t &p = s.pieces[i]; DPiece &q = H->pieces[i];
-        q.begin = p.vert_begin; q.count = p.vert_count; q.cx = (float)p.center[0]; q.cy = (float)p.center[1]; q.cz = (float)p.center[2]; q.margin = (float)p.margin;
-        float r = 0, hx = 0, hy = 0, hz = 0;
-        for (int k = 0; k < p.vert_count; ++k) {
-            const float4 &v = H->verts[p.vert_begin + k];
-            float dx = v.x - q.cx, dy = v.y - q.cy, dz = v.z - q.cz;
-            r = std::max(r, std::sqrt(dx*dx + dy*dy + dz*dz)); hx = std::max(hx, std::fabs(dx)); hy = std::max(hy, std::fabs(dy)); hz = std::max(hz, std::fabs(dz));
-        }
-        q.radius = r * 1.00001f + 1e-7f; q.hx = hx + 1e-7f; q.hy = hy + 1e-7f; q.hz = hz + 1e-7f;
-    }
-    d.verts = H->verts.data(); d.pieces = H->pieces.data();
+    if (const char *msg = build_host_geometry(s, H->G)) { std::fprintf(stderr, "emul_scene_create: %s\n", msg); delete H; return nullptr; }
+    d.verts = H->G.verts.data(); d.pieces = H->G.pieces.data(); d.span = H->G.span.data(); d.ids4 = H->G.ids4.data(); d.start = H->G.start.data();
     for (int l = 0; l < 8; ++l) d.link_piece[l] = s.link_piece[l];
     d.n_static = s.n_static; for (int i = 0; i < s.n_static; ++i) d.static_piece[i] = s.static_piece[i];
     d.static_mask = s.static_link_mask; d.static_max = (float)s.static_max_distance; d.moving_mask = s.moving_link_mask; d.contact_mask = s.contact_link_mask;
@@ -92,6 +83,7 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
         DPlanet &q = d.planet[p];
         q.piece_begin = pl.piece_begin; q.piece_count = pl.piece_count; q.n_orbit = pl.n_orbit; q.index_shift = pl.index_shift; q.coupled = pl.coupled;
         q.orbit_pose = H->pose[p].data(); q.orbit_local = H->local[p].data();
+        planet_bounds(H->G.pieces, q);
     }
     d.term_moving = s.terminate_on_moving_collision; d.collision_dist = (float)s.collision_distance;
     return H;
@@ -101,6 +93,21 @@ extern "C" void emul_distances(void *h, const float *q, const int *idx, int want
     Sample r = collide_sample(H->d, q, idx, want_dist != 0, want_contact != 0);
     out[0] = r.d_static; out[1] = r.d_moving; out[2] = r.contact ? 1.f : 0.f;
 }
+
+// support of piece `pi` along d (piece frame): climbing result vs exhaustive scan; returns the two dot products
+extern "C" void emul_support_check(void *h, int pi, const float *dir, int warm_start_vertex, float *out /*climb, scan, steps unused*/) {
+    HostScene *H = (HostScene *)h;
+    const DPiece P = load_piece(H->d.pieces, pi);
+    const GlobalHull hull = global_hull(H->d, pi, P);
+    F3 d{dir[0], dir[1], dir[2]};
+    int hint = warm_start_vertex < 0 ? 0 : warm_start_vertex;
+    F3 a = hull.support(d, hint, warm_start_vertex < 0);
+    const ScanHull sc{(const float *)H->d.verts, P.begin, P.count};
+    int dummy = 0;
+    F3 b = sc.support(d, dummy, true);
+    out[0] = dot(a, d); out[1] = dot(b, d); out[2] = (float)hint;
+}
+extern "C" int emul_piece_count(void *h, int pi) { return ((HostScene *)h)->d.pieces[pi].count; }
 
 extern "C" int emul_simplex(float *w /*4x3 in/out*/, int n, float *v_out) {
     F3 a{w[0],w[1],w[2]}, b{w[3],w[4],w[5]}, c{w[6],w[7],w[8]}, d{w[9],w[10],w[11]}, v{0,0,0};

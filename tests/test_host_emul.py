@@ -21,8 +21,9 @@ def emul(request, built):
     """Two builds: without and with FMA contraction (hipcc contracts by default)."""
     lib = LIB.replace(".so", "_%s.so" % request.param)
     flags = ["-ffp-contract=off"] if request.param == "off" else ["-ffp-contract=fast", "-mfma"]
-    dev = os.path.join(HERE, "..", "safemotionsrisk_amd", "csrc", "smr_device.h")
-    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(SRC), os.path.getmtime(dev)):
+    csrc = os.path.join(HERE, "..", "safemotionsrisk_amd", "csrc")
+    deps = [SRC, os.path.join(csrc, "smr_device.h"), os.path.join(csrc, "smr_tables.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", lib, SRC] + flags)
     E = C.CDLL(lib)
     E.emul_scene_create.restype = C.c_void_p
@@ -51,6 +52,28 @@ def test_device_distances_on_host(emul, space_scene):
         if abs(d[2] - 0.02) > 2e-5:
             assert c[2] == d[3]
     assert worst < 2e-6
+
+
+def test_hill_climbing_support_equals_scan(emul, space_scene, ball_scene):
+    """Climbing along the hull's edge graph (the link-hull support of the kernels) reaches the same maximum as the
+    exhaustive scan, for every piece, from the cube-map start and from arbitrary warm starts."""
+    rng = np.random.default_rng(5)
+    emul.emul_support_check.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    for scene in (space_scene, ball_scene):
+        H = C.c_void_p(emul.emul_scene_create(C.cast(scene.pointer(), C.c_void_p)))
+        assert H.value
+        for pi in range(scene.struct.n_pieces):
+            n = emul.emul_piece_count(H, pi)
+            dirs = rng.normal(size=(60, 3)).astype(np.float32)
+            dirs[:6] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float32)
+            dirs[6] *= 1e-6                               # tiny and huge directions
+            dirs[7] *= 1e6
+            for d in dirs:
+                for warm in (-1, int(rng.integers(n))):
+                    out = np.zeros(3, np.float32)
+                    emul.emul_support_check(H, pi, d.ctypes.data_as(C.c_void_p), warm, out.ctypes.data_as(C.c_void_p))
+                    scale = float(np.linalg.norm(d))
+                    assert out[0] >= out[1] - 2e-7 * scale, (pi, d, warm, out)
 
 
 def test_device_acc_range_on_host(emul, space_scene):
