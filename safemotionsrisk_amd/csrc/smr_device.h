@@ -182,6 +182,9 @@ __device__ __forceinline__ float interp_vel(float v0, float a0, float a1, float 
 struct JointLim { float plo, phi, V, A, J, dt, plo_res, phi_res, V_res; };   // *_res: float64 limit - float32 image
 
 constexpr float kNoBound = 3.0e38f;
+#ifndef SMR_CNT
+#define SMR_CNT(i)            // work counters of the host emulation build (tests/host_emul)
+#endif
 
 // largest end acceleration a1 (unclamped) that keeps v <= Vlim forever; -kNoBound if none exists.
 // c = head room when the segment ends with a1 = 0.  For a1 > 0 the profile that lowers a by D per knot
@@ -231,12 +234,14 @@ __device__ __forceinline__ float seg_dmax(float v0, float a0, float a1, float dt
 // holds.  Works on displacements relative to the current position (gap = limit - p0), so float32 resolves the
 // few-micrometre margins that decide the bound near a limit.  Continuous and decreasing in a1.
 __device__ inline float pos_margin(float gap, float v0, float a0, float a1, float Vtol, const JointLim &L) {
+    SMR_CNT(0);
     float dmax = seg_dmax(v0, a0, a1, L.dt);
     float d = seg_disp(v0, a0, a1, L.dt, L.dt);
     float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1;
     const float D = L.J * L.dt;
     for (int it = 0; it < 4096; ++it) {
         if (v <= 0.f && a <= 0.f) break;
+        SMR_CNT(1);
         if (dmax > gap + 1.0f) break;                           // hopeless (also bounds the loop for absurd inputs)
         float floor_v = -vel_upper_a1max(-v, -a, L.V, Vtol, L);
         float an = fmaxf(fmaxf(a - D, -L.A), fminf(floor_v, fminf(a + D, L.A)));
@@ -252,34 +257,74 @@ __device__ __forceinline__ bool pos_upper_ok(float gap, float v0, float a0, floa
     return pos_margin(gap, v0, a0, a1, Vtol, L) >= 0.f;
 }
 
-constexpr int kRootIters = 48;
-
-// largest a1 in [lo, hi] with pos_margin >= 0 (the margin decreases with a1): regula falsi (Illinois) steps,
-// with a bisection step whenever the previous step failed to halve the bracket - the margin is flat where the
-// first segment decides and steep where the braking phase does, and pure regula falsi creeps along such a kink.
-// The answer is taken from the feasible end.  (The float64 oracle bisects.)
-__device__ inline float pos_upper_end(float gap, float v, float a, float Vtol, const JointLim &L, float lo, float hi, bool &infeasible) {
+// Largest a1 in [lo, hi] with pos_margin >= 0, where pos_margin(hi) < 0 is known and the margin decreases with
+// a1; `infeasible` when not even lo qualifies.  Cooperative k-section: the lanes of a SEGMENT of W adjacent lanes
+// (W = 64: the wavefront; 8: one reset group; 1: a lone lane = plain bisection, the host emulation) share the work of
+// the segment's n open brackets - about one lane in ten needs one, the rest would idle through its ~25 bisection
+// steps.  Each bracket gets k = W/n helpers (a power of two) that evaluate k points of it per round, so it shrinks
+// (k+1)-fold per round: 4 rounds with 64 helpers, 8 with 8.  The answer is the largest evaluated feasible point, so
+// pos_margin(result) >= 0 exactly as with bisection (the float64 oracle bisects), and the two agree to the bracket
+// tolerance 2e-7 A.  All W lanes of a segment must call this together.
+template <int W>
+__device__ inline float coop_pos_upper_end(bool need, float gap, float v, float a, float lo, float hi, float Vtol, const JointLim &L,
+                                           bool &infeasible) {
+    const int lane = W > 1 ? (int)__lane_id() : 0;
+    const int seg_base = W >= 64 ? 0 : (lane & ~(W - 1));
+    const int r = lane - seg_base;
+    const unsigned long long segmask = W >= 64 ? ~0ull : ((1ull << W) - 1ull);
+    const unsigned long long needs = (__ballot(need) >> seg_base) & segmask;
+    const int n = __popcll(needs);
     infeasible = false;
-    float fhi = pos_margin(gap, v, a, hi, Vtol, L);
-    if (fhi >= 0.f) return hi;
-    float flo = pos_margin(gap, v, a, lo, Vtol, L);
-    if (flo < 0.f) { infeasible = true; return lo; }
-    const float xtol = 2e-7f * L.A;
-    int side = 0;
-    bool bisect = false;
-    for (int it = 0; it < kRootIters && hi - lo > xtol; ++it) {
-        const float w = hi - lo;
-        float x = (flo * hi - fhi * lo) / (flo - fhi);          // flo >= 0 > fhi
-        if (bisect || !(x > lo && x < hi)) x = 0.5f * (lo + hi);
-        float fx = pos_margin(gap, v, a, x, Vtol, L);
-        if (fx >= 0.f) { lo = x; flo = fx; if (side == 1) fhi *= 0.5f; side = 1; }
-        else { hi = x; fhi = fx; if (side == -1) flo *= 0.5f; side = -1; }
-        bisect = (hi - lo) > 0.5f * w;
+    if (n == 0) return lo;                                        // uniform over the segment
+    int k = 1;
+    while (2 * k * n <= W) k *= 2;
+    const unsigned long long kmask = k >= 64 ? ~0ull : ((1ull << k) - 1ull);
+    const int t = r / k, sub = r % k;                             // this lane evaluates point `sub` of bracket t
+    const bool helper = t < n;
+    unsigned long long m = needs;
+    for (int i = 0; i < t && m; ++i) m &= m - 1;                  // owner of bracket t = t-th set bit of needs
+    const int owner = seg_base + ((helper && m) ? __ffsll((long long)m) - 1 : 0);
+    const float tg = __shfl(gap, owner), tv = __shfl(v, owner), ta = __shfl(a, owner), tvtol = __shfl(Vtol, owner);
+    float tlo = __shfl(lo, owner), thi = __shfl(hi, owner);
+    JointLim TL = L;
+    TL.V = __shfl(L.V, owner); TL.A = __shfl(L.A, owner); TL.J = __shfl(L.J, owner); TL.V_res = __shfl(L.V_res, owner);
+    const float xtol = 2e-7f * TL.A;
+    bool tinf = false;
+    for (int round = 0; round < 48; ++round) {
+        const bool live = helper && !tinf && (round == 0 || thi - tlo > xtol);
+        if (((__ballot(live) >> seg_base) & segmask) == 0ull) break;          // uniform over the segment
+        // round 0 includes lo itself (its feasibility is not known yet): points lo + w s/k; later rounds the k interior points
+        const float w = thi - tlo, den = round == 0 ? 1.0f / (float)k : 1.0f / (float)(k + 1);
+        const int first = round == 0 ? 0 : 1;
+        const float x = tlo + w * ((float)(sub + first) * den);
+        const bool feas = live && pos_margin(tg, tv, ta, x, tvtol, TL) >= 0.f;
+        const unsigned long long fb = (__ballot(feas) >> seg_base) & segmask;
+        const unsigned long long bits = (fb >> (t * k)) & kmask;
+        const int c = bits == kmask ? k : __ffsll((long long)~bits) - 1;       // leading feasible points
+        if (live) {
+            // evaluated points have indices first .. k-1+first; index 0 is tlo and index k (k+1 after round 0) is thi
+            if (round == 0 && c == 0) tinf = true;                                   // lo itself violates the limit
+            else {
+                const float nlo = tlo + w * ((float)(c + first - 1) * den);          // last feasible point (bitwise the x of its helper)
+                const float nhi = c < k ? tlo + w * ((float)(c + first) * den) : thi;
+                if (c > 0) tlo = nlo;
+                thi = nhi;
+            }
+        }
     }
-    return lo;
+    // hand the result to the owners: bracket of the owner with rank q among the needs sits in lanes q k .. q k + k - 1
+    const int rank = __popcll(needs & ((1ull << r) - 1ull));
+    const int src = seg_base + ((need ? rank : 0) * k);
+    const float res = __shfl(tlo, src);
+    const int rinf = __shfl((int)tinf, src);
+    infeasible = need && rinf != 0;
+    return need ? res : lo;
 }
 
-__device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v, float a, float &lo, float &hi, int &code) {
+// W: cooperation width (see coop_pos_upper_end); `want`: this lane's result is used (a lane that only tags along,
+// e.g. the eighth lane of a reset group, opens no bracket).  All W lanes of a segment must call this together.
+template <int W>
+__device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v, float a, float &lo, float &hi, int &code, bool want = true) {
     const float D = L.J * L.dt;
     float blo = fmaxf(-L.A, a - D), bhi = fminf(L.A, a + D);
     if (blo > bhi) blo = bhi = fminf(fmaxf(a, -L.A), L.A);
@@ -292,15 +337,27 @@ __device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v,
     if (lv > bhi) { if (-vel_upper_a1max(-v, -a, L.V, vrep, L) > bhi) code |= 1; lv = bhi; }
     float vlo = fmaxf(blo, lv), vhi = fminf(bhi, uv);
     if (vlo > vhi) { code |= 4; vlo = vhi = 0.5f * (vlo + vhi); }
-    bool inf;
     // exact for p near the limit (Sterbenz) + the part of the float64 limit that float32 cannot hold
     const float gap_hi = (L.phi - p) + L.phi_res, gap_lo = (p - L.plo) - L.plo_res;
-    float up = pos_upper_end(gap_hi + ptol, v, a, vtol, L, vlo, vhi, inf);
-    if (inf && !pos_upper_ok(gap_hi + prep, v, a, vlo, vtol, L)) code |= 2;
-    float lp = -pos_upper_end(gap_lo + ptol, -v, -a, vtol, L, -vhi, -vlo, inf);
-    if (inf && !pos_upper_ok(gap_lo + prep, -v, -a, -vhi, vtol, L)) code |= 2;
+    // a bracket is open on a side when the far end of [vlo, vhi] violates that position limit (lower side: mirrored)
+    const bool need_up = want && pos_margin(gap_hi + ptol, v, a, vhi, vtol, L) < 0.f;
+    const bool need_dn = want && pos_margin(gap_lo + ptol, -v, -a, -vlo, vtol, L) < 0.f;
+    float up = vhi, dn = -vlo;                                    // dn: mirrored lower end
+    bool inf_up = false, inf_dn = false;
+    {   // first pass: every lane's first open side; second pass: the lanes with both sides open (rare)
+        const bool first_up = need_up, any_need = need_up || need_dn;
+        bool inf1;                                                // ONE call site: the segment's lanes must arrive together
+        const float r1 = coop_pos_upper_end<W>(any_need, (first_up ? gap_hi : gap_lo) + ptol, first_up ? v : -v, first_up ? a : -a,
+                                               first_up ? vlo : -vhi, first_up ? vhi : -vlo, vtol, L, inf1);
+        if (first_up) { up = r1; inf_up = inf1; } else if (need_dn) { dn = r1; inf_dn = inf1; }
+        bool inf2;
+        const float r2 = coop_pos_upper_end<W>(need_up && need_dn, gap_lo + ptol, -v, -a, -vhi, -vlo, vtol, L, inf2);
+        if (need_up && need_dn) { dn = r2; inf_dn = inf2; }
+    }
+    if (inf_up && !pos_upper_ok(gap_hi + prep, v, a, vlo, vtol, L)) code |= 2;
+    if (inf_dn && !pos_upper_ok(gap_lo + prep, -v, -a, -vhi, vtol, L)) code |= 2;
     hi = up;
-    lo = lp;
+    lo = -dn;
     if (lo > hi) {
         code |= 4;
         float mid = 0.5f * (lo + hi);
@@ -442,9 +499,9 @@ struct ClimbHull {
 using GlobalHull = ClimbHull<const SMR_GLOBAL float *, const SMR_GLOBAL uint32_t *, const SMR_GLOBAL uint8_t *>;
 using LocalHull = ClimbHull<const float *, const uint32_t *, const uint8_t *>;      // LDS copy (collide kernel)
 
-__device__ __forceinline__ DPiece load_piece(const DPiece *pieces, int idx) {
+template <class WP>
+__device__ __forceinline__ DPiece piece_from_words(WP w) {
     static_assert(sizeof(DPiece) == 4 * kPieceDwords, "DPiece is read as dwords");
-    const SMR_CONST int *w = (const SMR_CONST int *)pieces + kPieceDwords * (size_t)__builtin_amdgcn_readfirstlane(idx);
     DPiece P;
     P.begin = w[0]; P.count = w[1];
     P.cx = __int_as_float(w[2]); P.cy = __int_as_float(w[3]); P.cz = __int_as_float(w[4]); P.radius = __int_as_float(w[5]);
@@ -455,6 +512,14 @@ __device__ __forceinline__ DPiece load_piece(const DPiece *pieces, int idx) {
         for (int c = 0; c < 3; ++c) P.in[i][c] = __int_as_float(w[10 + 3 * i + c]);
     P.ids_begin = w[19]; P.ids_count = w[20];
     return P;
+}
+// idx is wave uniform: scalar loads
+__device__ __forceinline__ DPiece load_piece(const DPiece *pieces, int idx) {
+    return piece_from_words((const SMR_CONST int *)pieces + kPieceDwords * (size_t)__builtin_amdgcn_readfirstlane(idx));
+}
+// idx may differ between lanes (reset / spawn: lane g of a group works link g)
+__device__ __forceinline__ DPiece load_piece_lane(const DPiece *pieces, int idx) {
+    return piece_from_words((const SMR_GLOBAL int *)pieces + kPieceDwords * (size_t)idx);
 }
 
 // the link hull of piece index pi (already loaded as P) read from the global tables
@@ -558,7 +623,7 @@ template <bool IDENTITY, class HB>
 __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece &A, const Xf &XA, const HB &hb,
                                      const Xf &XB, F3 v, float cutoff, float stop_below) {
     F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
-    int n = 0, hint = 0;
+    int n = 0, hint = 0, stalls = 0;
     float vv = dot(v, v);
     const float cutoff2 = cutoff * cutoff, stop2 = stop_below > 0.f ? stop_below * stop_below : 0.f;
     for (int it = 0; it < 32; ++it) {
@@ -586,8 +651,16 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
         F3 vn;
         if (simplex_solve(w0, w1, w2, w3, n, vn)) return 0.f;                // origin inside the simplex
         float vvn = dot(vn, vn);
+#ifdef SMR_HOST_EMUL_TRACE
+        printf("  solved: n %d vvn %.9g vn=(%.7g %.7g %.7g) w0=(%.7g %.7g %.7g) w1=(%.7g %.7g %.7g) w2=(%.7g %.7g %.7g)\n", n, vvn, vn.x, vn.y, vn.z, w0.x, w0.y, w0.z, w1.x, w1.y, w1.z, w2.x, w2.y, w2.z);
+#endif
         if (!(vvn == vvn)) break;                                            // degenerate sub-simplex: keep the last valid v
-        if (it > 0 && vvn >= vv) break;                                      // no progress (rounding)
+        // No measurable progress.  Worse than rounding explains: keep the last v.  Equal within rounding: the new
+        // vertex helped by less than float32 resolves (it is far from the current feature); the slightly turned
+        // direction may still find the vertex that does, so go on - a few times.
+        if (it > 0 && vvn >= vv) {
+            if (vvn > vv * (1.0f + 4e-7f) || ++stalls > 3) break;
+        }
         v = vn;
         vv = vvn;
         if (vv <= stop2) break;

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,16 +27,18 @@ namespace smr {
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// one lane per (env, joint): 7x the wavefronts of a lane-per-env launch (the bisection loops diverge)
+// one lane per (env, joint); the lanes of a wavefront share the root finding of its open position-limit brackets
 __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions) {
     const DScene &S = *Sp;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S.B) return;
     const int B = S.B;
+    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e0 < B;                          // the wavefront searches its open brackets together: no lane leaves early
+    const int e = live ? e0 : B - 1;
     const int j = blockIdx.y;
     float lo, hi;
     int code;
-    safe_acc_range_joint(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code);
+    safe_acc_range_joint<64>(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code, live);
+    if (!live) return;
     float u = actions[(size_t)e * SMR_NJ + j];
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
 }
@@ -236,29 +239,81 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     }
 }
 
+// ---- reset / spawn helpers: one rejection-sampling job is worked by a GROUP of 8 adjacent lanes, lane g = iiwa_link_g
+// for every geometric test (its own FK chain, its own link hull, one GJK), lanes 0..6 = joint g for the kinematics.
+// Candidates are tried one after the other exactly as the reference does (about 9 of 10 start positions and 19 of
+// 20 planet phases are accepted at once), so the critical path of a candidate is one link's test, not eight.
+struct Group {
+    int g, gbase;
+    __device__ __forceinline__ unsigned ballot(bool pred) const { return (unsigned)((__ballot(pred) >> gbase) & 0xFFull); }
+    __device__ __forceinline__ bool all(bool pred) const { return ballot(pred) == 0xFFu; }
+    __device__ __forceinline__ bool any(bool pred) const { return ballot(pred) != 0u; }
+    // lane j of the group holds x_j: gather the 7 joint values
+    __device__ __forceinline__ void gather(float x, float q[SMR_NJ]) const {
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) q[j] = __shfl(x, gbase + j);
+    }
+};
+
+__device__ __forceinline__ Xf link_frame(const DScene &S, const float q[SMR_NJ], int l) {
+    Xf T = fk_base(S);
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j)
+        if (j < l) fk_advance(S, j, q[j], T);
+    return T;
+}
+
+// table clearance of ONE link (ctlp.py:2140-2168, 1605-1619; self-collision: no pairs for one iiwa)
+__device__ inline bool link_table_free(const DScene &S, int l, const Xf &T, float thr) {
+    if (!((S.static_mask >> l) & 1u)) return true;
+    const int pl = S.link_piece[l];
+    const DPiece LP = load_piece_lane(S.pieces, pl);
+    const GlobalHull hull = global_hull(S, pl, LP);
+    bool ok = true;
+    for (int s = 0; s < S.n_static; ++s) {
+        float d = piece_distance<true>(S, S.static_piece[s], T, LP, hull, T, thr + 0.005f, 0.f);
+        if (d <= thr + 0.005f && d < thr) ok = false;
+    }
+    return ok;
+}
+
 // A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138, for one candidate q.  box / thr: cartesian
 // range of the end-effector point and minimum table distance (start states ctlp.py:172-183,1468-1477; ball
 // targets ctlp.py:191-229,1725-1726).  (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is outside
 // the kinematic path.)
-__device__ inline bool pose_is_valid(const DScene &S, const float q[SMR_NJ], const float box[3][2], float thr) {
-    Xf T = fk_base(S), I = T;
-    bool ok = true;
-    for (int l = 0; l < SMR_NLINK; ++l) {
-        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
-        if (ok && ((S.static_mask >> l) & 1u)) {
-            for (int s = 0; s < S.n_static; ++s) {                                        // ctlp.py:2140-2168
-                const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
-                float d = piece_distance<true>(S, S.static_piece[s], I, LP, global_hull(S, S.link_piece[l], LP), T, thr + 0.005f, 0.f);
-                if (d <= thr + 0.005f && d < thr) ok = false;
-            }
-        }
+__device__ inline bool group_pose_valid(const DScene &S, const Group &G, const float q[SMR_NJ], const float box[3][2], float thr) {
+    const Xf T = link_frame(S, q, G.g);
+    bool ok = link_table_free(S, G.g, T, thr);
+    if (G.g == SMR_NLINK - 1) {
+        F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});                // ctlp.py:2051-2061
+        if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) ok = false;
     }
-    F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});                // ctlp.py:2051-2061
-    if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) ok = false;
-    return ok;
+    return G.all(ok);
 }
 
-__device__ inline bool position_is_valid(const DScene &S, const float q[SMR_NJ]) { return pose_is_valid(S, q, S.start_box, S.start_min_static); }
+__device__ inline bool group_table_free(const DScene &S, const Group &G, const float q[SMR_NJ]) {
+    return G.all(link_table_free(S, G.g, link_frame(S, q, G.g), S.start_min_static));
+}
+
+// Bullet contact between any planet piece and any robot link (Planet.check_if_object_is_colliding, ctlp.py:4570-4579)
+__device__ inline bool group_planet_contact(const DScene &S, const Group &G, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS]) {
+    const int pl = S.link_piece[G.g];
+    const DPiece LP = load_piece_lane(S.pieces, pl);
+    const Sample r = collide_link(S, G.g, LP, global_hull(S, pl, LP), link_frame(S, q, G.g), idx, nullptr, false, false, true);
+    return G.any(r.contact);
+}
+
+// is the ball (pose XB) within Bullet's contact distance of any robot link? (Ball.check_if_object_is_colliding, ctlp.py:4186-4194)
+__device__ inline bool group_ball_contact(const DScene &S, const Group &G, const float q[SMR_NJ], const Xf &XB) {
+    bool contact = false;
+    if ((S.contact_mask >> G.g) & 1u) {
+        const int pl = S.link_piece[G.g];
+        const DPiece LP = load_piece_lane(S.pieces, pl);
+        float d = piece_distance<false>(S, S.ball_piece, XB, LP, global_hull(S, pl, LP), link_frame(S, q, G.g), S.contact_dist, S.contact_dist);
+        contact = d <= S.contact_dist;
+    }
+    return G.any(contact);
+}
 
 // end-effector point in float64 (the ball is aimed at it; its launch arithmetic runs in float64 so that the
 // integer update counters derived from it agree with the oracle)
@@ -294,10 +349,10 @@ __device__ inline double ball_height_time(double h0, double vz, double target, d
 
 struct BallSpawn { float p0[3], v0[3], e0[3], omega; int kmax, khit; };
 
-// _add_moving_object, ctlp.py:1723-1931, by a group of 8 lanes: 8 candidate target poses per round, first valid
-// one wins; the scalar launch arithmetic is computed redundantly by all lanes, in float64.
-__device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, int g, int gbase) {
-    auto gballot = [&](bool pred) -> unsigned { return (unsigned)((__ballot(pred) >> gbase) & 0xFFull); };
+// _add_moving_object, ctlp.py:1723-1931, by a group of 8 lanes: candidate target poses one after the other, each
+// tested link-parallel; the scalar launch arithmetic is computed redundantly by all lanes, in float64.
+__device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, const Group &G) {
+    const int jj = G.g < SMR_NJ ? G.g : 0;
     const double udt = S.dt64 / S.updates_per_step, v = S.ball_speed, grav = 9.81;
     double rel[3] = {0, 0, 0}, vel[3] = {0, 0, 1};
     unsigned pose_attempt = 0;
@@ -307,21 +362,11 @@ __device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, in
         const double ang = rng.uniformd(S_BALL_RELEASE, 3u * n + 1u, S.ball_angle[0], S.ball_angle[1]);
         rel[0] = S.ball_center[0] + r * cos(ang); rel[1] = S.ball_center[1] + r * sin(ang); rel[2] = S.ball_center[2] + h;
         double target[3] = {0, 0, 0};
-        for (int round = 0; round < 3125; ++round) {                                                        // ctlp.py:1782-1790
-            const unsigned m = pose_attempt + (unsigned)g;
+        for (int tries = 0; tries < 25000; ++tries) {                                                       // ctlp.py:1782-1790
             float q[SMR_NJ];
-#pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S_BALL_POSE, 7u * m + j, S.pos_lo[j], S.pos_hi[j]);
-            const unsigned mask = gballot(pose_is_valid(S, q, S.ball_target_box, S.ball_target_min_static));
-            if (mask) {
-                const int f = __ffs((int)mask) - 1;
-#pragma unroll
-                for (int j = 0; j < SMR_NJ; ++j) q[j] = __shfl(q[j], gbase + f);
-                ee_point_f64(S, q, target);
-                pose_attempt += (unsigned)f + 1u;
-                break;
-            }
-            pose_attempt += 8u;
+            G.gather(rng.uniform(S_BALL_POSE, 7u * pose_attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
+            ++pose_attempt;
+            if (group_pose_valid(S, G, q, S.ball_target_box, S.ball_target_min_static)) { ee_point_f64(S, q, target); break; }
         }
         const double dx = target[0] - rel[0], dy = target[1] - rel[1], dh = target[2] - rel[2];
         const double dxy = sqrt(dx * dx + dy * dy);
@@ -413,21 +458,6 @@ __device__ inline void store_ball(const DState &st, int B, int e, const BallSpaw
     st.ball_i[e] = k; st.ball_i[B + e] = b.kmax; st.ball_i[2 * B + e] = b.khit; st.ball_i[3 * B + e] = 1; st.ball_i[4 * B + e] = (int)spawns;
 }
 
-// is the ball (pose XB) within Bullet's contact distance of any robot link? (Ball.check_if_object_is_colliding, ctlp.py:4186-4194)
-__device__ inline bool ball_contact_all_links(const DScene &S, const float q[SMR_NJ], const Xf &XB) {
-    Xf T = fk_base(S);
-    bool contact = false;
-    for (int l = 0; l < SMR_NLINK; ++l) {
-        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
-        if (!contact && ((S.contact_mask >> l) & 1u)) {
-            const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
-            float d = piece_distance<false>(S, S.ball_piece, XB, LP, global_hull(S, S.link_piece[l], LP), T, S.contact_dist, S.contact_dist);
-            if (d <= S.contact_dist) contact = true;
-        }
-    }
-    return contact;
-}
-
 // a new ball for the envs whose ball was retired in this step (get_moving_object_observation, ctlp.py:2354-2360)
 __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp, DState st, int group_stride, float *__restrict__ obs) {
     const DScene &S = *Sp;
@@ -438,10 +468,10 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
     if (i >= *st.spawn_count) return;
     const int e = st.spawn_list[i];
     const int B = S.B;
-    const int gbase = (threadIdx.x & 63) & ~7;
+    const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const unsigned spawns = (unsigned)st.ball_i[4 * B + e];
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
-    const BallSpawn b = spawn_ball_group(S, rng, g, gbase);
+    const BallSpawn b = spawn_ball_group(S, rng, G);
     if (g == 0) {
         store_ball(st, B, e, b, 0, spawns + 1u);
         BallState bs;
@@ -451,24 +481,10 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
     }
 }
 
-// table clearance of a configuration (ctlp.py:1605-1619; self-collision: no pairs for one iiwa)
-__device__ inline bool table_free(const DScene &S, const float q[SMR_NJ]) {
-    Xf T = fk_base(S), I = T;
-    bool free_pos = true;
-    for (int l = 0; l < SMR_NLINK; ++l) {
-        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
-        if (free_pos && ((S.static_mask >> l) & 1u))
-            for (int s = 0; s < S.n_static; ++s) {
-                float thr = S.start_min_static;
-                const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
-                float d = piece_distance<true>(S, S.static_piece[s], I, LP, global_hull(S, S.link_piece[l], LP), T, thr + 0.005f, 0.f);
-                if (d <= thr + 0.005f && d < thr) free_pos = false;
-            }
-    }
-    return free_pos;
+static int reset_group_stride() {      // every n-th 8-lane group works (tuning knob SMR_RESET_GROUP_STRIDE: 1, 2, 4 or 8)
+    static const int v = [] { const char *e = std::getenv("SMR_RESET_GROUP_STRIDE"); int x = e ? std::atoi(e) : 4; return (x == 1 || x == 2 || x == 4 || x == 8) ? x : 4; }();
+    return v;
 }
-
-constexpr int kResetGroupStride = 4;   // every 4th 8-lane group works: 2 resets per wavefront
 
 // env.reset() for the envs in list[0..count): obs.py:144-149 -> base.py:913-1022.
 // One reset is worked by a GROUP of 8 adjacent lanes: they evaluate 8 candidate start positions / 8 candidate
@@ -488,50 +504,42 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
     if (i >= count) return;
     const int e = list ? list[i] : i;
     const int B = S.B;
-    const int gbase = (threadIdx.x & 63) & ~7;
-    auto gballot = [&](bool pred) -> unsigned { return (unsigned)((__ballot(pred) >> gbase) & 0xFFull); };
+    const Group G{g, (int)(threadIdx.x & 63) & ~7};
+    const int gbase = G.gbase;
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, st.reset_count[e]};
+    const int jj = g < SMR_NJ ? g : 0;
 
-    // ---- start position: 8 attempts per round, first valid wins (stream S_POS, attempt n = draws 7n..7n+6)
+    // ---- start position: attempts in sequence, each tested link-parallel (stream S_POS, attempt n = draws 7n..7n+6)
     float q[SMR_NJ];
     unsigned attempt = 0;
     auto next_position = [&]() {
-        for (int round = 0; round < 12500; ++round) {
-            const unsigned n = attempt + (unsigned)g;
-#pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S_POS, 7u * n + j, S.pos_lo[j], S.pos_hi[j]);   // ctlp.py:2035-2037
-            const unsigned m = gballot(position_is_valid(S, q));
-            if (m) {
-                const int f = __ffs((int)m) - 1;
-#pragma unroll
-                for (int j = 0; j < SMR_NJ; ++j) q[j] = __shfl(q[j], gbase + f);
-                attempt += (unsigned)f + 1u;
-                return;
-            }
-            attempt += 8u;
+        for (int tries = 0; tries < 100000; ++tries) {
+            G.gather(rng.uniform(S_POS, 7u * attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);               // ctlp.py:2035-2037
+            ++attempt;
+            if (group_pose_valid(S, G, q, S.start_box, S.start_min_static)) return;
         }
     };
     next_position();
 
     // ---- joint velocity / acceleration.  After this block lane j (< 7) holds joint j in (qj, vj, aj).
     float vj = 0.f, aj = 0.f, qj = 0.f;
-    const int jj = g < SMR_NJ ? g : 0;
     const JointLim L = joint_lim(S, jj);
     if (S.kin_mode && rng.uniform01(S_MODE, 0) < S.kin_prob) {                          // ctlp.py:1494-1556
         for (unsigned round = 0;; ++round) {
             bool found = (g >= SMR_NJ);
             const float qme = q[jj];
-            for (unsigned tv = 0; tv < 5 && !found; ++tv) {
+            // the group walks the 5 x 10 (velocity, acceleration) tries in lockstep; a lane that has its pair tags along
+            for (unsigned tv = 0; tv < 5 && !G.all(found); ++tv) {
                 const float vt = rng.uniform(S_JOINT + jj, round * 55u + tv * 11u, -L.V, L.V);
-                for (unsigned ta = 0; ta < 10 && !found; ++ta) {
+                for (unsigned ta = 0; ta < 10 && !G.all(found); ++ta) {
                     const float at = rng.uniform(S_JOINT + jj, round * 55u + tv * 11u + 1u + ta, -L.A, L.A);
                     float lo, hi;
                     int code;
-                    safe_acc_range_joint(L, qme, vt, at, lo, hi, code);
-                    if (code == 0) { found = true; vj = vt; aj = at; }
+                    safe_acc_range_joint<8>(L, qme, vt, at, lo, hi, code, !found);
+                    if (!found && code == 0) { found = true; vj = vt; aj = at; }
                 }
             }
-            if (gballot(found) == 0xFFu) break;
+            if (G.all(found)) break;
             next_position();                                                            // ctlp.py:1547-1556
         }
         qj = q[jj];
@@ -547,15 +555,14 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
                         ca = cur == 0 ? ha0 : cur == 1 ? ha1 : ha2;
             float lo, hi;
             int code;
-            safe_acc_range_joint(L, cq, cv, ca, lo, hi, code);
+            safe_acc_range_joint<8>(L, cq, cv, ca, lo, hi, code, g < SMR_NJ);
             const float u = rng.uniform(S_WALK, w + (unsigned)jj, -1.f, 1.f);
             w += SMR_NJ;
             const float na = lo + 0.5f * (u + 1.f) * (hi - lo);
             const float nv = interp_vel(cv, ca, na, S.dt, S.dt), nq = interp_pos(cq, cv, ca, na, S.dt, S.dt);
             float nqv[SMR_NJ];
-#pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) nqv[j] = __shfl(nq, gbase + j);
-            if (table_free(S, nqv)) {
+            G.gather(nq, nqv);
+            if (group_table_free(S, G, nqv)) {
                 if (nxt == 0) { hq0 = nq; hv0 = nv; ha0 = na; } else if (nxt == 1) { hq1 = nq; hv1 = nv; ha1 = na; } else { hq2 = nq; hv2 = nv; ha2 = na; }
                 ++cnt;
             } else {
@@ -568,20 +575,17 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         qj = cur == 0 ? hq0 : cur == 1 ? hq1 : hq2;
         vj = cur == 0 ? hv0 : cur == 1 ? hv1 : hv2;
         aj = cur == 0 ? ha0 : cur == 1 ? ha1 : ha2;
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) q[j] = __shfl(qj, gbase + j);
+        G.gather(qj, q);
     }
 
-    // ---- planet phase: 8 candidate phases per round, first contact-free one wins (ctlp.py:4470-4501)
+    // ---- planet phase: candidate phases in sequence, first contact-free one wins (ctlp.py:4470-4501)
     int idx[SMR_MAX_PLANETS] = {0, 0};
     int hit = 0;
     if (S.n_planets > 0) {
         int n_indep = 0;
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p) n_indep += (p < S.n_planets && !S.planet[p].coupled) ? 1 : 0;
-        unsigned base = 0;
-        for (int round = 0; round < 12500; ++round) {
-            const unsigned n = base + (unsigned)g;
+        for (unsigned n = 0; n < 100000u; ++n) {
             int k = 0;
 #pragma unroll
             for (int p = 0; p < SMR_MAX_PLANETS; ++p) {
@@ -590,35 +594,24 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
                 if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % no + no) % no;
                 else idx[p] = rng.randint(S_PLANET, n * (unsigned)n_indep + (unsigned)(k++), no);
             }
-            const Sample r = collide_sample(S, q, idx, false, true);
-            const unsigned m = gballot(!r.contact);
-            if (m) {
-                const int f = __ffs((int)m) - 1;
-                idx[0] = __shfl(idx[0], gbase + f);
-                idx[1] = __shfl(idx[1], gbase + f);
-                break;
-            }
-            base += 8u;
+            if (!group_planet_contact(S, G, q, idx)) break;
         }
         // obstacle_wrapper.update(update_after_reset=True): one planet update + contact check,
         // base.py:980-985, ctlp.py:2626-2637
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (idx[p] + 1) % S.planet[p].n_orbit;
-        if (S.term_moving) {
-            const Sample r = collide_sample(S, q, idx, false, true);
-            hit = r.contact ? 1 : 0;
-        }
+        if (S.term_moving) hit = group_planet_contact(S, G, q, idx) ? 1 : 0;
     }
 
-    // ---- ball: spawn + random initial time step, 8 candidate steps per round (ctlp.py:1052-1111)
+    // ---- ball: spawn + random initial time step, candidates in sequence (ctlp.py:1052-1111)
     BallSpawn bsp;
     int ball_k0 = 0;
     unsigned ball_spawns = 0;
     if (S.use_ball) {
         ball_spawns = (unsigned)st.ball_i[4 * B + e];
         const Rng brng = {S.seed_lo, S.seed_hi, (unsigned)e, ball_spawns};
-        bsp = spawn_ball_group(S, brng, g, gbase);
+        bsp = spawn_ball_group(S, brng, G);
         if (S.ball_random_initial) {
             BallState bs;
             for (int c = 0; c < 3; ++c) { bs.p0[c] = bsp.p0[c]; bs.v0[c] = bsp.v0[c]; bs.e0[c] = bsp.e0[c]; }
@@ -626,13 +619,9 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
             int kcap = bsp.kmax < bsp.khit ? bsp.kmax : bsp.khit;
             int max_ts = kcap / S.updates_per_step;
             if (max_ts < 0) max_ts = 0;
-            unsigned base = 0;
-            for (int round = 0; round < 12500; ++round) {
-                const int kc = brng.randint(S_BALL_MISC, 1u + base + (unsigned)g, max_ts + 1) * S.updates_per_step;
-                const Xf XB = ball_pose(S, bs, kc, nullptr);
-                const unsigned m = gballot(!ball_contact_all_links(S, q, XB));
-                if (m) { ball_k0 = __shfl(kc, gbase + __ffs((int)m) - 1); break; }
-                base += 8u;
+            for (unsigned n = 0; n < 100000u; ++n) {
+                ball_k0 = brng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
+                if (!group_ball_contact(S, G, q, ball_pose(S, bs, ball_k0, nullptr))) break;
             }
         }
     }
@@ -698,11 +687,14 @@ __global__ void test_fk_kernel(const DScene *__restrict__ Sp, const float *__res
 __global__ void test_range_kernel(const DScene *__restrict__ Sp, const float *__restrict__ p, const float *__restrict__ v,
                                   const float *__restrict__ a, int n, float *__restrict__ lo, float *__restrict__ hi, int *__restrict__ code) {
     const DScene &S = *Sp;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < n;
+    const int i = live ? i0 : n - 1;
     for (int j = 0; j < SMR_NJ; ++j) {
-        int k = i * SMR_NJ + j;
-        safe_acc_range_joint(joint_lim(S, j), p[k], v[k], a[k], lo[k], hi[k], code[k]);
+        int k = i * SMR_NJ + j, c;
+        float l, h;
+        safe_acc_range_joint<64>(joint_lim(S, j), p[k], v[k], a[k], l, h, c, live);
+        if (live) { lo[k] = l; hi[k] = h; code[k] = c; }
     }
 }
 
@@ -1033,8 +1025,8 @@ static int launch_reset_list(smr_env *env, float *obs_dev) {
     // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
     LaunchTimer t(env, SMR_K_RESET);
     const int B = env->B;
-    hipLaunchKernelGGL(reset_kernel, dim3(((size_t)B * 8 * kResetGroupStride + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
-                       env->st.done_list, env->st.done_count, 0, kResetGroupStride, obs_dev);
+    hipLaunchKernelGGL(reset_kernel, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+                       env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
     SMR_HIP(hipGetLastError());
     return SMR_OK;
 }
@@ -1084,8 +1076,8 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipGetLastError());
     if (env->hscene.use_ball) {
         LaunchTimer t(env, SMR_K_SPAWN);
-        hipLaunchKernelGGL(spawn_kernel, dim3(((size_t)B * 8 * kResetGroupStride + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
-                           kResetGroupStride, obs_dev);
+        hipLaunchKernelGGL(spawn_kernel, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+                           reset_group_stride(), obs_dev);
         SMR_HIP(hipGetLastError());
     }
     if (env->auto_reset) return launch_reset_list(env, obs_dev);

@@ -14,10 +14,17 @@ struct float4 { float x, y, z, w; };
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
 static inline int __popc(int x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }     // a "wavefront" of one lane
+static inline unsigned __lane_id() { return 0u; }
+template <class T> static inline T __shfl(T x, int) { return x; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline void sincosf_(float x, float *s, float *c) { *s = std::sin(x); *c = std::cos(x); }
 #define sincosf sincosf_
 #include <math.h>
+extern "C" { long emul_counters[4] = {0, 0, 0, 0}; }
+#define SMR_CNT(i) (++emul_counters[i])
 #include "../../include/smr_scene.h"
 #include "../../safemotionsrisk_amd/csrc/smr_device.h"
 #include "../../safemotionsrisk_amd/csrc/smr_tables.h"
@@ -48,7 +55,7 @@ float emul_gjk(const float *va, int na, const float *vb, int nb, const float *Rb
 void emul_safe_acc_range(double plo, double phi, double V, double A, double J, double dt, float p, float v, float a, float *lo, float *hi, int *code) {
     JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f};
     L.plo_res = (float)(plo - (double)L.plo); L.phi_res = (float)(phi - (double)L.phi); L.V_res = (float)(V - (double)L.V);
-    safe_acc_range_joint(L, p, v, a, *lo, *hi, *code);
+    safe_acc_range_joint<1>(L, p, v, a, *lo, *hi, *code);
 }
 }
 
@@ -85,6 +92,7 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
         q.orbit_pose = H->pose[p].data(); q.orbit_local = H->local[p].data();
         planet_bounds(H->G.pieces, q);
     }
+    d.use_ball = s.use_ball; d.ball_piece = s.ball_piece; d.ball_radius = (float)s.ball_radius;
     d.term_moving = s.terminate_on_moving_collision; d.collision_dist = (float)s.collision_distance;
     return H;
 }
@@ -108,6 +116,24 @@ extern "C" void emul_support_check(void *h, int pi, const float *dir, int warm_s
     out[0] = dot(a, d); out[1] = dot(b, d); out[2] = (float)hint;
 }
 extern "C" int emul_piece_count(void *h, int pi) { return ((HostScene *)h)->d.pieces[pi].count; }
+
+// ball scene: per-link moving distance (no cut-off sharing between links) for configuration q and the ball after k updates
+extern "C" void emul_ball_link_distances(void *h, const float *q, const float *ball, int k, float *out /*8*/, int use_scan) {
+    HostScene *H = (HostScene *)h;
+    const DScene &S = H->d;
+    BallState b;
+    for (int c = 0; c < 3; ++c) { b.p0[c] = ball[c]; b.v0[c] = ball[3 + c]; b.e0[c] = ball[6 + c]; }
+    b.omega = ball[9];
+    const Xf XB = ball_pose(S, b, k, nullptr);
+    Xf T = fk_base(S);
+    for (int l = 0; l < SMR_NLINK; ++l) {
+        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
+        const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
+        Sample r = use_scan ? collide_link(S, l, LP, ScanHull{(const float *)S.verts, LP.begin, LP.count}, T, nullptr, &XB, false, true, false)
+                            : collide_link(S, l, LP, global_hull(S, S.link_piece[l], LP), T, nullptr, &XB, false, true, false);
+        out[l] = r.d_moving;
+    }
+}
 
 extern "C" int emul_simplex(float *w /*4x3 in/out*/, int n, float *v_out) {
     F3 a{w[0],w[1],w[2]}, b{w[3],w[4],w[5]}, c{w[6],w[7],w[8]}, d{w[9],w[10],w[11]}, v{0,0,0};
