@@ -15,6 +15,11 @@
 
 #include "../../include/safemotions_hip.h"
 
+#ifndef SMR_CNT
+#define SMR_CNT(i)            // work counters of the host emulation build (tests/host_emul)
+#define SMR_CNT_SLOT(i)
+#endif
+
 namespace smr {
 
 // Batch-shared read-only tables are read through the constant address space: with a wave-uniform
@@ -105,6 +110,15 @@ struct DState {
     int *ball_i;               // [5][B]  update counter k, k_max (passed the robot), k_hit (table/ground), active, spawn counter
     int *spawn_list;           // [B]  envs whose ball was retired in this step
     int *spawn_count;          // [1]
+    // staged start states (scenes without a ball): the start state of every env's NEXT episode, prepared off the
+    // critical path on a second stream and committed by the finish kernel when the env is done
+    float *next_q, *next_v, *next_a;   // [7][B]
+    int *next_planet_idx;              // [2][B]
+    int *next_hit;                     // [B]
+    unsigned *staged_tag;              // [B]  reset_count value the staged state belongs to (~0u: none)
+    int *refill_list;                  // [B]  envs whose staged state was consumed
+    int *refill_count;                 // [1]
+    int *stale_commits;                // [1]  commits that found no matching staged state (must stay 0)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -182,9 +196,7 @@ __device__ __forceinline__ float interp_vel(float v0, float a0, float a1, float 
 struct JointLim { float plo, phi, V, A, J, dt, plo_res, phi_res, V_res; };   // *_res: float64 limit - float32 image
 
 constexpr float kNoBound = 3.0e38f;
-#ifndef SMR_CNT
-#define SMR_CNT(i)            // work counters of the host emulation build (tests/host_emul)
-#endif
+
 
 // largest end acceleration a1 (unclamped) that keeps v <= Vlim forever; -kNoBound if none exists.
 // c = head room when the segment ends with a1 = 0.  For a1 > 0 the profile that lowers a by D per knot
@@ -626,7 +638,10 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
     int n = 0, hint = 0, stalls = 0;
     float vv = dot(v, v);
     const float cutoff2 = cutoff * cutoff, stop2 = stop_below > 0.f ? stop_below * stop_below : 0.f;
+    SMR_CNT(2);
     for (int it = 0; it < 32; ++it) {
+        SMR_CNT(3);
+        SMR_CNT(4);
         F3 w = support<IDENTITY>(verts, A.begin, A.count, XA, neg(v)) - apply(XB, hb.support(rot_t(XB, v), hint, it == 0));
         float vw = dot(v, w);
 #ifdef SMR_HOST_EMUL_TRACE
@@ -854,6 +869,7 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
             float cutoff = mov ? fminf(out.d_moving, cut_moving) : S.contact_dist;
             if (con) cutoff = fmaxf(cutoff, S.contact_dist);
             if (plb > cutoff) continue;
+            SMR_CNT_SLOT(pb + c);
             float d = piece_distance<false>(S, pb + c, XP, LP, hull, T, cutoff, stop_moving);
             if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
             if (con && d <= S.contact_dist) out.contact = true;

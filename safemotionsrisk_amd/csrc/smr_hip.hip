@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
 // one lane per (env, sample k, link l); grid = (B/64, N, 8)
 __global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
-    const int l = (int)blockIdx.z;                     // iiwa_link_l
+    const int l = SMR_NLINK - 1 - (int)blockIdx.z;     // iiwa_link_l; the outer links (most planet work) are dispatched first
     // the link's hull, edge graph and start map staged in LDS: every support call of this block climbs over them
     __shared__ float lds_v[4 * kMaxPieceVerts];
     __shared__ uint32_t lds_span[kMaxPieceVerts];
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ 
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
     const int B = S.B, N = S.checks_per_step;
-    const int k = (int)blockIdx.y + 1;                 // sample k of N, t_k = k dt / N
+    const int k = N - (int)blockIdx.y;                 // sample k of N, t_k = k dt / N; the end-of-step sample (distances) first
     const bool final_sample = (k == N);
     const int upd = S.updates_per_step / N;
     float *res = st.res + ((size_t)(k - 1) * SMR_NLINK + l) * B;
@@ -118,9 +118,38 @@ __global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ 
     if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(SMR_NLINK + l) * B + e] = r.d_moving; }
 }
 
+// env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
+__device__ inline void commit_staged(const DScene &S, const DState &st, int e, float *row) {
+    const int B = S.B;
+    const unsigned tag = st.reset_count[e];
+    if (st.staged_tag[e] != tag) atomicAdd(st.stale_commits, 1);          // host checks: never expected
+    float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) {
+        q[j] = st.next_q[j * B + e]; v[j] = st.next_v[j * B + e]; a[j] = st.next_a[j * B + e];
+        st.q[j * B + e] = q[j]; st.v[j * B + e] = v[j]; st.a[j * B + e] = a[j];
+    }
+    int idx[SMR_MAX_PLANETS] = {st.next_planet_idx[e], st.next_planet_idx[B + e]};
+    st.planet_idx[e] = idx[0]; st.planet_idx[B + e] = idx[1];
+    st.step_count[e] = 0;
+    st.moving_hit[e] = st.next_hit[e];
+    st.reset_count[e] = tag + 1u;
+    if (row) write_observation(S, q, v, a, idx, row);
+}
+
+__global__ void commit_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list, const int *__restrict__ count_ptr,
+                              int count_fixed, float *__restrict__ obs) {
+    const DScene &S = *Sp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int count = count_ptr ? *count_ptr : count_fixed;
+    if (i >= count) return;
+    const int e = list ? list[i] : i;
+    commit_staged(S, st, e, obs ? obs + (size_t)e * S.obs_size : nullptr);
+}
+
 __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions,
                                                      float *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ done,
-                                                     int8_t *__restrict__ reason, float *__restrict__ info) {
+                                                     int8_t *__restrict__ reason, float *__restrict__ info, int staged) {
     const DScene &S = *Sp;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
@@ -226,8 +255,11 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     st.moving_hit[e] = hit;
 
     if (S.use_ball) { st.ball_i[e] = ball_k; st.ball_i[3 * B + e] = ball_active; }
-    if (d && S.auto_reset) {
-        int slot = atomicAdd(st.done_count, 1);          // hipcc folds this into one atomic per wave
+    if (d && S.auto_reset && staged) {
+        commit_staged(S, st, e, obs + (size_t)e * S.obs_size);   // next episode's start state was prepared in the background
+        st.refill_list[atomicAdd(st.refill_count, 1)] = e;       // hipcc folds this into one atomic per wave
+    } else if (d && S.auto_reset) {
+        int slot = atomicAdd(st.done_count, 1);
         st.done_list[slot] = e;
     } else {
         float *row = obs + (size_t)e * S.obs_size;
@@ -492,6 +524,9 @@ static int reset_group_stride() {      // every n-th 8-lane group works (tuning 
 // ctlp.py:2030-2138,4477-4490), and lanes 0..6 handle one joint each for the velocity/acceleration tries
 // and the random walk (ctlp.py:1499-1654).  Rejection sampling is a chain of data-dependent loops: latency,
 // not lane count, bounds this kernel, so only every group_stride-th group takes an entry.
+// STAGED: the result goes to the staging arrays (next_*, staged_tag) and nothing of the live env is touched -
+// the kernel then runs on the side stream while the main stream steps the envs (scenes without a ball).
+template <bool STAGED>
 __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                    const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                    float *__restrict__ obs) {
@@ -626,6 +661,11 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         }
     }
 
+    if (STAGED) {
+        if (g < SMR_NJ) { st.next_q[g * B + e] = qj; st.next_v[g * B + e] = vj; st.next_a[g * B + e] = aj; }
+        else { st.next_planet_idx[e] = idx[0]; st.next_planet_idx[B + e] = idx[1]; st.next_hit[e] = hit; st.staged_tag[e] = rng.tag; }
+        return;
+    }
     // ---- write back: lane j < 7 owns joint j, lane 7 the scalars
     float *row = obs ? obs + (size_t)e * S.obs_size : nullptr;
     if (g < SMR_NJ) {
@@ -656,6 +696,12 @@ __global__ void mask_to_list_kernel(const uint8_t *__restrict__ mask, int B, int
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B) return;
     if (mask[e]) list[atomicAdd(count, 1)] = e;
+}
+
+__global__ void iota_list_kernel(int B, int *__restrict__ list, int *__restrict__ count) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < B) list[e] = e;
+    if (e == 0) *count = B;
 }
 
 __global__ void observe_kernel(const DScene *__restrict__ Sp, DState st, float *__restrict__ obs) {
@@ -746,6 +792,9 @@ struct smr_env {
     hipStream_t stream = nullptr;
     int B = 0, obs_size = 0, N = 1;
     int auto_reset = 0;
+    bool staged = false;        // start states are prepared on `side` and committed by finish (no ball in the scene)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_commit = nullptr, ev_refill = nullptr;
     DScene hscene;              // host copy (device pointers inside)
     DScene *dscene = nullptr;
     DState st;
@@ -911,6 +960,9 @@ int smr_destroy(smr_env_t *env) {
     if (!env) return SMR_OK;
     (void)hipSetDevice(env->device);
     (void)hipStreamSynchronize(env->stream);
+    if (env->side) { (void)hipStreamSynchronize(env->side); (void)hipStreamDestroy(env->side); }
+    if (env->ev_commit) (void)hipEventDestroy(env->ev_commit);
+    if (env->ev_refill) (void)hipEventDestroy(env->ev_refill);
     for (auto &p : env->pending) { env->event_pool.push_back(p.a); env->event_pool.push_back(p.b); }
     for (auto e : env->event_pool) (void)hipEventDestroy(e);
     for (void *p : env->allocs) (void)hipFree(p);
@@ -949,6 +1001,22 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    // staged start states: scenes without a ball (a ball's launch depends on how many balls the last episode spawned)
+    {
+        const char *off = std::getenv("SMR_SYNC_RESET");          // debugging / A-B measurement: reset on the critical path
+        env->staged = !scene->use_ball && !(off && off[0] == '1');
+    }
+    if (env->staged) {
+        if ((rc = dev_alloc(env, &st.next_q, 7 * B)) || (rc = dev_alloc(env, &st.next_v, 7 * B)) || (rc = dev_alloc(env, &st.next_a, 7 * B)) ||
+            (rc = dev_alloc(env, &st.next_planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.next_hit, B)) || (rc = dev_alloc(env, &st.staged_tag, B)) ||
+            (rc = dev_alloc(env, &st.refill_list, B)) || (rc = dev_alloc(env, &st.refill_count, 1)) || (rc = dev_alloc(env, &st.stale_commits, 1)))
+            return fail(rc);
+        if (hipMemset(st.staged_tag, 0xFF, B * 4) || hipMemset(st.refill_count, 0, 4) || hipMemset(st.stale_commits, 0, 4) ||
+            hipMemset(st.next_planet_idx, 0, 2 * B * 4) || hipMemset(st.next_hit, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+        if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_commit, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&env->ev_refill, hipEventDisableTiming) != hipSuccess) { env->err = "could not create the side stream"; return fail(SMR_E_HIP); }
+        if (hipEventRecord(env->ev_refill, env->side) != hipSuccess) { env->err = "hipEventRecord failed"; return fail(SMR_E_HIP); }
+    }
     if (hipDeviceSynchronize() != hipSuccess) { env->err = "hipDeviceSynchronize failed"; return fail(SMR_E_HIP); }
     *out = env;
     return SMR_OK;
@@ -968,17 +1036,18 @@ static hipEvent_t pool_get(smr_env *env) {
 }
 
 struct LaunchTimer {
-    smr_env *env; int k; hipEvent_t a = nullptr, b = nullptr;
-    LaunchTimer(smr_env *e, int kk) : env(e), k(kk) {
-        if (env->profiling) { a = pool_get(env); b = pool_get(env); (void)hipEventRecord(a, env->stream); }
+    smr_env *env; int k; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    LaunchTimer(smr_env *e, int kk, hipStream_t stream = nullptr) : env(e), k(kk), s(stream ? stream : e->stream) {
+        if (env->profiling) { a = pool_get(env); b = pool_get(env); (void)hipEventRecord(a, s); }
     }
     ~LaunchTimer() {
-        if (env->profiling) { (void)hipEventRecord(b, env->stream); env->pending.push_back({k, a, b}); }
+        if (env->profiling) { (void)hipEventRecord(b, s); env->pending.push_back({k, a, b}); }
     }
 };
 
 static int resolve_profile(smr_env *env) {
     SMR_HIP(hipStreamSynchronize(env->stream));
+    if (env->side) SMR_HIP(hipStreamSynchronize(env->side));
     for (auto &p : env->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { env->prof_ms[p.k] += ms; env->prof_n[p.k] += 1; }
@@ -1025,9 +1094,47 @@ static int launch_reset_list(smr_env *env, float *obs_dev) {
     // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
     LaunchTimer t(env, SMR_K_RESET);
     const int B = env->B;
-    hipLaunchKernelGGL(reset_kernel, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+    hipLaunchKernelGGL(reset_kernel<false>, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
                        env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
     SMR_HIP(hipGetLastError());
+    return SMR_OK;
+}
+
+// ---- staged start states -------------------------------------------------------------------
+// main stream:  ... finish/commit (consumes staged states, appends to refill_list) -> ev_commit
+// side stream:  wait ev_commit -> reset_kernel<true>(refill_list) -> ev_refill
+// main stream:  wait ev_refill before the next commit (and before refill_count is cleared for it)
+static int staged_wait_refill(smr_env *env) {          // main stream: the previous refill must have landed
+    SMR_HIP(hipStreamWaitEvent(env->stream, env->ev_refill, 0));
+    return SMR_OK;
+}
+static int staged_launch_refill(smr_env *env) {        // side stream: prepare new start states for the consumed ones
+    SMR_HIP(hipEventRecord(env->ev_commit, env->stream));
+    SMR_HIP(hipStreamWaitEvent(env->side, env->ev_commit, 0));
+    {
+        LaunchTimer t(env, SMR_K_RESET, env->side);
+        const int B = env->B;
+        hipLaunchKernelGGL(reset_kernel<true>, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->side, env->dscene, env->st,
+                           env->st.refill_list, env->st.refill_count, 0, reset_group_stride(), (float *)nullptr);
+    }
+    SMR_HIP(hipGetLastError());
+    SMR_HIP(hipEventRecord(env->ev_refill, env->side));
+    return SMR_OK;
+}
+// main stream, synchronous: (re)compute the staged state of every env for its current reset_count
+static int staged_prepare_all(smr_env *env) {
+    int rc;
+    if ((rc = staged_wait_refill(env))) return rc;
+    LaunchTimer t(env, SMR_K_RESET);
+    hipLaunchKernelGGL(reset_kernel<true>, dim3(((size_t)env->B * 8 + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+                       (const int *)nullptr, (const int *)nullptr, env->B, 1, (float *)nullptr);
+    SMR_HIP(hipGetLastError());
+    return SMR_OK;
+}
+static int staged_check(smr_env *env) {                // after a synchronisation: no commit may have missed its staged state
+    int stale = 0;
+    SMR_HIP(hipMemcpy(&stale, env->st.stale_commits, sizeof(int), hipMemcpyDeviceToHost));
+    if (stale) { env->err = "internal error: a reset was committed without a matching staged start state"; return SMR_E_INVALID; }
     return SMR_OK;
 }
 
@@ -1037,9 +1144,30 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     if (!env) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     const int B = env->B;
+    int rc;
+    if (env->staged) {
+        if (!mask_dev) {
+            // every env: prepare for the current tags, commit, and refill all in the background
+            if ((rc = staged_prepare_all(env))) return rc;
+            hipLaunchKernelGGL(commit_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, (const int *)nullptr,
+                               (const int *)nullptr, B, obs_dev);
+            SMR_HIP(hipGetLastError());
+            hipLaunchKernelGGL(iota_list_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, B, env->st.refill_list, env->st.refill_count);
+            SMR_HIP(hipGetLastError());
+            return staged_launch_refill(env);
+        }
+        if ((rc = staged_wait_refill(env))) return rc;
+        SMR_HIP(hipMemsetAsync(env->st.refill_count, 0, sizeof(int), env->stream));
+        hipLaunchKernelGGL(mask_to_list_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, mask_dev, B, env->st.refill_list, env->st.refill_count);
+        SMR_HIP(hipGetLastError());
+        hipLaunchKernelGGL(commit_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, (const int *)env->st.refill_list,
+                           (const int *)env->st.refill_count, 0, obs_dev);
+        SMR_HIP(hipGetLastError());
+        return staged_launch_refill(env);
+    }
     if (!mask_dev) {
         LaunchTimer t(env, SMR_K_RESET);
-        hipLaunchKernelGGL(reset_kernel, dim3(((size_t)B * 8 + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
+        hipLaunchKernelGGL(reset_kernel<false>, dim3(((size_t)B * 8 + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
                            (const int *)nullptr, (const int *)nullptr, B, 1, obs_dev);
         SMR_HIP(hipGetLastError());
         return SMR_OK;
@@ -1068,12 +1196,19 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         hipLaunchKernelGGL(collide_kernel, dim3((B + 63) / 64, env->N, SMR_NLINK), dim3(64), 0, env->stream, env->dscene, env->st);
     }
     SMR_HIP(hipGetLastError());
+    const bool staged = env->staged && env->auto_reset;
+    if (staged) {
+        int rc = staged_wait_refill(env);
+        if (rc) return rc;
+        SMR_HIP(hipMemsetAsync(env->st.refill_count, 0, sizeof(int), env->stream));
+    }
     {
         LaunchTimer t(env, SMR_K_FINISH);
         hipLaunchKernelGGL(finish_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, obs_dev,
-                           reward_dev, done_dev, reason_dev, info_dev);
+                           reward_dev, done_dev, reason_dev, info_dev, staged ? 1 : 0);
     }
     SMR_HIP(hipGetLastError());
+    if (staged) return staged_launch_refill(env);
     if (env->hscene.use_ball) {
         LaunchTimer t(env, SMR_K_SPAWN);
         hipLaunchKernelGGL(spawn_kernel, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
@@ -1096,6 +1231,7 @@ int smr_synchronize(smr_env_t *env) {
     if (!env) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     SMR_HIP(hipStreamSynchronize(env->stream));
+    if (env->side) { SMR_HIP(hipStreamSynchronize(env->side)); return staged_check(env); }
     return SMR_OK;
 }
 
@@ -1104,6 +1240,7 @@ int smr_get_state(smr_env_t *env, const smr_host_state_t *h) {
     SMR_HIP(hipSetDevice(env->device));
     SMR_HIP(hipStreamSynchronize(env->stream));
     int rc;
+    if (env->side && (rc = staged_check(env))) return rc;
     if ((rc = state_get(env, h->q, env->st.q, 7)) || (rc = state_get(env, h->v, env->st.v, 7)) || (rc = state_get(env, h->a, env->st.a, 7)) ||
         (rc = state_get(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_get(env, h->step_count, env->st.step_count, 1)) ||
         (rc = state_get(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_get(env, h->reset_count, env->st.reset_count, 1)) ||
@@ -1116,6 +1253,7 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     if (!env || !h) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     SMR_HIP(hipStreamSynchronize(env->stream));
+    if (env->side) SMR_HIP(hipStreamSynchronize(env->side));
     if (h->planet_idx)
         for (size_t e = 0; e < (size_t)env->B; ++e)
             for (int p = 0; p < env->hscene.n_planets; ++p) {
@@ -1129,6 +1267,10 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
         (rc = state_set(env, h->ball, env->st.ball, 10)) || (rc = state_set(env, h->ball_i, env->st.ball_i, 5)))
         return rc;
     SMR_HIP(hipDeviceSynchronize());
+    if (env->staged && h->reset_count) {               // the staged start states belong to the old reset counters
+        if ((rc = staged_prepare_all(env))) return rc;
+        SMR_HIP(hipStreamSynchronize(env->stream));
+    }
     return SMR_OK;
 }
 

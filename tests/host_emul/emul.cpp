@@ -23,8 +23,10 @@ static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); ret
 static inline void sincosf_(float x, float *s, float *c) { *s = std::sin(x); *c = std::cos(x); }
 #define sincosf sincosf_
 #include <math.h>
-extern "C" { long emul_counters[4] = {0, 0, 0, 0}; }
-#define SMR_CNT(i) (++emul_counters[i])
+extern "C" { long emul_counters[8] = {0, 0, 0, 0, 0, 0, 0, 0}; }
+extern "C" { long emul_slot = 0, emul_slot_counters[64] = {0}; }
+#define SMR_CNT(i) ((i) == 4 ? ++emul_slot_counters[emul_slot & 63] : ++emul_counters[i])
+#define SMR_CNT_SLOT(i) (emul_slot = (i))
 #include "../../include/smr_scene.h"
 #include "../../safemotionsrisk_amd/csrc/smr_device.h"
 #include "../../safemotionsrisk_amd/csrc/smr_tables.h"
@@ -116,6 +118,17 @@ extern "C" void emul_support_check(void *h, int pi, const float *dir, int warm_s
     out[0] = dot(a, d); out[1] = dot(b, d); out[2] = (float)hint;
 }
 extern "C" int emul_piece_count(void *h, int pi) { return ((HostScene *)h)->d.pieces[pi].count; }
+
+// planets: the end-of-step query set of one (env, link) lane of the collide kernel
+extern "C" void emul_link_query(void *h, const float *q, const int *idx, int l, int want_static, int want_moving, int want_contact, float *out) {
+    HostScene *H = (HostScene *)h;
+    const DScene &S = H->d;
+    Xf T = fk_base(S);
+    for (int j = 0; j < l; ++j) fk_advance(S, j, q[j], T);
+    const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
+    Sample r = collide_link(S, l, LP, global_hull(S, S.link_piece[l], LP), T, idx, nullptr, want_static != 0, want_moving != 0, want_contact != 0);
+    out[0] = r.d_static; out[1] = r.d_moving; out[2] = r.contact ? 1.f : 0.f;
+}
 
 // ball scene: per-link moving distance (no cut-off sharing between links) for configuration q and the ball after k updates
 extern "C" void emul_ball_link_distances(void *h, const float *q, const float *ball, int k, float *out /*8*/, int use_scan) {

@@ -76,6 +76,24 @@ def test_hill_climbing_support_equals_scan(emul, space_scene, ball_scene):
                     assert out[0] >= out[1] - 2e-7 * scale, (pi, d, warm, out)
 
 
+def test_gjk_continues_through_a_rounding_level_stall(emul, ball_scene):
+    """Regression (found by the ball rollout on the GPU): the triangle built with a far new vertex improved |v|^2 by
+    4e-9 - less than float32 resolves - and the "no progress" exit returned a distance 1.5e-5 m too large."""
+    q = np.array([-2.9045886993408203, -0.8068791031837463, -2.3876144886016846, -1.90622878074646, 2.388410806655884,
+                  0.18951769173145294, 2.6782050132751465], np.float32)
+    ball = np.array([-1.1466519832611084, 2.185420513153076, 0.10109367221593857, 1.195295810699463, -1.5054339170455933,
+                     5.683743000030518, 0.25892138481140137, 0.20055784285068512, 0.026196885854005814, 6.032756805419922], np.float32)
+    k = 240
+    H = C.c_void_p(emul.emul_scene_create(C.cast(ball_scene.pointer(), C.c_void_p)))
+    ora = O.OracleEnv(ball_scene, 1)
+    want = ora.ball_distances(q.astype(np.float64), ball.astype(np.float64), k)[2]
+    for use_scan in (0, 1):
+        out = np.zeros(8, np.float32)
+        emul.emul_ball_link_distances(H, q.ctypes.data_as(C.c_void_p), ball.ctypes.data_as(C.c_void_p), k,
+                                      out.ctypes.data_as(C.c_void_p), use_scan)
+        assert abs(out.min() - want) < 1e-6
+
+
 def test_device_acc_range_on_host(emul, space_scene):
     s = space_scene.struct
     rng = np.random.default_rng(1)
