@@ -35,7 +35,7 @@ class HostState(C.Structure):
 
 
 def _sources():
-    return [os.path.join(CSRC, "smr_hip.hip"), os.path.join(CSRC, "smr_device.h"),
+    return [os.path.join(CSRC, "smr_hip.hip"), os.path.join(CSRC, "smr_device.h"), os.path.join(CSRC, "smr_tables.h"),
             os.path.join(INCLUDE, "safemotions_hip.h"), os.path.join(INCLUDE, "smr_scene.h")]
 
 
@@ -60,6 +60,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime; it has to be in the process before libsmr_hip.so is bound, or the library
+    # binds the system copy and the two runtimes do not see each other's device, streams and memory
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the product has no CPU path)" % LIB_PATH)

@@ -69,3 +69,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "smr_oracle" not in text, f
+
+
+def test_library_is_bound_after_pytorch():
+    """PyTorch ships its own HIP runtime: lib.load() has to pull torch in first, or libsmr_hip.so binds the system copy
+    and the process ends up with two runtimes that do not share devices, streams or memory (seen as 'no HIP device'
+    and as kernels racing torch's copies when this test file alone ran on the GPU box)."""
+    import subprocess, sys
+    code = ("import sys; from safemotionsrisk_amd import lib; assert 'torch' not in sys.modules; lib.load(); "
+            "assert 'torch' in sys.modules; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-500:]
