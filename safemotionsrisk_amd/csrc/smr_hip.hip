@@ -44,7 +44,10 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
 }
 
 // one lane per (env, sample k, link l); grid = (B/64, N, 8)
-__global__ __launch_bounds__(64) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
+#ifndef SMR_COLLIDE_WAVES
+#define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     const int l = SMR_NLINK - 1 - (int)blockIdx.z;     // iiwa_link_l; the outer links (most planet work) are dispatched first
     // the link's hull, edge graph and start map staged in LDS: every support call of this block climbs over them
