@@ -125,6 +125,28 @@ def main():
         dominant = max(kernels, key=kernels.get)
         dom_ms = kernels[dominant]
         achieved = ALGO_BYTES_PER_ENV_STEP * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel: measured in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
+        # FETCH_SIZE doubled on gfx950) of this command at the default configuration, committed under profiles/
+        traffic, pmc_note = None, ""
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_final_pmc.json")))
+            if B == 65536 and n_checks == 3 and world == 1:
+                traffic = pmc["kernels"]["smr::%s_kernel" % dominant]["hbm_bytes"]
+                pmc_note = "; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/round1_final_pmc.json"
+        except Exception:
+            pass
+        # kernels on the critical path: the reset kernel of a scene without a ball runs on the side stream, overlapped
+        overlapped = ["reset"] if not env.scene.struct.use_ball and not os.environ.get("SMR_SYNC_RESET") == "1" else []
+        critical = {k: v for k, v in kernels.items() if k not in overlapped}
+        if critical:
+            dominant = max(critical, key=critical.get)
+            dom_ms = critical[dominant]
+            achieved = ALGO_BYTES_PER_ENV_STEP * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            if traffic is not None:
+                try:
+                    traffic = pmc["kernels"]["smr::%s_kernel" % dominant]["hbm_bytes"]
+                except Exception:
+                    traffic = None
         out = {
             "metric": "env-steps/sec at batch 65 536, 7-DoF space scene",
             "value": total_env_steps / elapsed,
@@ -144,10 +166,11 @@ def main():
                        "envs_per_gpu": B, "global_batch": B * world, "collision_checks_per_step": n_checks,
                        "all_gather": bool(rollout is not None), "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "note": "path is FP32-VALU/scalar-load bound, not HBM bound (SURVEY section 0.5): %d algorithmic B per "
-                                 "env-step x %d envs per launch / mean %s-kernel time" % (ALGO_BYTES_PER_ENV_STEP, B, dominant)},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "note": "path is FP32-VALU/LDS-latency bound, not HBM bound (SURVEY section 0.5): %d algorithmic B per "
+                                 "env-step x %d envs per launch / mean %s-kernel time%s" % (ALGO_BYTES_PER_ENV_STEP, B, dominant, pmc_note)},
             "kernel_ms": kernels,
+            "overlapped_kernels": overlapped,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(SPACE_ENV_CONFIG)
