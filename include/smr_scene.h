@@ -21,9 +21,12 @@
 extern "C" {
 #endif
 
-#define SMR_SCENE_VERSION 4
+#define SMR_SCENE_VERSION 5
 #define SMR_NJ 7          /* manipulator joints (iiwa_joint_1..7, robot.urdf)            */
-#define SMR_NLINK 8       /* rigid bodies iiwa_link_0..7; body k moves with joints 1..k    */
+#define SMR_NLINK 8       /* chain links iiwa_link_0..7; link k moves with joints 1..k      */
+#define SMR_MAX_BODIES 10 /* collision bodies = the 8 chain links + convex pieces rigidly mounted on one of them
+                             (ball machine on iiwa_link_7, robot_ball_machine.urdf); one convex piece per body */
+#define SMR_MAX_SELF_PAIRS 16
 #define SMR_MAX_PLANETS 2
 #define SMR_MAX_STATIC 4
 
@@ -38,12 +41,19 @@ extern "C" {
 /* One convex piece = convex hull of verts[vert_begin .. vert_begin+vert_count) inflated by `margin`
  * (Bullet: btConvexHullShape + collision margin).  center/radius: a bounding sphere of the
  * un-inflated hull in the same frame as the vertices, used only to cull far pairs. */
+#define SMR_PIECE_HULL 0
+#define SMR_PIECE_CYLINDER_Z 1   /* Bullet btCylinderShapeZ: axis z through `center`, core radius / half length below; its
+                                    vertices are the 8 corners of its bounding box (bounds only, not the support) */
 typedef struct smr_piece {
     int32_t vert_begin;
     int32_t vert_count;
     double center[3];
     double radius;
     double margin;
+    int32_t kind;             /* SMR_PIECE_* */
+    int32_t _pad;
+    double cyl_radius;        /* core (margin already subtracted) */
+    double cyl_half_length;
 } smr_piece_t;
 
 typedef struct smr_planet {
@@ -89,7 +99,16 @@ typedef struct smr_scene {
     const int32_t *adj;                 /* neighbour vertex ids, LOCAL to the vertex's piece; a piece has <= 256 vertices */
     int32_t n_verts;
     int32_t n_pieces;
-    int32_t link_piece[SMR_NLINK];      /* piece (link frame) of iiwa_link_k */
+    int32_t n_bodies;                   /* 8, or 8 + pieces of the ball machine (ball_machine_mode, scene.py:171) */
+    int32_t link_piece[SMR_MAX_BODIES]; /* piece (body frame) of body k; bodies 0..7 = iiwa_link_k */
+    int32_t body_parent[SMR_MAX_BODIES];/* chain link the body is rigidly attached to (k itself for k < 8) */
+    int32_t ee_body;                    /* body whose frame carries ee_offset (target link, scene.py:185-208) */
+    double body_xyz[SMR_MAX_BODIES][3]; /* parent link frame -> body frame (identity for k < 8) */
+    double body_rot[SMR_MAX_BODIES][9];
+    /* self-collision pairs (A7 self), ctlp.py:1398-1460,3345-3372: (body, partner); partner >= 0: body index,
+     * partner < 0: world-frame piece -(partner + 1) (the base adapter's cylinder) */
+    int32_t n_self_pairs;
+    int32_t self_pair[SMR_MAX_SELF_PAIRS][2];
 
     /* static obstacles (A7): pieces given in the world frame */
     int32_t n_static;
@@ -130,6 +149,7 @@ typedef struct smr_scene {
     double ball_active_xy_radius;       /* 1.25, ctlp.py:2830 */
     double ball_target_box[3][2];       /* _target_point_cartesian_range, ctlp.py:191-229 */
     double ball_target_min_dist_static; /* ctlp.py:1726 */
+    double ball_target_min_dist_self;   /* closest_point_safety_distance, ctlp.py:2357 */
     double plane_z;                     /* scene.py:172 */
     double table_half_xy[2];            /* ctlp.py:1901-1902 */
 

@@ -39,6 +39,7 @@ def lib():
         L.smo_scene_sizeof.restype = C.c_size_t
         L.smo_gjk.restype = C.c_double
         L.smo_link_planet_piece_distance.restype = C.c_double
+        L.smo_self_pair_distance.restype = C.c_double
         L.smo_support_vertex_visits.restype = C.c_int64
         L.smo_vel_upper_a1max.restype = C.c_double
         L.smo_vel_upper_a1max.argtypes = [C.c_double] * 6
@@ -151,6 +152,15 @@ class OracleEnv:
     def link_planet_piece_distance(self, q, link, planet, piece, idx):
         return self.L.smo_link_planet_piece_distance(self.h, _p(_d(q)), C.c_int32(link), C.c_int32(planet),
                                                      C.c_int32(piece), C.c_int32(idx))
+
+    def body_frames(self, q):
+        n = int(self.bundle.struct.n_bodies)
+        pos, rot = np.zeros((n, 3)), np.zeros((n, 9))
+        self.L.smo_body_frames(self.h, _p(_d(q)), _p(pos), _p(rot))
+        return pos, rot.reshape(n, 3, 3)
+
+    def self_pair_distance(self, q, i):
+        return self.L.smo_self_pair_distance(self.h, _p(_d(q)), C.c_int32(i))
 
     def position_is_valid(self, q):
         return bool(self.L.smo_position_is_valid(self.h, _p(_d(q))))

@@ -255,7 +255,7 @@ double vel_peak_bruteforce(double v0, double a0, double a1, const JointLim &L) {
  * A6: forward kinematics = pybullet getLinkState(...)[4],[5] (URDF link frames) of iiwa_link_0..7
  * for joint vector q (ctlp.py:2940-2985, 5163-5195; chain from description/urdf/robot.urdf).
  * ------------------------------------------------------------------------------------------- */
-void forward_kinematics(const smr_scene_t &S, const double q[SMR_NJ], Xf out[SMR_NLINK]) {
+void forward_kinematics(const smr_scene_t &S, const double q[SMR_NJ], Xf out[SMR_MAX_BODIES]) {
     Xf T = identity_xf();
     T.t = {S.base_xyz[0], S.base_xyz[1], S.base_xyz[2]};
     out[0] = T;
@@ -274,6 +274,16 @@ void forward_kinematics(const smr_scene_t &S, const double q[SMR_NJ], Xf out[SMR
         std::memcpy(T.R, Rn, sizeof Rn);
         out[k + 1] = T;
     }
+    /* bodies rigidly mounted on a chain link (ball machine on iiwa_link_7, robot_ball_machine.urdf) */
+    for (int b = SMR_NLINK; b < S.n_bodies; ++b) {
+        const Xf &P = out[S.body_parent[b]];
+        Xf X;
+        X.t = apply(P, {S.body_xyz[b][0], S.body_xyz[b][1], S.body_xyz[b][2]});
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                X.R[3 * i + j] = P.R[3 * i] * S.body_rot[b][j] + P.R[3 * i + 1] * S.body_rot[b][3 + j] + P.R[3 * i + 2] * S.body_rot[b][6 + j];
+        out[b] = X;
+    }
 }
 
 /* ------------------------------------------------------------------------------------------- *
@@ -283,13 +293,20 @@ void forward_kinematics(const smr_scene_t &S, const double q[SMR_NJ], Xf out[SMR
  * The closest point of the current simplex to the origin is found by brute force over all of its
  * sub-simplices (Johnson's sub-algorithm without the recursive shortcuts).
  * ------------------------------------------------------------------------------------------- */
-struct Hull { const double *v; int n; Xf X; };
+/* a convex vertex set, or (cyl_r > 0) Bullet's btCylinderShapeZ core: axis z through c, radius cyl_r, half length cyl_h */
+struct Hull { const double *v; int n; Xf X; double cyl_r = 0, cyl_h = 0; V3 c = {0, 0, 0}; };
 
 long g_support_calls = 0;   /* work counter for the flop model, not thread safe by design */
 bool g_count_work = false;
 
 inline V3 support(const Hull &H, V3 d) {
     V3 dl = rot_t(H.X, d);
+    if (H.cyl_r > 0) {                       /* btCylinderShapeZ::localGetSupportingVertexWithoutMargin */
+        double s = std::sqrt(dl.x * dl.x + dl.y * dl.y);
+        V3 p = s > 0 ? V3{H.c.x + H.cyl_r * dl.x / s, H.c.y + H.cyl_r * dl.y / s, H.c.z} : V3{H.c.x + H.cyl_r, H.c.y, H.c.z};
+        p.z += dl.z < 0 ? -H.cyl_h : H.cyl_h;
+        return apply(H.X, p);
+    }
     int best = 0;
     double bd = -1e300;
     for (int i = 0; i < H.n; ++i) {
@@ -364,7 +381,7 @@ static V3 simplex_closest(V3 w[4], int &n) {
  * the search stops and a lower bound > cutoff is returned. */
 double gjk_distance(const Hull &A, const Hull &B, double cutoff) {
     V3 w[4];
-    V3 v = apply(A.X, {A.v[0], A.v[1], A.v[2]}) - apply(B.X, {B.v[0], B.v[1], B.v[2]});
+    V3 v = support(A, {1, 0, 0}) - support(B, {1, 0, 0});
     w[0] = v;                       /* the start point is a point of A - B: it seeds the simplex */
     int n = 1;
     double vv = dot(v, v);
@@ -423,7 +440,9 @@ Xf ball_pose(const Oracle &O, const EnvState &st, int k, double *vel_out);
 
 inline Hull piece_hull(const Oracle &O, int piece, const Xf &X) {
     const smr_piece_t &P = O.pieces[piece];
-    return {&O.verts[3 * (size_t)P.vert_begin], P.vert_count, X};
+    Hull H{&O.verts[3 * (size_t)P.vert_begin], P.vert_count, X};
+    if (P.kind == SMR_PIECE_CYLINDER_Z) { H.cyl_r = P.cyl_radius; H.cyl_h = P.cyl_half_length; H.c = {P.center[0], P.center[1], P.center[2]}; }
+    return H;
 }
 
 /* signed distance (margins subtracted) between two pieces; values above `cutoff` only mean
@@ -447,14 +466,35 @@ Xf planet_pose(const Oracle &O, int p, int idx) {
     return X;
 }
 
+/* distance of self-collision pair i = (body, partner); partner < 0: a world-frame piece (base adapter) */
+double self_pair_distance(const Oracle &O, const Xf link[SMR_MAX_BODIES], int i, double cutoff) {
+    const smr_scene_t &S = O.S;
+    const int a = S.self_pair[i][0], b = S.self_pair[i][1];
+    if (b >= 0) return piece_distance(O, S.link_piece[b], link[b], S.link_piece[a], link[a], cutoff);
+    return piece_distance(O, -(b + 1), identity_xf(), S.link_piece[a], link[a], cutoff);
+}
+
+/* _check_if_minimum_distance_between_robot_links_exceeds_threshold, ctlp.py:2170-2208 */
+bool self_pairs_clear(const Oracle &O, const Xf link[SMR_MAX_BODIES], double thr) {
+    for (int i = 0; i < O.S.n_self_pairs; ++i) {
+        double d = self_pair_distance(O, link, i, thr + 0.005);
+        if (d <= thr + 0.005 && d < thr) return false;
+    }
+    return true;
+}
+
 /* A7: get_minimum_distance(check_safety_distance=False), ctlp.py:3282-3374 -> (static, self). */
-void min_distance_static_self(const Oracle &O, const Xf link[SMR_NLINK], double &d_static, double &d_self) {
+void min_distance_static_self(const Oracle &O, const Xf link[SMR_MAX_BODIES], double &d_static, double &d_self) {
     const smr_scene_t &S = O.S;
     d_static = S.static_max_distance;
-    d_self = S.static_max_distance;      /* no self-collision pairs for one iiwa, ctlp.py:1409-1459 */
+    d_self = S.static_max_distance;      /* self-collision pairs exist only with the ball machine, ctlp.py:1409-1459 */
     Xf I = identity_xf();
+    for (int i = 0; i < S.n_self_pairs; ++i) {                                               /* ctlp.py:3345-3372 */
+        double d = self_pair_distance(O, link, i, S.static_max_distance);
+        if (d <= S.static_max_distance && d < d_self) d_self = d;
+    }
     for (int s = 0; s < S.n_static; ++s)
-        for (int k = 0; k < SMR_NLINK; ++k) {
+        for (int k = 0; k < S.n_bodies; ++k) {
             if (!(S.static_link_mask & (1u << k))) continue;
             double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], S.static_max_distance);
             if (d <= S.static_max_distance && d < d_static) d_static = d;
@@ -462,12 +502,12 @@ void min_distance_static_self(const Oracle &O, const Xf link[SMR_NLINK], double 
 }
 
 /* A8: _get_minimum_distance_to_obstacles, ctlp.py:3258-3280 (planets). */
-double min_distance_moving(const Oracle &O, const Xf link[SMR_NLINK], const int32_t planet_idx[]) {
+double min_distance_moving(const Oracle &O, const Xf link[SMR_MAX_BODIES], const int32_t planet_idx[]) {
     const smr_scene_t &S = O.S;
     double dmin = S.moving_max_distance + 0.002;
     for (int p = 0; p < S.n_planets; ++p) {
         Xf Xp = planet_pose(O, p, planet_idx[p]);
-        for (int k = 0; k < SMR_NLINK; ++k) {
+        for (int k = 0; k < S.n_bodies; ++k) {
             if (!(S.moving_link_mask & (1u << k))) continue;
             for (int c = 0; c < S.planet[p].piece_count; ++c) {
                 double d = piece_distance(O, S.planet[p].piece_begin + c, Xp, S.link_piece[k], link[k],
@@ -484,11 +524,11 @@ double min_distance_moving(const Oracle &O, const Xf link[SMR_NLINK], const int3
 
 /* A11: Planet.check_if_object_is_colliding, ctlp.py:4570-4579 = "Bullet holds a contact point
  * between the planet and any robot link", i.e. separation <= contact breaking threshold. */
-bool moving_contact(const Oracle &O, const Xf link[SMR_NLINK], const int32_t planet_idx[]) {
+bool moving_contact(const Oracle &O, const Xf link[SMR_MAX_BODIES], const int32_t planet_idx[]) {
     const smr_scene_t &S = O.S;
     for (int p = 0; p < S.n_planets; ++p) {
         Xf Xp = planet_pose(O, p, planet_idx[p]);
-        for (int k = 0; k < SMR_NLINK; ++k) {
+        for (int k = 0; k < S.n_bodies; ++k) {
             if (!(S.contact_link_mask & (1u << k))) continue;
             for (int c = 0; c < S.planet[p].piece_count; ++c) {
                 double d = piece_distance(O, S.planet[p].piece_begin + c, Xp, S.link_piece[k], link[k],
@@ -540,27 +580,27 @@ void observation(const Oracle &O, const EnvState &e, float *obs) {
 /* A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138 (gravity-torque check via one
  * physics step omitted: kinematic restatement).  box / thr: cartesian range of the end-effector point and
  * minimum table distance (start states: ctlp.py:172-183,1468-1477; ball targets: ctlp.py:191-229,1725-1726). */
-bool pose_is_valid(const Oracle &O, const double q[SMR_NJ], const double box[3][2], double thr, V3 *ee_out) {
+bool pose_is_valid(const Oracle &O, const double q[SMR_NJ], const double box[3][2], double thr, double thr_self, V3 *ee_out) {
     const smr_scene_t &S = O.S;
-    Xf link[SMR_NLINK];
+    Xf link[SMR_MAX_BODIES];
     forward_kinematics(S, q, link);
-    V3 ee = apply(link[SMR_NLINK - 1], {S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
+    V3 ee = apply(link[S.ee_body], {S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
     if (ee_out) *ee_out = ee;
     double e[3] = {ee.x, ee.y, ee.z};
     for (int c = 0; c < 3; ++c)
         if (e[c] < box[c][0] || e[c] > box[c][1]) return false;                             /* ctlp.py:2054-2061 */
     Xf I = identity_xf();
     for (int s = 0; s < S.n_static; ++s)                                                    /* ctlp.py:2140-2168 */
-        for (int k = 0; k < SMR_NLINK; ++k) {
+        for (int k = 0; k < S.n_bodies; ++k) {
             if (!(S.static_link_mask & (1u << k))) continue;
             double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], thr + 0.005);
             if (d <= thr + 0.005 && d < thr) return false;
         }
-    return true;
+    return self_pairs_clear(O, link, thr_self);                                             /* ctlp.py:2083-2089 */
 }
 
 bool position_is_valid(const Oracle &O, const double q[SMR_NJ]) {
-    return pose_is_valid(O, q, O.S.start_box, O.S.start_min_dist_static, nullptr);
+    return pose_is_valid(O, q, O.S.start_box, O.S.start_min_dist_static, O.S.start_min_dist_self, nullptr);
 }
 
 /* next valid start position: attempt n uses draws 7n..7n+6 of stream S_POS (ctlp.py:2030-2037) */
@@ -574,17 +614,17 @@ void sample_position(const Oracle &O, const Rng &rng, uint32_t &attempt, double 
 
 bool table_free(const Oracle &O, const double q[SMR_NJ]) {                    /* ctlp.py:1605-1619 (table + self: no pairs) */
     const smr_scene_t &S = O.S;
-    Xf link[SMR_NLINK];
+    Xf link[SMR_MAX_BODIES];
     forward_kinematics(S, q, link);
     Xf I = identity_xf();
     for (int s = 0; s < S.n_static; ++s)
-        for (int k = 0; k < SMR_NLINK; ++k) {
+        for (int k = 0; k < S.n_bodies; ++k) {
             if (!(S.static_link_mask & (1u << k))) continue;
             double thr = S.start_min_dist_static;
             double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], thr + 0.005);
             if (d <= thr + 0.005 && d < thr) return false;
         }
-    return true;
+    return self_pairs_clear(O, link, S.start_min_dist_self);                                /* ctlp.py:1610-1615 */
 }
 
 /* ------------------------------------------------------------------------------------------- *
@@ -662,9 +702,9 @@ Xf ball_pose(const Oracle &O, const EnvState &st, int k, double *vel_out) {
     return X;
 }
 
-bool ball_contact(const Oracle &O, const Xf link[SMR_NLINK], const Xf &Xb) {        /* Ball.check_if_object_is_colliding */
+bool ball_contact(const Oracle &O, const Xf link[SMR_MAX_BODIES], const Xf &Xb) {        /* Ball.check_if_object_is_colliding */
     const smr_scene_t &S = O.S;
-    for (int k = 0; k < SMR_NLINK; ++k) {
+    for (int k = 0; k < S.n_bodies; ++k) {
         if (!(S.contact_link_mask & (1u << k))) continue;
         double d = piece_distance(O, S.ball_piece, Xb, S.link_piece[k], link[k], S.contact_distance);
         if (d <= S.contact_distance) return true;
@@ -672,10 +712,10 @@ bool ball_contact(const Oracle &O, const Xf link[SMR_NLINK], const Xf &Xb) {    
     return false;
 }
 
-double ball_min_distance(const Oracle &O, const Xf link[SMR_NLINK], const Xf &Xb) {   /* ctlp.py:3258-3280 */
+double ball_min_distance(const Oracle &O, const Xf link[SMR_MAX_BODIES], const Xf &Xb) {   /* ctlp.py:3258-3280 */
     const smr_scene_t &S = O.S;
     double dmin = S.moving_max_distance + 0.002;
-    for (int k = 0; k < SMR_NLINK; ++k) {
+    for (int k = 0; k < S.n_bodies; ++k) {
         if (!(S.moving_link_mask & (1u << k))) continue;
         double d = piece_distance(O, S.ball_piece, Xb, S.link_piece[k], link[k], S.moving_max_distance);
         if (d <= S.moving_max_distance && d < dmin) { dmin = d; if (dmin <= 0.0) return 0.0; }
@@ -705,7 +745,7 @@ void spawn_ball(Oracle &O, int e) {
             uint32_t m = pose_attempt++;
             double q[SMR_NJ];
             for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S_BALL_POSE, 7 * m + j, S.pos_lo[j], S.pos_hi[j]);
-            if (pose_is_valid(O, q, S.ball_target_box, S.ball_target_min_dist_static, &target)) break;
+            if (pose_is_valid(O, q, S.ball_target_box, S.ball_target_min_dist_static, S.ball_target_min_dist_self, &target)) break;
         }
         double dx = target.x - rel[0], dy = target.y - rel[1], dh = target.z - rel[2];
         double dxy = std::sqrt(dx * dx + dy * dy);
@@ -838,7 +878,7 @@ void reset_env(Oracle &O, int e) {
             if (st.ball_khit < kcap) kcap = st.ball_khit;
             int max_ts = kcap / S.updates_per_step;
             if (max_ts < 0) max_ts = 0;
-            Xf link[SMR_NLINK];
+            Xf link[SMR_MAX_BODIES];
             forward_kinematics(S, q, link);
             for (uint32_t m = 0; m < 100000; ++m) {
                 st.ball_k = brng.randint(S_BALL_MISC, 1 + m, max_ts + 1) * S.updates_per_step;
@@ -848,7 +888,7 @@ void reset_env(Oracle &O, int e) {
     }
     if (S.n_planets > 0) {
         /* Planet.reset: random phase until contact free, ctlp.py:4470-4501 */
-        Xf link[SMR_NLINK];
+        Xf link[SMR_MAX_BODIES];
         forward_kinematics(S, q, link);
         int32_t idx[SMR_MAX_PLANETS] = {0, 0};
         int n_indep = 0;
@@ -893,7 +933,7 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
     /* A11: moving-obstacle contact latch along the segment, ctlp.py:2626-2637 (N samples per step) */
     int N = S.collision_checks_per_step;
     int upd = S.updates_per_step / N;
-    Xf link[SMR_NLINK];
+    Xf link[SMR_MAX_BODIES];
     /* ball: update at which it is retired for having passed the robot or hit table/ground, ctlp.py:2836-2848 */
     const bool ball_active0 = S.use_ball && st.ball_active;
     int u_end = S.updates_per_step + 1;
@@ -1119,7 +1159,7 @@ void smo_set_state(void *h, const double *q, const double *v, const double *a, c
 
 void smo_fk(void *h, const double *q, double *pos_out /*8x3*/, double *rot_out /*8x9*/) {
     Oracle &O = *(Oracle *)h;
-    Xf link[SMR_NLINK];
+    Xf link[SMR_MAX_BODIES];
     forward_kinematics(O.S, q, link);
     for (int k = 0; k < SMR_NLINK; ++k) {
         pos_out[3 * k] = link[k].t.x; pos_out[3 * k + 1] = link[k].t.y; pos_out[3 * k + 2] = link[k].t.z;
@@ -1164,7 +1204,7 @@ double smo_gjk(const double *va, int32_t na, const double *Ra, const double *ta,
 /* distances of one configuration: out = {d_static, d_self, d_moving (no latch), contact flag} */
 void smo_distances(void *h, const double *q, const int32_t *planet_idx, double *out) {
     Oracle &O = *(Oracle *)h;
-    Xf link[SMR_NLINK];
+    Xf link[SMR_MAX_BODIES];
     forward_kinematics(O.S, q, link);
     min_distance_static_self(O, link, out[0], out[1]);
     out[2] = O.S.n_planets > 0 ? min_distance_moving(O, link, planet_idx) : O.S.moving_max_distance + 0.002;
@@ -1174,9 +1214,28 @@ void smo_distances(void *h, const double *q, const int32_t *planet_idx, double *
 /* exact (cutoff-free) distance between link k and piece `piece` of planet p at orbit index idx */
 double smo_link_planet_piece_distance(void *h, const double *q, int32_t k, int32_t p, int32_t piece, int32_t idx) {
     Oracle &O = *(Oracle *)h;
-    Xf link[SMR_NLINK];
+    Xf link[SMR_MAX_BODIES];
     forward_kinematics(O.S, q, link);
     return piece_distance(O, O.S.planet[p].piece_begin + piece, planet_pose(O, p, idx), O.S.link_piece[k], link[k], 1e30);
+}
+
+/* frames of all bodies (chain links + mounted pieces): pos [n_bodies][3], rot [n_bodies][9] */
+void smo_body_frames(void *h, const double *q, double *pos_out, double *rot_out) {
+    Oracle &O = *(Oracle *)h;
+    Xf link[SMR_MAX_BODIES];
+    forward_kinematics(O.S, q, link);
+    for (int k = 0; k < O.S.n_bodies; ++k) {
+        pos_out[3 * k] = link[k].t.x; pos_out[3 * k + 1] = link[k].t.y; pos_out[3 * k + 2] = link[k].t.z;
+        std::memcpy(rot_out + 9 * k, link[k].R, sizeof link[k].R);
+    }
+}
+
+/* distance of self-collision pair i for joint vector q (no cut-off) */
+double smo_self_pair_distance(void *h, const double *q, int32_t i) {
+    Oracle &O = *(Oracle *)h;
+    Xf link[SMR_MAX_BODIES];
+    forward_kinematics(O.S, q, link);
+    return self_pair_distance(O, link, i, 1e30);
 }
 
 /* ball scene: {d_static, d_self, d_moving, contact} for joint vector q and a ball given by (p0,v0,e0,omega) after k updates */
@@ -1186,7 +1245,7 @@ void smo_ball_distances(void *h, const double *q, const double *ball, int32_t k,
     std::memset(&st, 0, sizeof st);
     for (int c = 0; c < 3; ++c) { st.ball_p0[c] = ball[c]; st.ball_v0[c] = ball[3 + c]; st.ball_e0[c] = ball[6 + c]; }
     st.ball_omega = ball[9];
-    Xf link[SMR_NLINK];
+    Xf link[SMR_MAX_BODIES];
     forward_kinematics(O.S, q, link);
     min_distance_static_self(O, link, out[0], out[1]);
     Xf Xb = ball_pose(O, st, k, nullptr);

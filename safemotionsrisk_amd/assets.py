@@ -221,7 +221,37 @@ def compile_assets(ref_root):
         out[key + "_verts"] = v
         out[key + "_offsets"] = offs
 
-    for key in ("link", "iss", "asteroid", "ball"):
+    # ---- ball-machine variant (robot_ball_machine.urdf): a rigid body on iiwa_link_7 (compound of convex pieces) and
+    # the base adapter's cylinder, which only takes part in self-collision pairs (ctlp.py:1438-1446)
+    bm_root = ET.parse(os.path.join(urdf_dir, "robot_ball_machine.urdf")).getroot()
+    bm_joint = [j for j in bm_root.findall("joint") if j.get("name") == "ball_machine_joint"][0]
+    assert bm_joint.get("type") == "fixed" and bm_joint.find("parent").get("link") == "iiwa_link_7"
+    out["bm_joint_xyz"] = np.array(_floats(bm_joint.find("origin").get("xyz")))
+    out["bm_joint_rot"] = rpy_to_matrix(np.array(_floats(bm_joint.find("origin").get("rpy"))))
+    bm_link = [l for l in bm_root.findall("link") if l.get("name") == "ball_machine"][0]
+    col = bm_link.find("collision")
+    assert col.find("origin") is None
+    mesh = col.find("geometry").find("mesh")
+    scale = np.array(_floats(mesh.get("scale")))
+    pieces = [hull_vertices(g * scale) for g in load_obj_groups(_resolve(ref_root, mesh.get("filename")))]
+    out["bm_verts"] = np.concatenate(pieces)
+    out["bm_offsets"] = np.cumsum([0] + [len(p) for p in pieces]).astype(np.int32)
+    adapter = [l for l in bm_root.findall("link") if l.get("name") == "iiwa_base_adapter"][0]
+    acol = adapter.find("collision")
+    cyl = acol.find("geometry").find("cylinder")
+    assert np.allclose(_floats(acol.find("origin").get("rpy")), 0.0)
+    # world -> iiwa_base_adapter (fixed joints, rpy 0) + the collision origin
+    child_to_joint = {j.find("child").get("link"): j for j in bm_root.findall("joint")}
+    xyz, name = np.array(_floats(acol.find("origin").get("xyz"))), "iiwa_base_adapter"
+    while name != "world":
+        j = child_to_joint[name]
+        assert j.get("type") == "fixed" and np.allclose(_floats(j.find("origin").get("rpy")), 0.0)
+        xyz = xyz + np.array(_floats(j.find("origin").get("xyz")))
+        name = j.find("parent").get("link")
+    out["adapter_center"] = xyz
+    out["adapter_radius_length"] = np.array([float(cyl.get("radius")), float(cyl.get("length"))])
+
+    for key in ("link", "iss", "asteroid", "ball", "bm"):
         out[key + "_adj_offsets"], out[key + "_adj"] = _family_adjacency(out[key + "_verts"], out[key + "_offsets"])
     out["urdf_collision_margin"] = np.array(URDF_COLLISION_MARGIN)
     return out

@@ -41,8 +41,10 @@ struct DPiece {
     float in[3][3];             // three points INSIDE the hull (means of vertex subsets: all / upper / lower half along
                                 // the longest box axis): any pair of interior points bounds the hull distance from above
     int ids_begin, ids_count;   // the piece's neighbour-id groups in DScene::ids4 (hill-climbing support)
+    int kind;                   // SMR_PIECE_HULL / SMR_PIECE_CYLINDER_Z (axis z through (cx,cy,cz), core cyl_r x cyl_h)
+    float cyl_r, cyl_h;
 };
-constexpr int kPieceDwords = 21;
+constexpr int kPieceDwords = 24;
 constexpr int kStartBins = 4;                                // cube-map resolution of the climb start table
 constexpr int kStartCells = 6 * kStartBins * kStartBins;     // entries per piece
 
@@ -65,7 +67,11 @@ struct DScene {
     const uint32_t *span;      // per vertex (indexed like verts): first neighbour-id group relative to the piece | groups << 16
     const uint32_t *ids4;      // groups of 4 neighbour ids, one byte each, local to the piece
     const uint8_t *start;      // kStartCells per piece: support vertex of each cube-map cell centre
-    int link_piece[SMR_NLINK];
+    int n_bodies;                         // 8 chain links + pieces rigidly mounted on one (ball machine on iiwa_link_7)
+    int link_piece[SMR_MAX_BODIES];
+    int body_parent[SMR_MAX_BODIES], ee_body;
+    float body_xyz[SMR_MAX_BODIES][3], body_rot[SMR_MAX_BODIES][9];   // parent link frame -> body frame
+    int n_self_pairs, self_pair[SMR_MAX_SELF_PAIRS][2];               // (body, partner body | -(world piece + 1))
     int n_static, static_piece[SMR_MAX_STATIC];
     unsigned static_mask;
     float static_max;
@@ -78,7 +84,7 @@ struct DScene {
     int use_ball, ball_piece, ball_check_invalid, ball_random_initial;
     float ball_radius, ball_active_xy_radius;
     float ball_obs_pos_min[3], ball_obs_pos_max[3], ball_obs_vel_min[3], ball_obs_vel_max[3];
-    float ball_target_box[3][2], ball_target_min_static;
+    float ball_target_box[3][2], ball_target_min_static, ball_target_min_self;
     double ball_speed, ball_center[3], ball_sphere_radius, ball_height[2], ball_angle[2], ball_high_prob;   // spawn math runs in float64
     double ball_invalid_min[3], ball_invalid_max[3], ball_final_min[3], ball_final_max[3], plane_z, table_half_xy[2];
     double dt64;
@@ -523,6 +529,7 @@ __device__ __forceinline__ DPiece piece_from_words(WP w) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) P.in[i][c] = __int_as_float(w[10 + 3 * i + c]);
     P.ids_begin = w[19]; P.ids_count = w[20];
+    P.kind = w[21]; P.cyl_r = __int_as_float(w[22]); P.cyl_h = __int_as_float(w[23]);
     return P;
 }
 // idx is wave uniform: scalar loads
@@ -628,21 +635,21 @@ __device__ inline bool simplex_solve(F3 &w0, F3 &w1, F3 &w2, F3 &w3, int &n, F3 
     return false;
 }
 
-// Distance between hull A (piece pa under XA; IDENTITY: XA is the identity) and hull B (piece pb under
-// XB), margins excluded.  Returns a lower bound > cutoff as soon as one is proven, and the current
-// upper bound as soon as it drops below stop_below (callers only test it against a threshold then).
-template <bool IDENTITY, class HB>
-__device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece &A, const Xf &XA, const HB &hb,
-                                     const Xf &XB, F3 v, float cutoff, float stop_below) {
+// GJK distance between convex sets A and B given by their world-space support mappings sa(dir, hint, first) and
+// sb(dir, hint, first) (hint: a per-run integer the mapping may use as a warm start; first: first call of the run),
+// margins excluded, started from the point v of A - B.  Returns a lower bound > cutoff as soon as one is proven, and
+// the current upper bound as soon as it drops below stop_below (callers only test it against a threshold then).
+template <class SA, class SB>
+__device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff, float stop_below) {
     F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
-    int n = 0, hint = 0, stalls = 0;
+    int n = 0, hint_a = 0, hint_b = 0, stalls = 0;
     float vv = dot(v, v);
     const float cutoff2 = cutoff * cutoff, stop2 = stop_below > 0.f ? stop_below * stop_below : 0.f;
     SMR_CNT(2);
     for (int it = 0; it < 32; ++it) {
         SMR_CNT(3);
         SMR_CNT(4);
-        F3 w = support<IDENTITY>(verts, A.begin, A.count, XA, neg(v)) - apply(XB, hb.support(rot_t(XB, v), hint, it == 0));
+        F3 w = sa(neg(v), hint_a, it == 0) - sb(v, hint_b, it == 0);
         float vw = dot(v, w);
 #ifdef SMR_HOST_EMUL_TRACE
         printf("  it %d n %d vv %.9g vw %.9g v=(%.7g %.7g %.7g) w=(%.7g %.7g %.7g)\n", it, n, vv, vw, v.x, v.y, v.z, w.x, w.y, w.z);
@@ -656,18 +663,17 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
             F3 e0 = w - w0, e1 = w - w1, e2 = w - w2;
             const float tiny = 1e-12f * fmaxf(dot(w, w), 1e-6f);
             bool dup = (n > 0 && dot(e0, e0) <= tiny) || (n > 1 && dot(e1, e1) <= tiny) || (n > 2 && dot(e2, e2) <= tiny);
-#ifdef SMR_HOST_EMUL_TRACE
-            if (dup) printf("  dup: n %d w0=(%.7g %.7g %.7g) w1=(%.7g %.7g %.7g) w2=(%.7g %.7g %.7g)\n", n, w0.x, w0.y, w0.z, w1.x, w1.y, w1.z, w2.x, w2.y, w2.z);
-#endif
             if (dup) break;
         }
-        if (n == 0) w0 = w; else if (n == 1) w1 = w; else if (n == 2) w2 = w; else w3 = w;
+        // selects, not an if / else-if chain: hipcc 7.2 was seen to drop a component of `w3 = w` in that form when this
+        // loop is inlined into a larger divergent loop (gfx950, -O3)
+        w0 = n == 0 ? w : w0; w1 = n == 1 ? w : w1; w2 = n == 2 ? w : w2; w3 = n >= 3 ? w : w3;
         ++n;
         F3 vn;
         if (simplex_solve(w0, w1, w2, w3, n, vn)) return 0.f;                // origin inside the simplex
         float vvn = dot(vn, vn);
 #ifdef SMR_HOST_EMUL_TRACE
-        printf("  solved: n %d vvn %.9g vn=(%.7g %.7g %.7g) w0=(%.7g %.7g %.7g) w1=(%.7g %.7g %.7g) w2=(%.7g %.7g %.7g)\n", n, vvn, vn.x, vn.y, vn.z, w0.x, w0.y, w0.z, w1.x, w1.y, w1.z, w2.x, w2.y, w2.z);
+        printf("  solved: n %d vvn %.9g vn=(%.7g %.7g %.7g)\n", n, vvn, vn.x, vn.y, vn.z);
 #endif
         if (!(vvn == vvn)) break;                                            // degenerate sub-simplex: keep the last valid v
         // No measurable progress.  Worse than rounding explains: keep the last v.  Equal within rounding: the new
@@ -682,6 +688,15 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
         if (n == 4) return 0.f;
     }
     return sqrtf(vv);
+}
+
+// A = hull piece scanned with scalar loads (wave-uniform piece) under XA (IDENTITY: XA is the identity), B = link hull hb under XB
+template <bool IDENTITY, class HB>
+__device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece &A, const Xf &XA, const HB &hb,
+                                     const Xf &XB, F3 v, float cutoff, float stop_below) {
+    const auto sa = [&](F3 d, int &, bool) { return support<IDENTITY>(verts, A.begin, A.count, XA, d); };
+    const auto sb = [&](F3 d, int &hint, bool first) { return apply(XB, hb.support(rot_t(XB, d), hint, first)); };
+    return gjk_core(sa, sb, v, cutoff, stop_below);
 }
 
 // signed distance (margins subtracted) between obstacle piece pa and link piece pb, or any value
@@ -714,12 +729,68 @@ __device__ __forceinline__ Xf planet_pose(const DScene &S, int p, int idx) {
 //   want_dist   : compute d_static (A7) and d_moving (A8) - the end-of-step sample
 //   want_contact: compute the Bullet-contact flag between planets and robot links (A11)
 // ---------------------------------------------------------------------------------------------
-struct Sample { float d_static, d_moving; bool contact; };
+struct Sample { float d_static, d_moving, d_self; bool contact; };
+
+// frame of body b (>= 8: rigidly mounted on iiwa_link_7, whose frame is T7)
+__device__ __forceinline__ Xf mounted_frame(const DScene &S, int b, const Xf &T7) {
+    Xf X;
+    X.t = apply(T7, F3{S.body_xyz[b][0], S.body_xyz[b][1], S.body_xyz[b][2]});
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            X.r[3 * i + j] = T7.r[3 * i] * S.body_rot[b][j] + T7.r[3 * i + 1] * S.body_rot[b][3 + j] + T7.r[3 * i + 2] * S.body_rot[b][6 + j];
+    return X;
+}
+
+// frame of body b for joint vector q
+__device__ inline Xf body_frame(const DScene &S, const float q[SMR_NJ], int b) {
+    const int link = b < SMR_NLINK ? b : SMR_NLINK - 1;
+    Xf T = fk_base(S);
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j)
+        if (j < link) fk_advance(S, j, q[j], T);
+    return b < SMR_NLINK ? T : mounted_frame(S, b, T);
+}
+
+// A7 self: distance of self-collision pair i = (body a with hull (LP, hull) under T, partner): the partner is another
+// chain link (its hull climbed from the global tables, per lane) or the base adapter's cylinder in the world frame
+// (btCylinderShapeZ::localGetSupportingVertexWithoutMargin).  Margins subtracted; > cutoff means "farther than cutoff".
+template <class HB>
+__device__ inline float self_pair_distance(const DScene &S, int i, const float q[SMR_NJ], const DPiece &LP, const HB &hull,
+                                           const Xf &T, float cutoff, float stop_below) {
+    const int partner = S.self_pair[i][1];
+    const int pa = partner >= 0 ? S.link_piece[partner] : -(partner + 1);
+    const DPiece A = load_piece(S.pieces, pa);
+    const float margins = A.margin + LP.margin;
+    const F3 cb = apply(T, F3{LP.cx, LP.cy, LP.cz});
+    const auto sb = [&](F3 d, int &hint, bool first) { return apply(T, hull.support(rot_t(T, d), hint, first)); };
+    if (partner >= 0) {
+        const Xf XA = body_frame(S, q, partner);
+        const F3 d = apply(XA, F3{A.cx, A.cy, A.cz}) - cb;
+        const float lb = sqrtf(dot(d, d)) - A.radius - LP.radius - margins;
+        if (lb > cutoff) return lb;
+        const GlobalHull ha = global_hull(S, pa, A);
+        const auto sa = [&](F3 dd, int &hint, bool first) { return apply(XA, ha.support(rot_t(XA, dd), hint, first)); };
+        return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins) - margins;
+    }
+    const F3 d = F3{A.cx, A.cy, A.cz} - cb;
+    const float lb = sqrtf(dot(d, d)) - A.radius - LP.radius - margins;
+    if (lb > cutoff) return lb;
+    const auto sa = [&](F3 dd, int &, bool) {
+        const float sxy = sqrtf(dd.x * dd.x + dd.y * dd.y);
+        F3 p = sxy > 0.f ? F3{A.cx + A.cyl_r * dd.x / sxy, A.cy + A.cyl_r * dd.y / sxy, A.cz} : F3{A.cx + A.cyl_r, A.cy, A.cz};
+        p.z += dd.z < 0.f ? -A.cyl_h : A.cyl_h;
+        return p;
+    };
+    return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins) - margins;
+}
 
 __device__ inline Sample collide_sample(const DScene &S, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS],
                                         bool want_dist, bool want_contact) {
     Sample out;
     out.d_static = S.static_max;
+    out.d_self = S.static_max;
     out.d_moving = S.moving_max + 0.002f;          // ctlp.py:3261
     out.contact = false;
     Xf XP[SMR_MAX_PLANETS];
@@ -728,10 +799,11 @@ __device__ inline Sample collide_sample(const DScene &S, const float q[SMR_NJ], 
         if (p < S.n_planets) XP[p] = planet_pose(S, p, idx[p]);
     // once a contact is certain the moving distance is 0 anyway (ctlp.py:3229-3234)
     const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
-    Xf T = fk_base(S);
-    Xf I = T;   // unused placeholder for the identity branch
-    for (int l = 0; l < SMR_NLINK; ++l) {
-        if (l > 0) fk_advance(S, l - 1, q[l - 1], T);
+    Xf Tc = fk_base(S);
+    Xf I = Tc;   // unused placeholder for the identity branch
+    for (int l = 0; l < S.n_bodies; ++l) {
+        if (l > 0 && l < SMR_NLINK) fk_advance(S, l - 1, q[l - 1], Tc);
+        const Xf T = l < SMR_NLINK ? Tc : mounted_frame(S, l, Tc);
         const int pl = S.link_piece[l];
         const DPiece LP = load_piece(S.pieces, pl);
         const GlobalHull hull = global_hull(S, pl, LP);
@@ -741,6 +813,12 @@ __device__ inline Sample collide_sample(const DScene &S, const float q[SMR_NJ], 
                 if (d <= S.static_max && d < out.d_static) out.d_static = d;
             }
         }
+        if (want_dist)
+            for (int i = 0; i < S.n_self_pairs; ++i) {
+                if (S.self_pair[i][0] != l) continue;
+                float d = self_pair_distance(S, i, q, LP, hull, T, out.d_self, S.collision_dist);
+                if (d <= S.static_max && d < out.d_self) out.d_self = d;
+            }
         const bool mov_link = (S.moving_mask >> l) & 1u, con_link = (S.contact_mask >> l) & 1u;
         if (!(mov_link || con_link)) continue;
         const F3 lc = apply(T, F3{LP.cx, LP.cy, LP.cz});
@@ -811,9 +889,10 @@ __device__ __forceinline__ int ball_retire_update(const DScene &S, int k, int km
 template <class HB>
 __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, const HB &hull, const Xf &T,
                                       const int idx[SMR_MAX_PLANETS], const Xf *XB, bool want_static, bool want_moving,
-                                      bool want_contact) {
+                                      bool want_contact, const float *q_self = nullptr) {
     Sample out;
     out.d_static = S.static_max;
+    out.d_self = S.static_max;
     out.d_moving = S.moving_max + 0.002f;
     out.contact = false;
     if (want_static && ((S.static_mask >> l) & 1u)) {
@@ -822,6 +901,12 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
             if (d <= S.static_max && d < out.d_static) out.d_static = d;
         }
     }
+    if (q_self)                                         // end-of-step sample: the self-collision pairs of this body
+        for (int i = 0; i < S.n_self_pairs; ++i) {
+            if (S.self_pair[i][0] != l) continue;
+            float d = self_pair_distance(S, i, q_self, LP, hull, T, out.d_self, S.collision_dist);
+            if (d <= S.static_max && d < out.d_self) out.d_self = d;
+        }
     const bool mov = want_moving && ((S.moving_mask >> l) & 1u);
     const bool con_link = (S.contact_mask >> l) & 1u;
     if (!(mov || (want_contact && con_link))) return out;

@@ -43,13 +43,13 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
 }
 
-// one lane per (env, sample k, link l); grid = (B/64, N, 8)
+// one lane per (env, sample k, body l); grid = (B/64, N, n_bodies)
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
-    const int l = SMR_NLINK - 1 - (int)blockIdx.z;     // iiwa_link_l; the outer links (most planet work) are dispatched first
+    const int l = S.n_bodies - 1 - (int)blockIdx.z;    // body l; the outer bodies (most planet work) are dispatched first
     // the link's hull, edge graph and start map staged in LDS: every support call of this block climbs over them
     __shared__ float lds_v[4 * kMaxPieceVerts];
     __shared__ uint32_t lds_span[kMaxPieceVerts];
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_
     const int k = N - (int)blockIdx.y;                 // sample k of N, t_k = k dt / N; the end-of-step sample (distances) first
     const bool final_sample = (k == N);
     const int upd = S.updates_per_step / N;
-    float *res = st.res + ((size_t)(k - 1) * SMR_NLINK + l) * B;
+    const int NB = S.n_bodies;
+    float *res = st.res + ((size_t)(k - 1) * NB + l) * B;
     const bool con_link = (S.contact_mask >> l) & 1u;
     bool want_contact, moving_alive = true;
     BallState ball;
@@ -96,29 +97,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_
     }
     const bool want_static = final_sample && ((S.static_mask >> l) & 1u);
     const bool want_moving = final_sample && moving_alive && ((S.moving_mask >> l) & 1u);
-    if (final_sample) { st.dist[(size_t)l * B + e] = S.static_max; st.dist[(size_t)(SMR_NLINK + l) * B + e] = S.moving_max + 0.002f; }
-    res[e] = 0.f;
-    if (!want_static && !want_moving && !want_contact) return;
-    const float t = final_sample ? S.dt : S.dt * (float)k / (float)N;
-    Xf T = fk_base(S);
-    for (int j = 0; j < l; ++j) {                      // FK up to this link; joint values straight from the cubic
-        float qj = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
-        fk_advance(S, j, qj, T);
+    bool want_self = false;                            // this body has self-collision pairs (ball machine pieces)
+    for (int i = 0; i < S.n_self_pairs; ++i) want_self |= final_sample && S.self_pair[i][0] == l;
+    if (final_sample) {
+        st.dist[(size_t)l * B + e] = S.static_max; st.dist[(size_t)(NB + l) * B + e] = S.moving_max + 0.002f;
+        st.dist[(size_t)(2 * NB + l) * B + e] = S.static_max;
     }
+    res[e] = 0.f;
+    if (!want_static && !want_moving && !want_contact && !want_self) return;
+    const float t = final_sample ? S.dt : S.dt * (float)k / (float)N;
+    const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
+    Xf T = fk_base(S);
+    float qs[SMR_NJ] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j)                   // FK up to this body's link; joint values straight from the cubic
+        if (j < chain) {
+            qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
+            fk_advance(S, j, qs[j], T);
+        }
+    if (l >= SMR_NLINK) T = mounted_frame(S, l, T);
     Sample r;
     if (S.use_ball) {
         Xf XB = ball_pose(S, ball, ball_k, nullptr);
         const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near);
+        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near, want_self ? qs : nullptr);
     } else {
         int idx[SMR_MAX_PLANETS] = {0, 0};
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
-        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact);
+        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, want_self ? qs : nullptr);
     }
     res[e] = r.contact ? 1.f : 0.f;
-    if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(SMR_NLINK + l) * B + e] = r.d_moving; }
+    if (final_sample) {
+        st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving;
+        st.dist[(size_t)(2 * NB + l) * B + e] = r.d_self;
+    }
 }
 
 // env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
@@ -160,13 +174,14 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     const int steps = st.step_count[e] + 1;                                   // base.py:1044
     int hit = st.moving_hit[e];
     int contact = 0;
-    for (int k = 0; k < N * SMR_NLINK; ++k) contact |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;
+    const int NB = S.n_bodies;
+    for (int k = 0; k < N * NB; ++k) contact |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;
     if (S.term_moving && S.n_planets > 0) hit |= contact;                     // ctlp.py:2631-2637
     float d_static = S.static_max, d_self = S.static_max, d_moving = S.moving_max + 0.002f;
-#pragma unroll
-    for (int l = 0; l < SMR_NLINK; ++l) {                                     // minimum over links, ctlp.py:3263-3278,3294-3320
+    for (int l = 0; l < NB; ++l) {                                            // minimum over bodies, ctlp.py:3263-3278,3294-3372
         d_static = fminf(d_static, st.dist[(size_t)l * B + e]);
-        d_moving = fminf(d_moving, st.dist[(size_t)(SMR_NLINK + l) * B + e]);
+        d_moving = fminf(d_moving, st.dist[(size_t)(NB + l) * B + e]);
+        d_self = fminf(d_self, st.dist[(size_t)(2 * NB + l) * B + e]);
     }
 
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ], amax = 0.f, vrel = 0.f, arel = 0.f;
@@ -290,63 +305,73 @@ struct Group {
     }
 };
 
-__device__ __forceinline__ Xf link_frame(const DScene &S, const float q[SMR_NJ], int l) {
-    Xf T = fk_base(S);
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j)
-        if (j < l) fk_advance(S, j, q[j], T);
-    return T;
-}
+// Lane g of a group works the bodies g, g + 8, ... (8 chain links; the ball machine's pieces fold onto lanes 0, 1).
 
-// table clearance of ONE link (ctlp.py:2140-2168, 1605-1619; self-collision: no pairs for one iiwa)
-__device__ inline bool link_table_free(const DScene &S, int l, const Xf &T, float thr) {
-    if (!((S.static_mask >> l) & 1u)) return true;
-    const int pl = S.link_piece[l];
+// table and self-collision clearance of ONE body (ctlp.py:2140-2208, 1605-1619)
+__device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ], const Xf &T, float thr, float thr_self) {
+    const int pl = S.link_piece[b];
     const DPiece LP = load_piece_lane(S.pieces, pl);
     const GlobalHull hull = global_hull(S, pl, LP);
     bool ok = true;
-    for (int s = 0; s < S.n_static; ++s) {
-        float d = piece_distance<true>(S, S.static_piece[s], T, LP, hull, T, thr + 0.005f, 0.f);
-        if (d <= thr + 0.005f && d < thr) ok = false;
+    if ((S.static_mask >> b) & 1u)
+        for (int s = 0; s < S.n_static; ++s) {
+            float d = piece_distance<true>(S, S.static_piece[s], T, LP, hull, T, thr + 0.005f, 0.f);
+            if (d <= thr + 0.005f && d < thr) ok = false;
+        }
+    for (int i = 0; i < S.n_self_pairs; ++i) {
+        if (S.self_pair[i][0] != b) continue;
+        float d = self_pair_distance(S, i, q, LP, hull, T, thr_self + 0.005f, 0.f);
+        if (d <= thr_self + 0.005f && d < thr_self) ok = false;
     }
     return ok;
 }
 
 // A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138, for one candidate q.  box / thr: cartesian
-// range of the end-effector point and minimum table distance (start states ctlp.py:172-183,1468-1477; ball
-// targets ctlp.py:191-229,1725-1726).  (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is outside
-// the kinematic path.)
-__device__ inline bool group_pose_valid(const DScene &S, const Group &G, const float q[SMR_NJ], const float box[3][2], float thr) {
-    const Xf T = link_frame(S, q, G.g);
-    bool ok = link_table_free(S, G.g, T, thr);
-    if (G.g == SMR_NLINK - 1) {
-        F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});                // ctlp.py:2051-2061
-        if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) ok = false;
+// range of the end-effector point and minimum table / self distances (start states ctlp.py:172-183,1468-1477; ball
+// targets ctlp.py:191-229,1725-1726,2357).  (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is
+// outside the kinematic path.)
+__device__ inline bool group_pose_valid(const DScene &S, const Group &G, const float q[SMR_NJ], const float box[3][2], float thr,
+                                        float thr_self) {
+    bool ok = true;
+    for (int b = G.g; b < S.n_bodies; b += 8) {
+        const Xf T = body_frame(S, q, b);
+        ok = ok && body_clear(S, b, q, T, thr, thr_self);
+        if (b == S.ee_body) {
+            F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});            // ctlp.py:2051-2061
+            if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) ok = false;
+        }
     }
     return G.all(ok);
 }
 
 __device__ inline bool group_table_free(const DScene &S, const Group &G, const float q[SMR_NJ]) {
-    return G.all(link_table_free(S, G.g, link_frame(S, q, G.g), S.start_min_static));
+    bool ok = true;
+    for (int b = G.g; b < S.n_bodies; b += 8) ok = ok && body_clear(S, b, q, body_frame(S, q, b), S.start_min_static, S.start_min_self);
+    return G.all(ok);
 }
 
-// Bullet contact between any planet piece and any robot link (Planet.check_if_object_is_colliding, ctlp.py:4570-4579)
+// Bullet contact between any planet piece and any robot body (Planet.check_if_object_is_colliding, ctlp.py:4570-4579)
 __device__ inline bool group_planet_contact(const DScene &S, const Group &G, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS]) {
-    const int pl = S.link_piece[G.g];
-    const DPiece LP = load_piece_lane(S.pieces, pl);
-    const Sample r = collide_link(S, G.g, LP, global_hull(S, pl, LP), link_frame(S, q, G.g), idx, nullptr, false, false, true);
-    return G.any(r.contact);
+    bool contact = false;
+    for (int b = G.g; b < S.n_bodies; b += 8) {
+        const int pl = S.link_piece[b];
+        const DPiece LP = load_piece_lane(S.pieces, pl);
+        const Sample r = collide_link(S, b, LP, global_hull(S, pl, LP), body_frame(S, q, b), idx, nullptr, false, false, true);
+        contact = contact || r.contact;
+    }
+    return G.any(contact);
 }
 
-// is the ball (pose XB) within Bullet's contact distance of any robot link? (Ball.check_if_object_is_colliding, ctlp.py:4186-4194)
+// is the ball (pose XB) within Bullet's contact distance of any robot body? (Ball.check_if_object_is_colliding, ctlp.py:4186-4194)
 __device__ inline bool group_ball_contact(const DScene &S, const Group &G, const float q[SMR_NJ], const Xf &XB) {
     bool contact = false;
-    if ((S.contact_mask >> G.g) & 1u) {
-        const int pl = S.link_piece[G.g];
-        const DPiece LP = load_piece_lane(S.pieces, pl);
-        float d = piece_distance<false>(S, S.ball_piece, XB, LP, global_hull(S, pl, LP), link_frame(S, q, G.g), S.contact_dist, S.contact_dist);
-        contact = d <= S.contact_dist;
-    }
+    for (int b = G.g; b < S.n_bodies; b += 8)
+        if ((S.contact_mask >> b) & 1u) {
+            const int pl = S.link_piece[b];
+            const DPiece LP = load_piece_lane(S.pieces, pl);
+            float d = piece_distance<false>(S, S.ball_piece, XB, LP, global_hull(S, pl, LP), body_frame(S, q, b), S.contact_dist, S.contact_dist);
+            contact = contact || d <= S.contact_dist;
+        }
     return G.any(contact);
 }
 
@@ -366,7 +391,15 @@ __device__ inline void ee_point_f64(const DScene &S, const float q[SMR_NJ], doub
             for (int j = 0; j < 3; ++j) n[3 * i + j] = R[3 * i] * J[j] + R[3 * i + 1] * J[3 + j] + R[3 * i + 2] * J[6 + j];
         for (int i = 0; i < 9; ++i) R[i] = n[i];
     }
-    for (int i = 0; i < 3; ++i) ee[i] = t[i] + R[3 * i] * S.ee_offset[0] + R[3 * i + 1] * S.ee_offset[1] + R[3 * i + 2] * S.ee_offset[2];
+    double off[3] = {S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]};
+    if (S.ee_body >= SMR_NLINK) {          // the target link is mounted on iiwa_link_7 (ball machine): offset in ITS frame
+        const int b = S.ee_body;
+        double o2[3];
+        for (int i = 0; i < 3; ++i)
+            o2[i] = S.body_xyz[b][i] + S.body_rot[b][3 * i] * off[0] + S.body_rot[b][3 * i + 1] * off[1] + S.body_rot[b][3 * i + 2] * off[2];
+        for (int i = 0; i < 3; ++i) off[i] = o2[i];
+    }
+    for (int i = 0; i < 3; ++i) ee[i] = t[i] + R[3 * i] * off[0] + R[3 * i + 1] * off[1] + R[3 * i + 2] * off[2];
 }
 
 // Ball.get_target_height_time, ctlp.py:4346-4361
@@ -401,7 +434,7 @@ __device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, co
             float q[SMR_NJ];
             G.gather(rng.uniform(S_BALL_POSE, 7u * pose_attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
             ++pose_attempt;
-            if (group_pose_valid(S, G, q, S.ball_target_box, S.ball_target_min_static)) { ee_point_f64(S, q, target); break; }
+            if (group_pose_valid(S, G, q, S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); break; }
         }
         const double dx = target[0] - rel[0], dy = target[1] - rel[1], dh = target[2] - rel[2];
         const double dxy = sqrt(dx * dx + dy * dy);
@@ -554,7 +587,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         for (int tries = 0; tries < 100000; ++tries) {
             G.gather(rng.uniform(S_POS, 7u * attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);               // ctlp.py:2035-2037
             ++attempt;
-            if (group_pose_valid(S, G, q, S.start_box, S.start_min_static)) return;
+            if (group_pose_valid(S, G, q, S.start_box, S.start_min_static, S.start_min_self)) return;
         }
     };
     next_position();
@@ -757,7 +790,7 @@ __global__ void test_distances_kernel(const DScene *__restrict__ Sp, const float
     int idx[SMR_MAX_PLANETS] = {pidx[2 * i], pidx[2 * i + 1]};
     Sample d = collide_sample(S, qq, idx, true, false);
     Sample c = collide_sample(S, qq, idx, false, true);
-    out[4 * i] = d.d_static; out[4 * i + 1] = S.static_max; out[4 * i + 2] = d.d_moving; out[4 * i + 3] = c.contact ? 1.f : 0.f;
+    out[4 * i] = d.d_static; out[4 * i + 1] = d.d_self; out[4 * i + 2] = d.d_moving; out[4 * i + 3] = c.contact ? 1.f : 0.f;
 }
 
 __global__ void test_ball_distances_kernel(const DScene *__restrict__ Sp, const float *__restrict__ q, const float *__restrict__ ball,
@@ -771,16 +804,17 @@ __global__ void test_ball_distances_kernel(const DScene *__restrict__ Sp, const 
     const Xf XB = ball_pose(S, b, kk[i], nullptr);
     float dst = S.static_max, dmv = S.moving_max + 0.002f;
     bool contact = false;
-    Xf T = fk_base(S);
-    for (int l = 0; l < SMR_NLINK; ++l) {
-        if (l > 0) fk_advance(S, l - 1, q[i * SMR_NJ + l - 1], T);
+    float qq[SMR_NJ], dsf = S.static_max;
+    for (int j = 0; j < SMR_NJ; ++j) qq[j] = q[i * SMR_NJ + j];
+    for (int l = 0; l < S.n_bodies; ++l) {
+        const Xf T = body_frame(S, qq, l);
         const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
         const GlobalHull hull = global_hull(S, S.link_piece[l], LP);
-        Sample d = collide_link(S, l, LP, hull, T, nullptr, &XB, true, true, false);
+        Sample d = collide_link(S, l, LP, hull, T, nullptr, &XB, true, true, false, qq);
         Sample c = collide_link(S, l, LP, hull, T, nullptr, &XB, false, false, true);
-        dst = fminf(dst, d.d_static); dmv = fminf(dmv, d.d_moving); contact = contact || c.contact;
+        dst = fminf(dst, d.d_static); dmv = fminf(dmv, d.d_moving); dsf = fminf(dsf, d.d_self); contact = contact || c.contact;
     }
-    out[4 * i] = dst; out[4 * i + 1] = S.static_max; out[4 * i + 2] = dmv; out[4 * i + 3] = contact ? 1.f : 0.f;
+    out[4 * i] = dst; out[4 * i + 1] = dsf; out[4 * i + 2] = dmv; out[4 * i + 3] = contact ? 1.f : 0.f;
 }
 
 }  // namespace smr
@@ -860,10 +894,9 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
 
     HostGeometry G;
     if (const char *msg = build_host_geometry(s, G)) { env->err = msg; return SMR_E_INVALID; }
-    for (int l = 0; l < SMR_NLINK; ++l) {
-        const int p = s.link_piece[l];
-        if (p >= 0 && p < s.n_pieces && G.pieces[p].ids_count > kMaxPieceIdGroups) { env->err = "link hull adjacency exceeds the LDS budget"; return SMR_E_INVALID; }
-    }
+    if (const char *msg = scene_bodies(s, d)) { env->err = msg; return SMR_E_INVALID; }
+    for (int l = 0; l < s.n_bodies; ++l)
+        if (G.pieces[s.link_piece[l]].ids_count > kMaxPieceIdGroups) { env->err = "link hull adjacency exceeds the LDS budget"; return SMR_E_INVALID; }
     const std::vector<DPiece> &pieces = G.pieces;
     float4 *dverts; DPiece *dpieces; uint32_t *dspan, *dids; uint8_t *dstart;
     int rc;
@@ -872,7 +905,6 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
         (rc = dev_upload(env, &dids, G.ids4)) || (rc = dev_upload(env, &dstart, G.start))) return rc;
     d.verts = dverts; d.pieces = dpieces; d.span = dspan; d.ids4 = dids; d.start = dstart;
     auto piece_ok = [&](int p) { return p >= 0 && p < s.n_pieces; };
-    for (int l = 0; l < SMR_NLINK; ++l) { if (!piece_ok(s.link_piece[l])) { env->err = "bad link_piece"; return SMR_E_INVALID; } d.link_piece[l] = s.link_piece[l]; }
     if (s.n_static < 0 || s.n_static > SMR_MAX_STATIC) { env->err = "bad n_static"; return SMR_E_INVALID; }
     d.n_static = s.n_static;
     for (int i = 0; i < s.n_static; ++i) { if (!piece_ok(s.static_piece[i])) { env->err = "bad static_piece"; return SMR_E_INVALID; } d.static_piece[i] = s.static_piece[i]; }
@@ -912,7 +944,7 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
             d.ball_center[c] = s.ball_sphere_center[c]; d.ball_invalid_min[c] = s.ball_invalid_min[c]; d.ball_invalid_max[c] = s.ball_invalid_max[c];
             d.ball_final_min[c] = s.ball_final_min[c]; d.ball_final_max[c] = s.ball_final_max[c];
         }
-        d.ball_target_min_static = (float)s.ball_target_min_dist_static; d.ball_speed = s.ball_speed; d.ball_sphere_radius = s.ball_sphere_radius;
+        d.ball_target_min_static = (float)s.ball_target_min_dist_static; d.ball_target_min_self = (float)s.ball_target_min_dist_self; d.ball_speed = s.ball_speed; d.ball_sphere_radius = s.ball_sphere_radius;
         d.ball_height[0] = s.ball_sphere_height[0]; d.ball_height[1] = s.ball_sphere_height[1];
         d.ball_angle[0] = s.ball_sphere_angle[0]; d.ball_angle[1] = s.ball_sphere_angle[1]; d.ball_high_prob = s.ball_high_angle_prob;
         d.plane_z = s.plane_z; d.table_half_xy[0] = s.table_half_xy[0]; d.table_half_xy[1] = s.table_half_xy[1];
@@ -995,7 +1027,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)env->N * SMR_NLINK * B)) || (rc = dev_alloc(env, &st.dist, 2 * SMR_NLINK * B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)env->N * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)3 * scene->n_bodies * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &st.spawn_list, B)) || (rc = dev_alloc(env, &st.spawn_count, 1)))
         return fail(rc);
@@ -1196,7 +1228,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipGetLastError());
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
-        hipLaunchKernelGGL(collide_kernel, dim3((B + 63) / 64, env->N, SMR_NLINK), dim3(64), 0, env->stream, env->dscene, env->st);
+        hipLaunchKernelGGL(collide_kernel, dim3((B + 63) / 64, env->N, env->hscene.n_bodies), dim3(64), 0, env->stream, env->dscene, env->st);
     }
     SMR_HIP(hipGetLastError());
     const bool staged = env->staged && env->auto_reset;

@@ -47,6 +47,9 @@ inline const char *build_host_geometry(const smr_scene_t &s, HostGeometry &G) {
         }
         q.cx = (float)p.center[0]; q.cy = (float)p.center[1]; q.cz = (float)p.center[2];
         q.margin = (float)p.margin;
+        q.kind = p.kind; q.cyl_r = (float)p.cyl_radius; q.cyl_h = (float)p.cyl_half_length;
+        if (p.kind != SMR_PIECE_HULL && p.kind != SMR_PIECE_CYLINDER_Z) return "unknown piece kind";
+        if (p.kind == SMR_PIECE_CYLINDER_Z && !(p.cyl_radius > 0 && p.cyl_half_length > 0)) return "bad cylinder piece";
         // bounding data recomputed in float32 around the float32 centre, slightly inflated, so culling stays conservative
         float r = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
         for (int k = 0; k < p.vert_count; ++k) {
@@ -109,6 +112,32 @@ inline const char *build_host_geometry(const smr_scene_t &s, HostGeometry &G) {
     }
     for (int k = 0; k < 8; ++k) { G.verts.push_back(float4{0.f, 0.f, 0.f, 0.f}); G.span.push_back(0u); }   // slack for the last unrolled load
     G.ids4.push_back(0u);
+    return nullptr;
+}
+
+// bodies, their mounting transforms and the self-collision pairs (DScene image of the smr_scene_t fields); nullptr or a message
+inline const char *scene_bodies(const smr_scene_t &s, DScene &d) {
+    if (s.n_bodies < SMR_NLINK || s.n_bodies > SMR_MAX_BODIES) return "bad n_bodies";
+    d.n_bodies = s.n_bodies;
+    for (int b = 0; b < s.n_bodies; ++b) {
+        if (s.link_piece[b] < 0 || s.link_piece[b] >= s.n_pieces) return "bad link_piece";
+        if (s.pieces[s.link_piece[b]].kind != SMR_PIECE_HULL) return "a robot body must be a convex hull piece";
+        d.link_piece[b] = s.link_piece[b];
+        d.body_parent[b] = s.body_parent[b];
+        if (b < SMR_NLINK ? s.body_parent[b] != b : s.body_parent[b] != SMR_NLINK - 1) return "bodies beyond the chain must be mounted on iiwa_link_7";
+        for (int c = 0; c < 3; ++c) d.body_xyz[b][c] = (float)s.body_xyz[b][c];
+        for (int c = 0; c < 9; ++c) d.body_rot[b][c] = (float)s.body_rot[b][c];
+    }
+    if (s.ee_body < 0 || s.ee_body >= s.n_bodies) return "bad ee_body";
+    d.ee_body = s.ee_body;
+    if (s.n_self_pairs < 0 || s.n_self_pairs > SMR_MAX_SELF_PAIRS) return "bad n_self_pairs";
+    d.n_self_pairs = s.n_self_pairs;
+    for (int i = 0; i < s.n_self_pairs; ++i) {
+        const int a = s.self_pair[i][0], b = s.self_pair[i][1];
+        if (a < 0 || a >= s.n_bodies) return "bad self pair";
+        if (b >= 0 ? (b >= SMR_NLINK || b == a) : (-(b + 1) >= s.n_pieces)) return "bad self pair partner";
+        d.self_pair[i][0] = a; d.self_pair[i][1] = b;
+    }
     return nullptr;
 }
 

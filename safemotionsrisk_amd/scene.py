@@ -17,9 +17,11 @@ import os
 
 import numpy as np
 
-SCENE_VERSION = 4
+SCENE_VERSION = 5
 NJ = 7
 NLINK = 8
+MAX_BODIES = 10
+MAX_SELF_PAIRS = 16
 MAX_PLANETS = 2
 MAX_STATIC = 4
 
@@ -32,9 +34,13 @@ BULLET_CONTACT_BREAKING_THRESHOLD = 0.02         # Bullet gContactBreakingThresh
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "iiwa7_assets.npz")
 
 
+PIECE_HULL, PIECE_CYLINDER_Z = 0, 1
+
+
 class Piece(C.Structure):
     _fields_ = [("vert_begin", C.c_int32), ("vert_count", C.c_int32), ("center", C.c_double * 3),
-                ("radius", C.c_double), ("margin", C.c_double)]
+                ("radius", C.c_double), ("margin", C.c_double), ("kind", C.c_int32), ("_pad", C.c_int32),
+                ("cyl_radius", C.c_double), ("cyl_half_length", C.c_double)]
 
 
 class Planet(C.Structure):
@@ -57,7 +63,10 @@ class Scene(C.Structure):
         ("base_xyz", _D3), ("joint_xyz", _D3 * NJ), ("joint_axis", _D3 * NJ), ("ee_offset", _D3),
         ("verts", C.POINTER(C.c_double)), ("pieces", C.POINTER(Piece)),
         ("adj_offsets", C.POINTER(C.c_int32)), ("adj", C.POINTER(C.c_int32)),
-        ("n_verts", C.c_int32), ("n_pieces", C.c_int32), ("link_piece", C.c_int32 * NLINK),
+        ("n_verts", C.c_int32), ("n_pieces", C.c_int32), ("n_bodies", C.c_int32), ("link_piece", C.c_int32 * MAX_BODIES),
+        ("body_parent", C.c_int32 * MAX_BODIES), ("ee_body", C.c_int32),
+        ("body_xyz", _D3 * MAX_BODIES), ("body_rot", (C.c_double * 9) * MAX_BODIES),
+        ("n_self_pairs", C.c_int32), ("self_pair", (C.c_int32 * 2) * MAX_SELF_PAIRS),
         ("n_static", C.c_int32), ("static_piece", C.c_int32 * MAX_STATIC), ("static_link_mask", C.c_uint32),
         ("static_max_distance", C.c_double),
         ("moving_link_mask", C.c_uint32), ("contact_link_mask", C.c_uint32),
@@ -73,7 +82,7 @@ class Scene(C.Structure):
         ("ball_invalid_min", _D3), ("ball_invalid_max", _D3), ("ball_final_min", _D3), ("ball_final_max", _D3),
         ("ball_obs_pos_min", _D3), ("ball_obs_pos_max", _D3), ("ball_obs_vel_min", _D3), ("ball_obs_vel_max", _D3),
         ("ball_active_xy_radius", C.c_double), ("ball_target_box", (C.c_double * 2) * 3),
-        ("ball_target_min_dist_static", C.c_double), ("plane_z", C.c_double), ("table_half_xy", C.c_double * 2),
+        ("ball_target_min_dist_static", C.c_double), ("ball_target_min_dist_self", C.c_double), ("plane_z", C.c_double), ("table_half_xy", C.c_double * 2),
         ("punish_action", C.c_int32), ("terminate_on_self_collision", C.c_int32),
         ("terminate_on_static_collision", C.c_int32), ("terminate_on_moving_collision", C.c_int32),
         ("action_punishment_min_threshold", C.c_double), ("action_max_punishment", C.c_double),
@@ -163,7 +172,7 @@ _DEFAULTS = dict(
 
 # features of the reference outside the hot-path scope ("out of scope"/"next")
 _UNSUPPORTED_TRUE = ("use_real_robot", "use_target_points", "check_braking_trajectory_collisions",
-                     "check_braking_trajectory_torque_limits", "ball_machine_mode", "use_gui", "render_video",
+                     "check_braking_trajectory_torque_limits", "use_gui", "render_video",
                      "risk_check_initial_backup_trajectory", "risk_store_ground_truth", "static_robot",
                      "moving_object_aim_at_current_robot_position", "normalize_reward_to_frequency",
                      "obstacle_use_computed_actual_values", "always_use_collision_avoidance_starting_point_sampling")
@@ -297,6 +306,8 @@ def _build_ball(config, s, assets, add_piece):
     s.ball_radius, s.ball_speed, s.ball_sphere_radius = ball_radius, speed, radius
     s.ball_piece = add_piece(assets["ball_verts"] * (ball_radius / 0.12), _piece_adj(assets, "ball", 0))               # ctlp.py:4043-4044 globalScaling
     s.moving_link_mask = _link_mask(["iiwa_link_%d" % i for i in range(2, 8)])          # scene.py:226-228
+    for k in range(NLINK, s.n_bodies):                                                   # + the ball machine, scene.py:229-230
+        s.moving_link_mask |= 1 << k
     for c in range(3):
         s.ball_sphere_center[c] = center[c]
     s.ball_sphere_height[0], s.ball_sphere_height[1] = h
@@ -331,6 +342,7 @@ def _build_ball(config, s, assets, add_piece):
     for c in range(3):
         s.ball_target_box[c][0], s.ball_target_box[c][1] = tbox[c]
     s.ball_target_min_dist_static = float(_cfg(config, "closest_point_safety_distance")) + 0.09   # ctlp.py:1725-1726
+    s.ball_target_min_dist_self = float(_cfg(config, "closest_point_safety_distance"))            # ctlp.py:2357
 
 
 def _piece_adj(assets, family, i):
@@ -413,8 +425,11 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
             s.joint_xyz[j][c] = assets["robot_joint_xyz"][j][c]
             s.joint_axis[j][c] = assets["robot_joint_axis"][j][c]
     offset = _cfg(config, "target_link_offset")
-    if offset is None:
-        offset = [0, 0, 0.126]                                                           # scene.py:203-204
+    if offset is None:                                                                   # scene.py:196-208
+        if config.get("ball_machine_mode"):
+            offset = [0, 0, 0.10] if config.get("use_target_points") else [0, 0, 0]
+        else:
+            offset = [0, 0, 0.126]
     for c in range(3):
         s.base_xyz[c] = assets["robot_base_xyz"][c]
         s.ee_offset[c] = offset[c]
@@ -430,26 +445,67 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
         vert_blocks.append(np.asarray(v, dtype=np.float64))
         adj_blocks.append(adj)
         c, r = _bounding_sphere(vert_blocks[-1])
-        pieces.append((begin, len(v), c, r, margin))
+        pieces.append([begin, len(v), c, r, margin, PIECE_HULL, 0.0, 0.0])
         return len(pieces) - 1
+
+    # corner i of a box = sign bits (x, y, z) of i: the box edges join corners that differ in one bit
+    corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
+    box_adj = (np.arange(0, 25, 3, dtype=np.int32), np.array([i ^ b for i in range(8) for b in (1, 2, 4)], dtype=np.int32))
 
     lo = assets["link_offsets"]
     for k in range(NLINK):
         s.link_piece[k] = add_piece(assets["link_verts"][lo[k]:lo[k + 1]], _piece_adj(assets, "link", k))
+        s.body_parent[k] = k
+    for k in range(MAX_BODIES):
+        for c in range(9):
+            s.body_rot[k][c] = 1.0 if c in (0, 4, 8) else 0.0
+    s.n_bodies = NLINK
+    s.ee_body = NLINK - 1                                                                # iiwa_link_7, scene.py:191-192
+    s.n_self_pairs = 0
+    ball_machine = bool(config.get("ball_machine_mode"))
+    body_names = ["iiwa_link_%d" % i for i in range(NLINK)]
+    if ball_machine:
+        # robot_ball_machine.urdf: link "ball_machine" (a compound of convex pieces, one body each) fixed on iiwa_link_7;
+        # it is the target link (scene.py:188-189), closest_point_active (ctlp.py:585-586) and pairs with the base
+        # adapter and iiwa_link_0..5 for self-collisions (ctlp.py:1438-1446)
+        bo = assets["bm_offsets"]
+        # base adapter: Bullet cylinder of radius r, length L has the implicit core (r - margin, L/2 - margin) plus the margin
+        rad, length = [float(x) for x in assets["adapter_radius_length"]]
+        adapter = add_piece(assets["adapter_center"] + corners * np.array([rad, rad, 0.5 * length]), box_adj)
+        pieces[adapter][5:] = [PIECE_CYLINDER_Z, rad - margin, 0.5 * length - margin]
+        pieces[adapter][2] = np.asarray(assets["adapter_center"], dtype=np.float64)
+        for i in range(len(bo) - 1):
+            k = s.n_bodies
+            if k >= MAX_BODIES:
+                raise ValueError("too many ball machine pieces")
+            s.link_piece[k] = add_piece(assets["bm_verts"][bo[i]:bo[i + 1]], _piece_adj(assets, "bm", i))
+            s.body_parent[k] = NLINK - 1
+            for c in range(3):
+                s.body_xyz[k][c] = assets["bm_joint_xyz"][c]
+            for c in range(9):
+                s.body_rot[k][c] = assets["bm_joint_rot"].reshape(9)[c]
+            for partner in [-(adapter + 1)] + list(range(0, 6)):
+                s.self_pair[s.n_self_pairs][0], s.self_pair[s.n_self_pairs][1] = k, partner
+                s.n_self_pairs += 1
+            body_names.append("ball_machine")
+            s.n_bodies += 1
+        s.ee_body = NLINK                                                                # both pieces share the link frame
+
+    def body_mask(names):
+        return sum(1 << k for k, n in enumerate(body_names) if n in names)
 
     closest_point_active = ["iiwa_link_%d" % i for i in range(2, 8)]                    # ctlp.py:579-581
+    if ball_machine:
+        closest_point_active.append("ball_machine")                                      # ctlp.py:585-586
     s.n_static = 0
     s.static_link_mask = 0
     if _cfg(config, "obstacle_scene") == 5:
         # table: Bullet box of half extents h has the implicit core h - margin plus the margin
         half = 0.5 * assets["table_box_size"] - margin
-        corners = np.array([[sx, sy, sz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=np.float64)
-        # corner i = sign bits (x, y, z) of i: the box edges join corners that differ in one bit
-        box_adj = (np.arange(0, 25, 3, dtype=np.int32), np.array([i ^ b for i in range(8) for b in (1, 2, 4)], dtype=np.int32))
         s.static_piece[0] = add_piece(assets["table_box_center"] + corners * half, box_adj)
         s.n_static = 1
-        observed = ["iiwa_link_%d" % i for i in range(1, 8)]                            # ctlp.py:2419-2434
-        s.static_link_mask = _link_mask([n for n in observed if n in closest_point_active])
+        observed = ["iiwa_link_%d" % i for i in range(1, 8)] + ["ball_machine"]         # ctlp.py:2419-2434
+        s.static_link_mask = body_mask([n for n in observed if n in closest_point_active])
         s.table_half_xy[0], s.table_half_xy[1] = 0.6, 0.8                               # ctlp.py:1901-1902
     s.plane_z = -0.94                                                                    # scene.py:172
 
@@ -474,14 +530,14 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     s.moving_max_distance = 0.001 if moving_reward == 0 else \
         float(_cfg(config, "collision_avoidance_moving_obstacles_max_reward_distance"))  # rewards.py:142-145
     s.contact_distance = float(contact_distance)
-    s.contact_link_mask = (1 << NLINK) - 1
+    s.contact_link_mask = (1 << s.n_bodies) - 1
     s.n_planets = 0
     s.obs_planet_size_per_planet = int(_cfg(config, "obs_planet_size_per_planet"))
     s.obs_num_planets = 0
     s.use_ball = 0
     obs_size = 3 * NJ                                                                    # obs.py:54,108
     if config.get("planet_mode"):
-        s.moving_link_mask = _link_mask(["iiwa_link_%d" % i for i in range(3, 8)])      # scene.py:288-290
+        s.moving_link_mask = body_mask(["iiwa_link_%d" % i for i in range(3, 8)] + ["ball_machine"])   # scene.py:288-292
         update_time_step = dt / s.updates_per_step                                       # ctlp.py:97
         one_center = config.get("planet_one_center")
         two_center = config.get("planet_two_center")
@@ -584,8 +640,9 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     # ---- finalise geometry buffers ----
     b.verts = np.ascontiguousarray(np.concatenate(vert_blocks), dtype=np.float64)
     arr = (Piece * len(pieces))()
-    for i, (begin, count, c, r, m) in enumerate(pieces):
+    for i, (begin, count, c, r, m, kind, cyl_r, cyl_h) in enumerate(pieces):
         arr[i].vert_begin, arr[i].vert_count, arr[i].radius, arr[i].margin = begin, count, r, m
+        arr[i].kind, arr[i].cyl_radius, arr[i].cyl_half_length = kind, cyl_r, cyl_h
         for k in range(3):
             arr[i].center[k] = c[k]
     b.pieces = arr

@@ -29,3 +29,10 @@ def space_scene(built):
 def ball_scene(built):
     from safemotionsrisk_amd.scene import build_scene, BALL_ENV_CONFIG
     return build_scene(BALL_ENV_CONFIG, auto_reset=False)
+
+
+@pytest.fixture(scope="session")
+def bm_scene(built):
+    """the space scene on robot_ball_machine.urdf (what the shipped backup_networks/space/params.json asks for)"""
+    from safemotionsrisk_amd.scene import build_scene, SPACE_ENV_CONFIG
+    return build_scene(dict(SPACE_ENV_CONFIG, ball_machine_mode=True), auto_reset=False)

@@ -80,7 +80,7 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
     for (int j = 0; j < 7; ++j) { cp(d.joint_xyz[j], s.joint_xyz[j], 3); cp(d.joint_axis[j], s.joint_axis[j], 3); }
     if (const char *msg = build_host_geometry(s, H->G)) { std::fprintf(stderr, "emul_scene_create: %s\n", msg); delete H; return nullptr; }
     d.verts = H->G.verts.data(); d.pieces = H->G.pieces.data(); d.span = H->G.span.data(); d.ids4 = H->G.ids4.data(); d.start = H->G.start.data();
-    for (int l = 0; l < 8; ++l) d.link_piece[l] = s.link_piece[l];
+    if (const char *msg = scene_bodies(s, d)) { std::fprintf(stderr, "emul_scene_create: %s\n", msg); delete H; return nullptr; }
     d.n_static = s.n_static; for (int i = 0; i < s.n_static; ++i) d.static_piece[i] = s.static_piece[i];
     d.static_mask = s.static_link_mask; d.static_max = (float)s.static_max_distance; d.moving_mask = s.moving_link_mask; d.contact_mask = s.contact_link_mask;
     d.moving_max = (float)s.moving_max_distance; d.contact_dist = (float)s.contact_distance; d.n_planets = s.n_planets;
@@ -101,7 +101,7 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
 extern "C" void emul_distances(void *h, const float *q, const int *idx, int want_dist, int want_contact, float *out) {
     HostScene *H = (HostScene *)h;
     Sample r = collide_sample(H->d, q, idx, want_dist != 0, want_contact != 0);
-    out[0] = r.d_static; out[1] = r.d_moving; out[2] = r.contact ? 1.f : 0.f;
+    out[0] = r.d_static; out[1] = r.d_moving; out[2] = r.contact ? 1.f : 0.f; out[3] = r.d_self;
 }
 
 // support of piece `pi` along d (piece frame): climbing result vs exhaustive scan; returns the two dot products

@@ -371,3 +371,75 @@ def test_ball_full_size_invariants(built):
             assert np.allclose(np.linalg.norm(st["ball"][:, 3:6], axis=1), 6.0, atol=1e-4)
     assert {2, 4, 5} <= reasons
     env.close()
+
+
+# ---- robot_ball_machine.urdf (ball_machine_mode=True: what the shipped backup / task network env_configs ask for) ----------
+
+def _bm_env(B, **kw):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
+    kw.setdefault("auto_reset", False)
+    return VecSafeMotionsEnv(B, device=0, **kw, **dict(SPACE_ENV_CONFIG, ball_machine_mode=True))
+
+
+@pytest.mark.gpu
+def test_ball_machine_components_against_oracle(built):
+    """table / self / planet distances and contact flags with the ball machine mounted (10 bodies, 14 self pairs)."""
+    from oracle.oracle import OracleEnv
+    env = _bm_env(64, seed=0)
+    s = env.scene.struct
+    assert s.n_bodies == 10 and s.n_self_pairs == 14
+    ora = OracleEnv(env.scene, 1)
+    rng = np.random.default_rng(17)
+    n = 512
+    q = rng.uniform(np.array(s.pos_lo), np.array(s.pos_hi), (n, 7)).astype(np.float32)
+    i0 = rng.integers(0, 1200, n)
+    idx = np.stack([i0, (i0 - 480) % 1200], axis=1).astype(np.int32)
+    d = env.test_distances(q, idx)
+    clamp = lambda x: np.where(x < 0.001, 0.0, x)
+    od = np.array([ora.distances(q[i].astype(np.float64), idx[i]) for i in range(n)])
+    near = (np.abs(od[:, :3] - 0.001) < TIE).any(axis=1)
+    for c in range(3):                                       # static, self, moving
+        assert np.abs(clamp(d[:, c]) - clamp(od[:, c]))[~near].max() < 5e-6
+    safe = np.abs(od[:, 2] - 0.02) > TIE
+    assert np.array_equal(d[safe, 3], od[safe, 3])
+    assert (od[:, 1] < 0.001).sum() > 5 and (od[:, 1] < 0.1).sum() > 50     # the self pairs are exercised
+    env.close()
+
+
+@pytest.mark.gpu
+def test_ball_machine_rollout_and_reset_against_oracle(built):
+    import torch
+    from oracle.oracle import OracleEnv
+    B, T = 4096, 12
+    env = _bm_env(B, seed=5)
+    env.reset()
+    ora = OracleEnv(env.scene, B, seed=5, num_threads=16)
+    ora.reset()
+    st, ost = env.get_state(), ora.get_state()
+    same = (ost["planet_idx"] == st["planet_idx"]).all(axis=1) & (np.abs(ost["q"] - st["q"]).max(axis=1) < 1e-3)
+    assert same.mean() > 0.97                                 # same Philox streams -> same start states (self pairs included)
+    rng = np.random.default_rng(9)
+    mism, reasons = 0, []
+    for t in range(T):
+        st = env.get_state()
+        ora.set_state(**{k: st[k] for k in STATE_KEYS})
+        act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        o_obs, o_rew, o_done, o_reason, o_info = ora.step(act.astype(np.float64))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        reason = info["termination_reason"].cpu().numpy()
+        bad = (done != o_done) | (reason != o_reason)
+        tie = (np.abs(o_info[:, :3] - 0.001) < TIE).any(axis=1) | (np.abs(o_info[:, 2] - 0.02) < TIE)
+        mism += int((bad & ~tie).sum())
+        good = ~bad
+        assert (np.abs(obs[good] - o_obs[good]) < OBS_TOL).all()
+        assert np.abs(rew[good] - o_rew[good]).max() < 5e-5
+        assert np.abs(info["values"].cpu().numpy()[good, 1] - o_info[good, 1]).max() < 5e-6      # self distance
+        reasons += o_reason[o_done.astype(bool)].tolist()
+        if done.any():
+            env.reset(mask=torch.from_numpy(done).cuda())
+    assert mism <= 2, "%d unexplained mismatches" % mism      # contact ties inside a step are not excluded here
+    assert reasons.count(3) > 20 and reasons.count(4) > 20 and reasons.count(5) > 20     # self / static / moving terminations
+    env.close()

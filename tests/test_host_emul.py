@@ -41,17 +41,43 @@ def test_device_distances_on_host(emul, space_scene):
         q = rng.uniform(np.array(s.pos_lo), np.array(s.pos_hi)).astype(np.float32)
         i0 = int(rng.integers(1200))
         idx = np.array([i0, (i0 - 480) % 1200], dtype=np.int32)
-        out = np.zeros(3, np.float32)
+        out = np.zeros(4, np.float32)
         emul.emul_distances(H, q.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), 1, 0, out.ctypes.data_as(C.c_void_p))
         d = ora.distances(q.astype(np.float64), idx)
         if min(abs(d[0] - 0.001), abs(d[2] - 0.001)) < 2e-5:
             continue
         worst = max(worst, abs(clamp(out[0]) - clamp(d[0])), abs(clamp(out[1]) - clamp(d[2])))
-        c = np.zeros(3, np.float32)
+        c = np.zeros(4, np.float32)
         emul.emul_distances(H, q.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), 0, 1, c.ctypes.data_as(C.c_void_p))
         if abs(d[2] - 0.02) > 2e-5:
             assert c[2] == d[3]
     assert worst < 2e-6
+
+
+def test_device_distances_with_ball_machine_on_host(emul, bm_scene):
+    """robot_ball_machine.urdf: the two convex pieces mounted on iiwa_link_7 take part in the table / planet queries and
+    pair with the base adapter's cylinder and iiwa_link_0..5 for the self-collision distance (A7 self)."""
+    s = bm_scene.struct
+    assert s.n_bodies == 10 and s.n_self_pairs == 14
+    ora = O.OracleEnv(bm_scene, 1)
+    H = C.c_void_p(emul.emul_scene_create(C.cast(bm_scene.pointer(), C.c_void_p)))
+    assert H.value
+    rng = np.random.default_rng(3)
+    clamp = lambda x: 0.0 if x < 0.001 else x
+    worst, self_hits, self_seen = 0.0, 0, 0
+    for _ in range(1200):
+        q = rng.uniform(np.array(s.pos_lo), np.array(s.pos_hi)).astype(np.float32)
+        i0 = int(rng.integers(1200))
+        idx = np.array([i0, (i0 - 480) % 1200], dtype=np.int32)
+        out = np.zeros(4, np.float32)
+        emul.emul_distances(H, q.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), 1, 0, out.ctypes.data_as(C.c_void_p))
+        d = ora.distances(q.astype(np.float64), idx)                      # static, self, moving, contact
+        if min(abs(d[0] - 0.001), abs(d[1] - 0.001), abs(d[2] - 0.001)) < 2e-5:
+            continue
+        worst = max(worst, abs(clamp(out[0]) - clamp(d[0])), abs(clamp(out[3]) - clamp(d[1])), abs(clamp(out[1]) - clamp(d[2])))
+        self_seen += d[1] < 0.1
+        self_hits += d[1] < 0.001
+    assert worst < 3e-6 and self_seen > 100 and self_hits > 10
 
 
 def test_hill_climbing_support_equals_scan(emul, space_scene, ball_scene):

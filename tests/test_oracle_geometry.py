@@ -166,3 +166,49 @@ def test_gjk_regression_flat_tetrahedron(built, space_scene):
     link = space_scene.verts[pc.vert_begin:pc.vert_begin + pc.vert_count] @ rot[7].T + pos[7]
     assert O.gjk(table, I3, Z3, link, I3, Z3) == pytest.approx(qp_distance(table, link), abs=2e-6)
     assert ora.distances(q, [0, 720])[0] == pytest.approx(0.003914, abs=2e-5)
+
+
+def test_ball_machine_frames_against_urdf_numbers(built, bm_scene):
+    """robot_ball_machine.urdf: link ball_machine = iiwa_link_7 * (xyz 0 0.175 0.1645, rpy pi/2 0 0); at q = 0 the chain is
+    upright, so the numbers can be written down (iiwa_link_7 origin: base + joint offsets)."""
+    ora = O.OracleEnv(bm_scene, 1)
+    s = bm_scene.struct
+    pos, rot = ora.body_frames(np.zeros(7))
+    top = np.array(s.base_xyz) + np.sum(np.array([list(s.joint_xyz[j]) for j in range(7)]), axis=0)
+    assert np.allclose(pos[7], top, atol=1e-12) and np.allclose(rot[7], np.eye(3), atol=1e-12)
+    for b in (8, 9):                                     # both convex pieces share the link frame
+        assert np.allclose(pos[b], top + np.array([0.0, 0.175, 0.1645]), atol=1e-12)
+        assert np.allclose(rot[b], np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]]), atol=1e-6)   # Rx(pi/2)
+    # turning joint 7 by 90 degrees about z swings the mounting offset from +y to -x
+    pos2, rot2 = ora.body_frames(np.array([0, 0, 0, 0, 0, 0, np.pi / 2]))
+    assert np.allclose(pos2[8], top + np.array([-0.175, 0.0, 0.1645]), atol=1e-9)
+    assert s.ee_body == 8 and list(s.ee_offset) == [0, 0, 0]                                  # scene.py:188-199
+
+
+def test_self_pairs_against_qp(built, bm_scene):
+    """Self-collision pairs (ball machine piece x iiwa_link_0..5 / base adapter) against the independent QP solver; the
+    adapter's cylinder (Bullet: implicit core r - margin, L/2 - margin) is given to the QP as a 90-gon prism."""
+    ora = O.OracleEnv(bm_scene, 1)
+    s = bm_scene.struct
+    verts = bm_scene.verts
+    pairs = [(s.self_pair[i][0], s.self_pair[i][1]) for i in range(s.n_self_pairs)]
+    assert sorted(set(p[1] for p in pairs if p[1] >= 0)) == [0, 1, 2, 3, 4, 5] and len(pairs) == 14   # ctlp.py:1438-1446
+    rng = np.random.default_rng(8)
+    for i in (0, 3, 12):
+        a, b = pairs[i]
+        q = rng.uniform(-2.0, 2.0, 7)
+        pos, rot = ora.body_frames(q)
+        pa = bm_scene.pieces[s.link_piece[a]]
+        A = verts[pa.vert_begin:pa.vert_begin + pa.vert_count] @ rot[a].T + pos[a]
+        if b >= 0:
+            pb = bm_scene.pieces[s.link_piece[b]]
+            Bv = verts[pb.vert_begin:pb.vert_begin + pb.vert_count] @ rot[b].T + pos[b]
+            tol = 2e-6
+        else:
+            pc = bm_scene.pieces[-(b + 1)]
+            assert pc.kind == 1 and pc.cyl_radius == pytest.approx(0.159) and pc.cyl_half_length == pytest.approx(0.009)
+            ang = np.linspace(0, 2 * np.pi, 90, endpoint=False)
+            ring = np.stack([pc.cyl_radius * np.cos(ang), pc.cyl_radius * np.sin(ang)], axis=1)
+            Bv = np.concatenate([np.c_[ring, np.full(90, z)] for z in (-pc.cyl_half_length, pc.cyl_half_length)]) + np.array(list(pc.center))
+            tol = 1.2e-4                                # the polygon is inside the disc by r (1 - cos(pi/90)) = 1e-4
+        assert ora.self_pair_distance(q, i) == pytest.approx(qp_distance(A, Bv) - 0.002, abs=tol)
