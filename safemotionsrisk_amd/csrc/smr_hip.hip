@@ -47,6 +47,8 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
+// SELF: the scene has self-collision pairs (ball machine); the plain robot runs the instantiation without that code
+template <bool SELF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     const int l = S.n_bodies - 1 - (int)blockIdx.z;    // body l; the outer bodies (most planet work) are dispatched first
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_
     const bool want_static = final_sample && ((S.static_mask >> l) & 1u);
     const bool want_moving = final_sample && moving_alive && ((S.moving_mask >> l) & 1u);
     bool want_self = false;                            // this body has self-collision pairs (ball machine pieces)
-    for (int i = 0; i < S.n_self_pairs; ++i) want_self |= final_sample && S.self_pair[i][0] == l;
+    if (SELF)
+        for (int i = 0; i < S.n_self_pairs; ++i) want_self |= final_sample && S.self_pair[i][0] == l;
     if (final_sample) {
         st.dist[(size_t)l * B + e] = S.static_max; st.dist[(size_t)(NB + l) * B + e] = S.moving_max + 0.002f;
         st.dist[(size_t)(2 * NB + l) * B + e] = S.static_max;
@@ -109,24 +112,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_
     const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
     Xf T = fk_base(S);
     float qs[SMR_NJ] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (SELF) {
 #pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j)                   // FK up to this body's link; joint values straight from the cubic
-        if (j < chain) {
-            qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
-            fk_advance(S, j, qs[j], T);
-        }
-    if (l >= SMR_NLINK) T = mounted_frame(S, l, T);
+        for (int j = 0; j < SMR_NJ; ++j)               // FK up to this body's link; joint values straight from the cubic
+            if (j < chain) {
+                qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
+                fk_advance(S, j, qs[j], T);
+            }
+        if (l >= SMR_NLINK) T = mounted_frame(S, l, T);
+    } else {
+        for (int j = 0; j < chain; ++j)
+            fk_advance(S, j, interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt), T);
+    }
     Sample r;
     if (S.use_ball) {
         Xf XB = ball_pose(S, ball, ball_k, nullptr);
         const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near, want_self ? qs : nullptr);
+        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near, (SELF && want_self) ? qs : nullptr);
     } else {
         int idx[SMR_MAX_PLANETS] = {0, 0};
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
-        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, want_self ? qs : nullptr);
+        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, (SELF && want_self) ? qs : nullptr);
     }
     res[e] = r.contact ? 1.f : 0.f;
     if (final_sample) {
@@ -308,6 +316,8 @@ struct Group {
 // Lane g of a group works the bodies g, g + 8, ... (8 chain links; the ball machine's pieces fold onto lanes 0, 1).
 
 // table and self-collision clearance of ONE body (ctlp.py:2140-2208, 1605-1619)
+// EXTRA: the scene has bodies beyond the chain and self-collision pairs (ball machine); false compiles that code out
+template <bool EXTRA>
 __device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ], const Xf &T, float thr, float thr_self) {
     const int pl = S.link_piece[b];
     const DPiece LP = load_piece_lane(S.pieces, pl);
@@ -318,11 +328,12 @@ __device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ],
             float d = piece_distance<true>(S, S.static_piece[s], T, LP, hull, T, thr + 0.005f, 0.f);
             if (d <= thr + 0.005f && d < thr) ok = false;
         }
-    for (int i = 0; i < S.n_self_pairs; ++i) {
-        if (S.self_pair[i][0] != b) continue;
-        float d = self_pair_distance(S, i, q, LP, hull, T, thr_self + 0.005f, 0.f);
-        if (d <= thr_self + 0.005f && d < thr_self) ok = false;
-    }
+    if (EXTRA)
+        for (int i = 0; i < S.n_self_pairs; ++i) {
+            if (S.self_pair[i][0] != b) continue;
+            float d = self_pair_distance(S, i, q, LP, hull, T, thr_self + 0.005f, 0.f);
+            if (d <= thr_self + 0.005f && d < thr_self) ok = false;
+        }
     return ok;
 }
 
@@ -330,12 +341,13 @@ __device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ],
 // range of the end-effector point and minimum table / self distances (start states ctlp.py:172-183,1468-1477; ball
 // targets ctlp.py:191-229,1725-1726,2357).  (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is
 // outside the kinematic path.)
+template <bool EXTRA>
 __device__ inline bool group_pose_valid(const DScene &S, const Group &G, const float q[SMR_NJ], const float box[3][2], float thr,
                                         float thr_self) {
     bool ok = true;
-    for (int b = G.g; b < S.n_bodies; b += 8) {
+    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) {
         const Xf T = body_frame(S, q, b);
-        ok = ok && body_clear(S, b, q, T, thr, thr_self);
+        ok = ok && body_clear<EXTRA>(S, b, q, T, thr, thr_self);
         if (b == S.ee_body) {
             F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});            // ctlp.py:2051-2061
             if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) ok = false;
@@ -344,16 +356,18 @@ __device__ inline bool group_pose_valid(const DScene &S, const Group &G, const f
     return G.all(ok);
 }
 
+template <bool EXTRA>
 __device__ inline bool group_table_free(const DScene &S, const Group &G, const float q[SMR_NJ]) {
     bool ok = true;
-    for (int b = G.g; b < S.n_bodies; b += 8) ok = ok && body_clear(S, b, q, body_frame(S, q, b), S.start_min_static, S.start_min_self);
+    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear<EXTRA>(S, b, q, body_frame(S, q, b), S.start_min_static, S.start_min_self);
     return G.all(ok);
 }
 
 // Bullet contact between any planet piece and any robot body (Planet.check_if_object_is_colliding, ctlp.py:4570-4579)
+template <bool EXTRA>
 __device__ inline bool group_planet_contact(const DScene &S, const Group &G, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS]) {
     bool contact = false;
-    for (int b = G.g; b < S.n_bodies; b += 8) {
+    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) {
         const int pl = S.link_piece[b];
         const DPiece LP = load_piece_lane(S.pieces, pl);
         const Sample r = collide_link(S, b, LP, global_hull(S, pl, LP), body_frame(S, q, b), idx, nullptr, false, false, true);
@@ -363,9 +377,10 @@ __device__ inline bool group_planet_contact(const DScene &S, const Group &G, con
 }
 
 // is the ball (pose XB) within Bullet's contact distance of any robot body? (Ball.check_if_object_is_colliding, ctlp.py:4186-4194)
+template <bool EXTRA>
 __device__ inline bool group_ball_contact(const DScene &S, const Group &G, const float q[SMR_NJ], const Xf &XB) {
     bool contact = false;
-    for (int b = G.g; b < S.n_bodies; b += 8)
+    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8)
         if ((S.contact_mask >> b) & 1u) {
             const int pl = S.link_piece[b];
             const DPiece LP = load_piece_lane(S.pieces, pl);
@@ -419,6 +434,7 @@ struct BallSpawn { float p0[3], v0[3], e0[3], omega; int kmax, khit; };
 
 // _add_moving_object, ctlp.py:1723-1931, by a group of 8 lanes: candidate target poses one after the other, each
 // tested link-parallel; the scalar launch arithmetic is computed redundantly by all lanes, in float64.
+template <bool EXTRA>
 __device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, const Group &G) {
     const int jj = G.g < SMR_NJ ? G.g : 0;
     const double udt = S.dt64 / S.updates_per_step, v = S.ball_speed, grav = 9.81;
@@ -434,7 +450,7 @@ __device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, co
             float q[SMR_NJ];
             G.gather(rng.uniform(S_BALL_POSE, 7u * pose_attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
             ++pose_attempt;
-            if (group_pose_valid(S, G, q, S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); break; }
+            if (group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); break; }
         }
         const double dx = target[0] - rel[0], dy = target[1] - rel[1], dh = target[2] - rel[2];
         const double dxy = sqrt(dx * dx + dy * dy);
@@ -527,6 +543,7 @@ __device__ inline void store_ball(const DState &st, int B, int e, const BallSpaw
 }
 
 // a new ball for the envs whose ball was retired in this step (get_moving_object_observation, ctlp.py:2354-2360)
+template <bool EXTRA>
 __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp, DState st, int group_stride, float *__restrict__ obs) {
     const DScene &S = *Sp;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const unsigned spawns = (unsigned)st.ball_i[4 * B + e];
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
-    const BallSpawn b = spawn_ball_group(S, rng, G);
+    const BallSpawn b = spawn_ball_group<EXTRA>(S, rng, G);
     if (g == 0) {
         store_ball(st, B, e, b, 0, spawns + 1u);
         BallState bs;
@@ -562,7 +579,7 @@ static int reset_group_stride() {      // every n-th 8-lane group works (tuning 
 // not lane count, bounds this kernel, so only every group_stride-th group takes an entry.
 // STAGED: the result goes to the staging arrays (next_*, staged_tag) and nothing of the live env is touched -
 // the kernel then runs on the side stream while the main stream steps the envs (scenes without a ball).
-template <bool STAGED>
+template <bool STAGED, bool EXTRA>
 __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                    const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                    float *__restrict__ obs) {
@@ -587,7 +604,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         for (int tries = 0; tries < 100000; ++tries) {
             G.gather(rng.uniform(S_POS, 7u * attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);               // ctlp.py:2035-2037
             ++attempt;
-            if (group_pose_valid(S, G, q, S.start_box, S.start_min_static, S.start_min_self)) return;
+            if (group_pose_valid<EXTRA>(S, G, q, S.start_box, S.start_min_static, S.start_min_self)) return;
         }
     };
     next_position();
@@ -633,7 +650,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
             const float nv = interp_vel(cv, ca, na, S.dt, S.dt), nq = interp_pos(cq, cv, ca, na, S.dt, S.dt);
             float nqv[SMR_NJ];
             G.gather(nq, nqv);
-            if (group_table_free(S, G, nqv)) {
+            if (group_table_free<EXTRA>(S, G, nqv)) {
                 if (nxt == 0) { hq0 = nq; hv0 = nv; ha0 = na; } else if (nxt == 1) { hq1 = nq; hv1 = nv; ha1 = na; } else { hq2 = nq; hv2 = nv; ha2 = na; }
                 ++cnt;
             } else {
@@ -665,14 +682,14 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
                 if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % no + no) % no;
                 else idx[p] = rng.randint(S_PLANET, n * (unsigned)n_indep + (unsigned)(k++), no);
             }
-            if (!group_planet_contact(S, G, q, idx)) break;
+            if (!group_planet_contact<EXTRA>(S, G, q, idx)) break;
         }
         // obstacle_wrapper.update(update_after_reset=True): one planet update + contact check,
         // base.py:980-985, ctlp.py:2626-2637
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (idx[p] + 1) % S.planet[p].n_orbit;
-        if (S.term_moving) hit = group_planet_contact(S, G, q, idx) ? 1 : 0;
+        if (S.term_moving) hit = group_planet_contact<EXTRA>(S, G, q, idx) ? 1 : 0;
     }
 
     // ---- ball: spawn + random initial time step, candidates in sequence (ctlp.py:1052-1111)
@@ -682,7 +699,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
     if (S.use_ball) {
         ball_spawns = (unsigned)st.ball_i[4 * B + e];
         const Rng brng = {S.seed_lo, S.seed_hi, (unsigned)e, ball_spawns};
-        bsp = spawn_ball_group(S, brng, G);
+        bsp = spawn_ball_group<EXTRA>(S, brng, G);
         if (S.ball_random_initial) {
             BallState bs;
             for (int c = 0; c < 3; ++c) { bs.p0[c] = bsp.p0[c]; bs.v0[c] = bsp.v0[c]; bs.e0[c] = bsp.e0[c]; }
@@ -692,7 +709,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
             if (max_ts < 0) max_ts = 0;
             for (unsigned n = 0; n < 100000u; ++n) {
                 ball_k0 = brng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
-                if (!group_ball_contact(S, G, q, ball_pose(S, bs, ball_k0, nullptr))) break;
+                if (!group_ball_contact<EXTRA>(S, G, q, ball_pose(S, bs, ball_k0, nullptr))) break;
             }
         }
     }
@@ -1125,12 +1142,19 @@ struct TmpBuf {
     }
 };
 
+static bool scene_extra(const smr_env *env) { return env->hscene.n_bodies > SMR_NLINK || env->hscene.n_self_pairs > 0; }
+
+template <bool STAGED>
+static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {
+    if (scene_extra(env)) hipLaunchKernelGGL((reset_kernel<STAGED, true>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+    else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+}
+
 static int launch_reset_list(smr_env *env, float *obs_dev) {
     // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
     LaunchTimer t(env, SMR_K_RESET);
     const int B = env->B;
-    hipLaunchKernelGGL(reset_kernel<false>, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
-                       env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
+    launch_reset<false>(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->stream, env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
     SMR_HIP(hipGetLastError());
     return SMR_OK;
 }
@@ -1149,8 +1173,7 @@ static int staged_launch_refill(smr_env *env) {        // side stream: prepare n
     {
         LaunchTimer t(env, SMR_K_RESET, env->side);
         const int B = env->B;
-        hipLaunchKernelGGL(reset_kernel<true>, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->side, env->dscene, env->st,
-                           env->st.refill_list, env->st.refill_count, 0, reset_group_stride(), (float *)nullptr);
+        launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(), (float *)nullptr);
     }
     SMR_HIP(hipGetLastError());
     SMR_HIP(hipEventRecord(env->ev_refill, env->side));
@@ -1161,8 +1184,7 @@ static int staged_prepare_all(smr_env *env) {
     int rc;
     if ((rc = staged_wait_refill(env))) return rc;
     LaunchTimer t(env, SMR_K_RESET);
-    hipLaunchKernelGGL(reset_kernel<true>, dim3(((size_t)env->B * 8 + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
-                       (const int *)nullptr, (const int *)nullptr, env->B, 1, (float *)nullptr);
+    launch_reset<true>(env, dim3(((size_t)env->B * 8 + 63) / 64), env->stream, (const int *)nullptr, (const int *)nullptr, env->B, 1, (float *)nullptr);
     SMR_HIP(hipGetLastError());
     return SMR_OK;
 }
@@ -1202,8 +1224,7 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     }
     if (!mask_dev) {
         LaunchTimer t(env, SMR_K_RESET);
-        hipLaunchKernelGGL(reset_kernel<false>, dim3(((size_t)B * 8 + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
-                           (const int *)nullptr, (const int *)nullptr, B, 1, obs_dev);
+        launch_reset<false>(env, dim3(((size_t)B * 8 + 63) / 64), env->stream, (const int *)nullptr, (const int *)nullptr, B, 1, obs_dev);
         SMR_HIP(hipGetLastError());
         return SMR_OK;
     }
@@ -1228,7 +1249,9 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipGetLastError());
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
-        hipLaunchKernelGGL(collide_kernel, dim3((B + 63) / 64, env->N, env->hscene.n_bodies), dim3(64), 0, env->stream, env->dscene, env->st);
+        const dim3 grid((B + 63) / 64, env->N, env->hscene.n_bodies);
+        if (env->hscene.n_self_pairs > 0) hipLaunchKernelGGL(collide_kernel<true>, grid, dim3(64), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL(collide_kernel<false>, grid, dim3(64), 0, env->stream, env->dscene, env->st);
     }
     SMR_HIP(hipGetLastError());
     const bool staged = env->staged && env->auto_reset;
@@ -1246,8 +1269,9 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (staged) return staged_launch_refill(env);
     if (env->hscene.use_ball) {
         LaunchTimer t(env, SMR_K_SPAWN);
-        hipLaunchKernelGGL(spawn_kernel, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st,
-                           reset_group_stride(), obs_dev);
+        const dim3 sgrid(((size_t)B * 8 * reset_group_stride() + 63) / 64);
+        if (scene_extra(env)) hipLaunchKernelGGL(spawn_kernel<true>, sgrid, dim3(64), 0, env->stream, env->dscene, env->st, reset_group_stride(), obs_dev);
+        else hipLaunchKernelGGL(spawn_kernel<false>, sgrid, dim3(64), 0, env->stream, env->dscene, env->st, reset_group_stride(), obs_dev);
         SMR_HIP(hipGetLastError());
     }
     if (env->auto_reset) return launch_reset_list(env, obs_dev);

@@ -2,7 +2,7 @@
 
 The reference itself cannot produce vectors (pybullet/klimits are not installable), so
 these fixtures pin the oracle against accidental change and give the GPU tests a data-only target that
-needs no oracle build on the box.  Run from the repo root:  python tests/golden/make_golden.py
+needs no oracle build on the box.  Run from the repo root:  python tests/golden/make_golden.py [--bm]
 """
 import os
 import sys
@@ -16,9 +16,10 @@ from oracle.oracle import OracleEnv                                   # noqa: E4
 from safemotionsrisk_amd.scene import SPACE_ENV_CONFIG, build_scene   # noqa: E402
 
 
-def main():
+def main(ball_machine=False):
+    """ball_machine: the same scene on robot_ball_machine.urdf (-> space_bm_step.npz; info column 1 = self distance)"""
     B, T = 512, 6
-    scene = build_scene(SPACE_ENV_CONFIG, auto_reset=False)
+    scene = build_scene(dict(SPACE_ENV_CONFIG, ball_machine_mode=ball_machine), auto_reset=False)
     env = OracleEnv(scene, B, seed=11, num_threads=4)
     env.reset()
     st0 = env.get_state()
@@ -58,10 +59,10 @@ def main():
     rr = [env.safe_acc_range(p[i].astype(np.float64), v[i].astype(np.float64), a[i].astype(np.float64)) for i in range(256)]
     out.update(comp_p=p, comp_v=v, comp_a=a, comp_lo=np.array([r[0] for r in rr]), comp_hi=np.array([r[1] for r in rr]),
                comp_code=np.array([r[2] for r in rr]))
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "space_step.npz")
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "space_bm_step.npz" if ball_machine else "space_step.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes; done fraction", np.mean(out["done"]), "reasons", np.unique(out["reason"]))
 
 
 if __name__ == "__main__":
-    main()
+    main(ball_machine="--bm" in sys.argv)

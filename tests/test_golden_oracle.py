@@ -8,10 +8,14 @@ from oracle.oracle import OracleEnv
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "space_step.npz")
 
 
-def test_oracle_reproduces_golden_step_vectors(built, space_scene):
-    g = np.load(GOLD)
+import pytest
+
+
+@pytest.mark.parametrize("name", ["space_step.npz", "space_bm_step.npz"])
+def test_oracle_reproduces_golden_step_vectors(built, space_scene, bm_scene, name):
+    g = np.load(os.path.join(os.path.dirname(GOLD), name))
     B, T = int(g["B"]), int(g["T"])
-    env = OracleEnv(space_scene, B, seed=int(g["seed"]), num_threads=4)
+    env = OracleEnv(bm_scene if "bm" in name else space_scene, B, seed=int(g["seed"]), num_threads=4)
     env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], planet_idx=g["planet_idx0"], step_count=g["step_count0"],
                   moving_hit=g["moving_hit0"])
     for t in range(T):
@@ -22,7 +26,7 @@ def test_oracle_reproduces_golden_step_vectors(built, space_scene):
         st = env.get_state()
         env.set_state(q=st["q"].astype(np.float32), v=st["v"].astype(np.float32), a=st["a"].astype(np.float32),
                       step_count=np.where(d, 0, st["step_count"]), moving_hit=np.where(d, 0, st["moving_hit"]))
-    assert g["done"].mean() > 0.02 and set(np.unique(g["reason"])) >= {-1, 2, 5}
+    assert g["done"].mean() > 0.02 and set(np.unique(g["reason"])) >= ({-1, 2, 3, 4, 5} if "bm" in name else {-1, 2, 5})
 
 
 def test_oracle_reproduces_golden_components(built, space_scene):

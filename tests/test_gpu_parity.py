@@ -35,7 +35,7 @@ def _threshold_ties(ora, st):
     tie = np.zeros(B, dtype=bool)
     for e in range(B):
         d = ora.distances(st["q"][e].astype(np.float64), st["planet_idx"][e])
-        tie[e] = abs(d[0] - 0.001) < TIE or abs(d[2] - 0.001) < TIE or abs(d[2] - 0.02) < TIE
+        tie[e] = abs(d[0] - 0.001) < TIE or abs(d[1] - 0.001) < TIE or abs(d[2] - 0.001) < TIE or abs(d[2] - 0.02) < TIE
     return tie
 
 
@@ -68,11 +68,12 @@ def test_components_against_golden(built):
     env.close()
 
 
-def test_step_against_golden(built):
+@pytest.mark.parametrize("name", ["space_step.npz", "space_bm_step.npz"])
+def test_step_against_golden(built, name):
     import torch
-    g = np.load(GOLD)
+    g = np.load(os.path.join(os.path.dirname(GOLD), name))
     B, T = int(g["B"]), int(g["T"])
-    env = _env(B, seed=int(g["seed"]))
+    env = (_bm_env if "bm" in name else _env)(B, seed=int(g["seed"]))
     env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], planet_idx=g["planet_idx0"], step_count=g["step_count0"],
                   moving_hit=g["moving_hit0"])
     from oracle.oracle import OracleEnv
