@@ -785,12 +785,13 @@ __device__ inline Xf body_frame(const DScene &S, const float q[SMR_NJ], int b) {
 // A7 self: distance of self-collision pair i = (body a with hull (LP, hull) under T, partner): the partner is another
 // chain link (its hull climbed from the global tables, per lane) or the base adapter's cylinder in the world frame
 // (btCylinderShapeZ::localGetSupportingVertexWithoutMargin).  Margins subtracted; > cutoff means "farther than cutoff".
-template <class HB>
+// LANE: the pair index differs between lanes (reset groups deal the pairs to their lanes), so nothing is wave uniform.
+template <bool LANE = false, class HB>
 __device__ inline float self_pair_distance(const DScene &S, int i, const float q[SMR_NJ], const DPiece &LP, const HB &hull,
                                            const Xf &T, float cutoff, float stop_below) {
     const int partner = S.self_pair[i][1];
     const int pa = partner >= 0 ? S.link_piece[partner] : -(partner + 1);
-    const DPiece A = load_piece(S.pieces, pa);
+    const DPiece A = LANE ? load_piece_lane(S.pieces, pa) : load_piece(S.pieces, pa);
     const float margins = A.margin + LP.margin;
     const F3 cb = apply(T, F3{LP.cx, LP.cy, LP.cz});
     const auto sb = [&](F3 d, int &hint, bool first) { return apply(T, hull.support(rot_t(T, d), hint, first)); };

@@ -318,7 +318,7 @@ struct Group {
 // table and self-collision clearance of ONE body (ctlp.py:2140-2208, 1605-1619)
 // EXTRA: the scene has bodies beyond the chain and self-collision pairs (ball machine); false compiles that code out
 template <bool EXTRA>
-__device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ], const Xf &T, float thr, float thr_self) {
+__device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ], const Xf &T, float thr) {
     const int pl = S.link_piece[b];
     const DPiece LP = load_piece_lane(S.pieces, pl);
     const GlobalHull hull = global_hull(S, pl, LP);
@@ -328,12 +328,18 @@ __device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ],
             float d = piece_distance<true>(S, S.static_piece[s], T, LP, hull, T, thr + 0.005f, 0.f);
             if (d <= thr + 0.005f && d < thr) ok = false;
         }
-    if (EXTRA)
-        for (int i = 0; i < S.n_self_pairs; ++i) {
-            if (S.self_pair[i][0] != b) continue;
-            float d = self_pair_distance(S, i, q, LP, hull, T, thr_self + 0.005f, 0.f);
-            if (d <= thr_self + 0.005f && d < thr_self) ok = false;
-        }
+    return ok;
+}
+
+// the self-collision pairs dealt round-robin to the lanes of a group: lane g tests pairs g, g + 8, ... (ctlp.py:2170-2208)
+__device__ inline bool lane_self_pairs_clear(const DScene &S, const Group &G, const float q[SMR_NJ], float thr_self) {
+    bool ok = true;
+    for (int i = G.g; i < S.n_self_pairs; i += 8) {
+        const int a = S.self_pair[i][0], pl = S.link_piece[a];
+        const DPiece LP = load_piece_lane(S.pieces, pl);
+        float d = self_pair_distance<true>(S, i, q, LP, global_hull(S, pl, LP), body_frame(S, q, a), thr_self + 0.005f, 0.f);
+        if (d <= thr_self + 0.005f && d < thr_self) ok = false;
+    }
     return ok;
 }
 
@@ -347,19 +353,21 @@ __device__ inline bool group_pose_valid(const DScene &S, const Group &G, const f
     bool ok = true;
     for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) {
         const Xf T = body_frame(S, q, b);
-        ok = ok && body_clear<EXTRA>(S, b, q, T, thr, thr_self);
+        ok = ok && body_clear<EXTRA>(S, b, q, T, thr);
         if (b == S.ee_body) {
             F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});            // ctlp.py:2051-2061
             if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) ok = false;
         }
     }
+    if (EXTRA) ok = ok && lane_self_pairs_clear(S, G, q, thr_self);
     return G.all(ok);
 }
 
 template <bool EXTRA>
 __device__ inline bool group_table_free(const DScene &S, const Group &G, const float q[SMR_NJ]) {
     bool ok = true;
-    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear<EXTRA>(S, b, q, body_frame(S, q, b), S.start_min_static, S.start_min_self);
+    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear<EXTRA>(S, b, q, body_frame(S, q, b), S.start_min_static);
+    if (EXTRA) ok = ok && lane_self_pairs_clear(S, G, q, S.start_min_self);
     return G.all(ok);
 }
 

@@ -106,7 +106,7 @@ class Scene(C.Structure):
 
 #: README "Training of the backup policy / Space environment" command as an env_config (README.md:74,
 #: train.py:168-309); identical to trained_networks/backup_networks/space/params.json except
-#: ball_machine_mode (False here: plain robot.urdf).
+#: ball_machine_mode (False here = the README command and BASELINE configs[2]; True, the shipped value, is supported too).
 SPACE_ENV_CONFIG = dict(
     experiment_name="backup_space", acc_limit_factor=1.0, action_max_punishment=0.4,
     action_punishment_min_threshold=0.95, closest_point_safety_distance=0.01,

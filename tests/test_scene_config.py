@@ -51,7 +51,7 @@ def test_obs_planet_size_variants():
 
 
 @pytest.mark.parametrize("key,value,exc", [
-    ("use_target_points", True, NotImplementedError), ("ball_machine_mode", True, NotImplementedError),
+    ("use_target_points", True, NotImplementedError),
     ("check_braking_trajectory_collisions", True, NotImplementedError), ("use_real_robot", True, NotImplementedError),
     ("human_network_checkpoint", "human_network/checkpoint/checkpoint", NotImplementedError),
     ("risk_config_dir", "risk_networks/state_action/space", NotImplementedError),
@@ -87,6 +87,28 @@ def test_readme_config_equals_shipped_params_json():
         assert ref[k] == v or (isinstance(v, list) and list(ref[k]) == list(v)), (k, ref[k], v)
     assert readme_only <= {"collision_avoidance_kinematic_state_sampling_probability"}
     assert ref["ball_machine_mode"] is True
+    # the shipped env_config is accepted UNCHANGED: robot_ball_machine.urdf = 10 collision bodies, 14 self-collision pairs,
+    # target link "ball_machine" with a zero offset (scene.py:188-199)
+    b = build_scene(ref)
+    assert b.struct.n_bodies == 10 and b.struct.n_self_pairs == 14 and b.struct.ee_body == 8 and list(b.struct.ee_offset) == [0, 0, 0]
+    assert b.obs_size == 23 and b.struct.static_link_mask == 0b1111111100 and b.struct.moving_link_mask == 0b1111111000
+
+
+def test_ball_machine_scene_fields():
+    """ball_machine_mode adds the two convex pieces of link "ball_machine" as bodies 8 and 9 (fixed on iiwa_link_7) and the
+    base adapter's cylinder as a world piece that only takes part in self-collision pairs (ctlp.py:1438-1446)."""
+    plain, bm = build_scene(SPACE_ENV_CONFIG), build_scene(dict(SPACE_ENV_CONFIG, ball_machine_mode=True))
+    assert plain.struct.n_bodies == 8 and plain.struct.n_self_pairs == 0 and plain.struct.ee_body == 7
+    s = bm.struct
+    assert s.n_bodies == 10 and [s.body_parent[b] for b in range(10)] == [0, 1, 2, 3, 4, 5, 6, 7, 7, 7]
+    assert list(s.body_xyz[8]) == [0.0, 0.175, 0.1645] and list(s.body_xyz[9]) == [0.0, 0.175, 0.1645]
+    pairs = [(s.self_pair[i][0], s.self_pair[i][1]) for i in range(s.n_self_pairs)]
+    adapter = -(pairs[0][1] + 1)
+    assert pairs == [(b, p) for b in (8, 9) for p in [-(adapter + 1), 0, 1, 2, 3, 4, 5]]
+    pc = bm.pieces[adapter]
+    assert pc.kind == 1 and abs(pc.cyl_radius - 0.159) < 1e-12 and abs(pc.cyl_half_length - 0.009) < 1e-12
+    assert list(pc.center) == [-0.2, 0.0, 0.01]
+    assert s.contact_link_mask == 0b1111111111 and bm.obs_size == plain.obs_size
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/safemotions/description/urdf/robot.urdf"),
