@@ -51,8 +51,17 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
 template <bool SELF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
-    const int l = S.n_bodies - 1 - (int)blockIdx.z;    // body l; the outer bodies (most planet work) are dispatched first
-    // the link's hull, edge graph and start map staged in LDS: every support call of this block climbs over them
+    // grid z: first the self-collision pairs (SELF; they only work at the end-of-step sample), then the bodies, outer ones
+    // (most planet work) first
+    const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
+    const bool pair_block = SELF && (int)blockIdx.z < n_pair_blocks;
+    const int pair = pair_block ? (int)blockIdx.z : 0;
+    if (pair_block && blockIdx.y != 0) return;
+    // the body whose hull this block climbs over: its own body, or for a pair block the partner link (the ball machine
+    // piece is then the scanned A side; with the base adapter as partner the piece itself is staged)
+    const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0])
+                             : S.n_bodies - 1 - ((int)blockIdx.z - n_pair_blocks);
+    // the hull, edge graph and start map staged in LDS: every support call of this block climbs over them
     __shared__ float lds_v[4 * kMaxPieceVerts];
     __shared__ uint32_t lds_span[kMaxPieceVerts];
     __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
@@ -76,10 +85,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
     const int B = S.B, N = S.checks_per_step;
+    const int NB = S.n_bodies;
+    if (SELF && pair_block) {
+        // A7 self, pair (a, partner) at the end of the step (ctlp.py:3345-3372): distance in dist[2 NB + pair]
+        float qs[SMR_NJ];
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], S.dt, S.dt);
+        const int a = S.self_pair[pair][0], partner = S.self_pair[pair][1];
+        const Xf Ta = body_frame(S, qs, a);
+        float d;
+        if (partner >= 0) d = piece_distance<false>(S, S.link_piece[a], Ta, LP, hull, body_frame(S, qs, partner), S.static_max, S.collision_dist);
+        else d = self_pair_distance(S, pair, qs, LP, hull, Ta, S.static_max, S.collision_dist);
+        st.dist[(size_t)(2 * NB + pair) * B + e] = d <= S.static_max ? d : S.static_max;
+        return;
+    }
     const int k = N - (int)blockIdx.y;                 // sample k of N, t_k = k dt / N; the end-of-step sample (distances) first
     const bool final_sample = (k == N);
     const int upd = S.updates_per_step / N;
-    const int NB = S.n_bodies;
     float *res = st.res + ((size_t)(k - 1) * NB + l) * B;
     const bool con_link = (S.contact_mask >> l) & 1u;
     bool want_contact, moving_alive = true;
@@ -99,48 +121,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_
     }
     const bool want_static = final_sample && ((S.static_mask >> l) & 1u);
     const bool want_moving = final_sample && moving_alive && ((S.moving_mask >> l) & 1u);
-    bool want_self = false;                            // this body has self-collision pairs (ball machine pieces)
-    if (SELF)
-        for (int i = 0; i < S.n_self_pairs; ++i) want_self |= final_sample && S.self_pair[i][0] == l;
-    if (final_sample) {
-        st.dist[(size_t)l * B + e] = S.static_max; st.dist[(size_t)(NB + l) * B + e] = S.moving_max + 0.002f;
-        st.dist[(size_t)(2 * NB + l) * B + e] = S.static_max;
-    }
+    if (final_sample) { st.dist[(size_t)l * B + e] = S.static_max; st.dist[(size_t)(NB + l) * B + e] = S.moving_max + 0.002f; }
     res[e] = 0.f;
-    if (!want_static && !want_moving && !want_contact && !want_self) return;
+    if (!want_static && !want_moving && !want_contact) return;
     const float t = final_sample ? S.dt : S.dt * (float)k / (float)N;
     const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
     Xf T = fk_base(S);
-    float qs[SMR_NJ] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (SELF) {
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j)               // FK up to this body's link; joint values straight from the cubic
-            if (j < chain) {
-                qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
-                fk_advance(S, j, qs[j], T);
-            }
-        if (l >= SMR_NLINK) T = mounted_frame(S, l, T);
-    } else {
-        for (int j = 0; j < chain; ++j)
-            fk_advance(S, j, interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt), T);
-    }
+    for (int j = 0; j < chain; ++j)                    // FK up to this body's link; joint values straight from the cubic
+        fk_advance(S, j, interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt), T);
+    if (SELF && l >= SMR_NLINK) T = mounted_frame(S, l, T);
     Sample r;
     if (S.use_ball) {
         Xf XB = ball_pose(S, ball, ball_k, nullptr);
         const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near, (SELF && want_self) ? qs : nullptr);
+        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near);
     } else {
         int idx[SMR_MAX_PLANETS] = {0, 0};
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
-        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, (SELF && want_self) ? qs : nullptr);
+        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact);
     }
     res[e] = r.contact ? 1.f : 0.f;
-    if (final_sample) {
-        st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving;
-        st.dist[(size_t)(2 * NB + l) * B + e] = r.d_self;
-    }
+    if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving; }
 }
 
 // env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     for (int l = 0; l < NB; ++l) {                                            // minimum over bodies, ctlp.py:3263-3278,3294-3372
         d_static = fminf(d_static, st.dist[(size_t)l * B + e]);
         d_moving = fminf(d_moving, st.dist[(size_t)(NB + l) * B + e]);
-        d_self = fminf(d_self, st.dist[(size_t)(2 * NB + l) * B + e]);
     }
+    for (int i = 0; i < S.n_self_pairs; ++i) d_self = fminf(d_self, st.dist[(size_t)(2 * NB + i) * B + e]);
 
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ], amax = 0.f, vrel = 0.f, arel = 0.f;
 #pragma unroll
@@ -1052,7 +1055,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)env->N * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)3 * scene->n_bodies * B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)env->N * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &st.spawn_list, B)) || (rc = dev_alloc(env, &st.spawn_count, 1)))
         return fail(rc);
@@ -1257,7 +1260,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipGetLastError());
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
-        const dim3 grid((B + 63) / 64, env->N, env->hscene.n_bodies);
+        const dim3 grid((B + 63) / 64, env->N, env->hscene.n_bodies + env->hscene.n_self_pairs);
         if (env->hscene.n_self_pairs > 0) hipLaunchKernelGGL(collide_kernel<true>, grid, dim3(64), 0, env->stream, env->dscene, env->st);
         else hipLaunchKernelGGL(collide_kernel<false>, grid, dim3(64), 0, env->stream, env->dscene, env->st);
     }
