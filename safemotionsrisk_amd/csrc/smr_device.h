@@ -41,10 +41,13 @@ struct DPiece {
     float in[3][3];             // three points INSIDE the hull (means of vertex subsets: all / upper / lower half along
                                 // the longest box axis): any pair of interior points bounds the hull distance from above
     int ids_begin, ids_count;   // the piece's neighbour-id groups in DScene::ids4 (hill-climbing support)
-    int kind;                   // SMR_PIECE_HULL / SMR_PIECE_CYLINDER_Z (axis z through (cx,cy,cz), core cyl_r x cyl_h)
+    int kind;                   // SMR_PIECE_HULL / SMR_PIECE_CYLINDER_Z (axis z through (cx,cy,cz), core cyl_r x cyl_h) /
+                                // kPieceAlignedBox (found by the table builder: a hull that is an axis-aligned box)
     float cyl_r, cyl_h;
+    float bx0, bx1, by0, by1, btop;   // kPieceAlignedBox: footprint [bx0,bx1] x [by0,by1] and the z of the top face (piece frame)
 };
-constexpr int kPieceDwords = 24;
+constexpr int kPieceDwords = 29;
+constexpr int kPieceAlignedBox = 100;
 constexpr int kStartBins = 4;                                // cube-map resolution of the climb start table
 constexpr int kStartCells = 6 * kStartBins * kStartBins;     // entries per piece
 
@@ -530,6 +533,8 @@ __device__ __forceinline__ DPiece piece_from_words(WP w) {
         for (int c = 0; c < 3; ++c) P.in[i][c] = __int_as_float(w[10 + 3 * i + c]);
     P.ids_begin = w[19]; P.ids_count = w[20];
     P.kind = w[21]; P.cyl_r = __int_as_float(w[22]); P.cyl_h = __int_as_float(w[23]);
+    P.bx0 = __int_as_float(w[24]); P.bx1 = __int_as_float(w[25]); P.by0 = __int_as_float(w[26]); P.by1 = __int_as_float(w[27]);
+    P.btop = __int_as_float(w[28]);
     return P;
 }
 // idx is wave uniform: scalar loads
@@ -746,6 +751,14 @@ __device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, co
         lb = sqrtf(dot(d, d)) - A.radius - B.radius - margins;
     }
     if (lb > cutoff) return lb;
+    if (IDENTITY && A.kind == kPieceAlignedBox) {
+        // The table: when the lowest point of the link hull lies above the box's top face, inside its footprint, the
+        // distance is that point's height above the face - any other hull point is at least as high, so at least as far
+        // from the box.  One support call instead of a GJK run; anything else (over the edge, below the top) falls through.
+        int hint = 0;
+        const F3 low = apply(XB, hb.support(rot_t(XB, F3{0.f, 0.f, -1.f}), hint, true));
+        if (low.x >= A.bx0 && low.x <= A.bx1 && low.y >= A.by0 && low.y <= A.by1 && low.z >= A.btop) return (low.z - A.btop) - margins;
+    }
     return gjk_distance<IDENTITY>((const SMR_CONST float *)S.verts, A, XA, hb, XB, d, cutoff + margins, stop_below + margins) - margins;
 }
 

@@ -59,6 +59,28 @@ inline const char *build_host_geometry(const smr_scene_t &s, HostGeometry &G) {
             hx = std::max(hx, std::fabs(dx)); hy = std::max(hy, std::fabs(dy)); hz = std::max(hz, std::fabs(dz));
         }
         q.radius = r * 1.00001f + 1e-7f; q.hx = hx + 1e-7f; q.hy = hy + 1e-7f; q.hz = hz + 1e-7f;
+        // an axis-aligned box given as its 8 corners (the table): every vertex is a corner of the vertices' bounding box
+        q.bx0 = q.bx1 = q.by0 = q.by1 = q.btop = 0.f;
+        if (p.kind == SMR_PIECE_HULL && p.vert_count == 8) {
+            float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+            for (int k = 0; k < 8; ++k) {
+                const float4 &vv = G.verts[(size_t)q.begin + k];
+                const float xyz[3] = {vv.x, vv.y, vv.z};
+                for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], xyz[c]); hi[c] = std::max(hi[c], xyz[c]); }
+            }
+            bool box = true; unsigned seen = 0;
+            for (int k = 0; k < 8; ++k) {
+                const float4 &vv = G.verts[(size_t)q.begin + k];
+                const float xyz[3] = {vv.x, vv.y, vv.z};
+                unsigned code = 0;
+                for (int c = 0; c < 3; ++c) { if (xyz[c] == hi[c]) code |= 1u << c; else if (xyz[c] != lo[c]) box = false; }
+                seen |= 1u << code;
+            }
+            if (box && seen == 0xFFu && hi[0] > lo[0] && hi[1] > lo[1] && hi[2] > lo[2]) {
+                q.kind = kPieceAlignedBox;
+                q.bx0 = lo[0]; q.bx1 = hi[0]; q.by0 = lo[1]; q.by1 = hi[1]; q.btop = hi[2];
+            }
+        }
         // three interior points: mean of all vertices, and of the halves above / below the box centre along the longest box axis
         {
             const int ax = (q.hx >= q.hy && q.hx >= q.hz) ? 0 : (q.hy >= q.hz ? 1 : 2);

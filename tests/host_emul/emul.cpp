@@ -118,6 +118,7 @@ extern "C" void emul_support_check(void *h, int pi, const float *dir, int warm_s
     out[0] = dot(a, d); out[1] = dot(b, d); out[2] = (float)hint;
 }
 extern "C" int emul_piece_count(void *h, int pi) { return ((HostScene *)h)->d.pieces[pi].count; }
+extern "C" int emul_piece_kind(void *h, int pi) { return ((HostScene *)h)->d.pieces[pi].kind; }
 
 // planets: the end-of-step query set of one (env, link) lane of the collide kernel
 extern "C" void emul_link_query(void *h, const float *q, const int *idx, int l, int want_static, int want_moving, int want_contact, float *out) {
