@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     if (d && S.auto_reset && staged) {
         commit_staged(S, st, e, obs + (size_t)e * S.obs_size);   // next episode's start state was prepared in the background
         st.refill_list[atomicAdd(st.refill_count, 1)] = e;       // hipcc folds this into one atomic per wave
+        if (S.use_ball) st.spawn_list[atomicAdd(st.spawn_count, 1)] = -(e + 1);   // its ball: spawn_kernel, as a reset
     } else if (d && S.auto_reset) {
         int slot = atomicAdd(st.done_count, 1);
         st.done_list[slot] = e;
@@ -554,26 +555,46 @@ __device__ inline void store_ball(const DState &st, int B, int e, const BallSpaw
 }
 
 // a new ball for the envs whose ball was retired in this step (get_moving_object_observation, ctlp.py:2354-2360)
+// list entry e >= 0: the ball of env e was retired in flight; -(e + 1): env e was reset (staged robot state committed) and
+// gets the ball of its new episode, advanced to a random contact-free time step (ctlp.py:1052-1111).  all_reset: every
+// entry is a reset (explicit env.reset()).
 template <bool EXTRA>
-__global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp, DState st, int group_stride, float *__restrict__ obs) {
+__global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
+                                                   const int *__restrict__ count_ptr, int count_fixed, int all_reset, int group_stride,
+                                                   float *__restrict__ obs) {
     const DScene &S = *Sp;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t >> 3, g = t & 7;
     if (grp % group_stride) return;
     const int i = grp / group_stride;
-    if (i >= *st.spawn_count) return;
-    const int e = st.spawn_list[i];
+    if (i >= (count_ptr ? *count_ptr : count_fixed)) return;
+    const int entry = list ? list[i] : i;
+    const bool is_reset = all_reset || entry < 0;
+    const int e = entry < 0 ? -(entry + 1) : entry;
     const int B = S.B;
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const unsigned spawns = (unsigned)st.ball_i[4 * B + e];
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
     const BallSpawn b = spawn_ball_group<EXTRA>(S, rng, G);
+    BallState bs;
+    for (int c = 0; c < 3; ++c) { bs.p0[c] = b.p0[c]; bs.v0[c] = b.v0[c]; bs.e0[c] = b.e0[c]; }
+    bs.omega = b.omega;
+    int k0 = 0;
+    if (is_reset && S.ball_random_initial) {
+        float q[SMR_NJ];
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) q[j] = st.q[j * B + e];
+        int kcap = b.kmax < b.khit ? b.kmax : b.khit;
+        int max_ts = kcap / S.updates_per_step;
+        if (max_ts < 0) max_ts = 0;
+        for (unsigned n = 0; n < 100000u; ++n) {
+            k0 = rng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
+            if (!group_ball_contact<EXTRA>(S, G, q, ball_pose(S, bs, k0, nullptr))) break;
+        }
+    }
     if (g == 0) {
-        store_ball(st, B, e, b, 0, spawns + 1u);
-        BallState bs;
-        for (int c = 0; c < 3; ++c) { bs.p0[c] = b.p0[c]; bs.v0[c] = b.v0[c]; bs.e0[c] = b.e0[c]; }
-        bs.omega = b.omega;
-        if (obs) write_ball_observation(S, bs, 0, obs + (size_t)e * S.obs_size + 3 * SMR_NJ);
+        store_ball(st, B, e, b, k0, spawns + 1u);
+        if (obs) write_ball_observation(S, bs, k0, obs + (size_t)e * S.obs_size + 3 * SMR_NJ);
     }
 }
 
@@ -703,6 +724,11 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         if (S.term_moving) hit = group_planet_contact<EXTRA>(S, G, q, idx) ? 1 : 0;
     }
 
+    if (STAGED) {      // robot part only; the ball of a reset depends on the env's spawn history: spawn_kernel draws it at commit time
+        if (g < SMR_NJ) { st.next_q[g * B + e] = qj; st.next_v[g * B + e] = vj; st.next_a[g * B + e] = aj; }
+        else { st.next_planet_idx[e] = idx[0]; st.next_planet_idx[B + e] = idx[1]; st.next_hit[e] = hit; st.staged_tag[e] = rng.tag; }
+        return;
+    }
     // ---- ball: spawn + random initial time step, candidates in sequence (ctlp.py:1052-1111)
     BallSpawn bsp;
     int ball_k0 = 0;
@@ -725,11 +751,6 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         }
     }
 
-    if (STAGED) {
-        if (g < SMR_NJ) { st.next_q[g * B + e] = qj; st.next_v[g * B + e] = vj; st.next_a[g * B + e] = aj; }
-        else { st.next_planet_idx[e] = idx[0]; st.next_planet_idx[B + e] = idx[1]; st.next_hit[e] = hit; st.staged_tag[e] = rng.tag; }
-        return;
-    }
     // ---- write back: lane j < 7 owns joint j, lane 7 the scalars
     float *row = obs ? obs + (size_t)e * S.obs_size : nullptr;
     if (g < SMR_NJ) {
@@ -1064,10 +1085,10 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
-    // staged start states: scenes without a ball (a ball's launch depends on how many balls the last episode spawned)
+    // staged start states (robot part; in ball scenes spawn_kernel draws the ball at commit time)
     {
         const char *off = std::getenv("SMR_SYNC_RESET");          // debugging / A-B measurement: reset on the critical path
-        env->staged = !scene->use_ball && !(off && off[0] == '1');
+        env->staged = !(off && off[0] == '1');
     }
     if (env->staged) {
         if ((rc = dev_alloc(env, &st.next_q, 7 * B)) || (rc = dev_alloc(env, &st.next_v, 7 * B)) || (rc = dev_alloc(env, &st.next_a, 7 * B)) ||
@@ -1161,6 +1182,11 @@ static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int 
     else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
 }
 
+static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int all_reset, int stride, float *obs) {
+    if (scene_extra(env)) hipLaunchKernelGGL(spawn_kernel<true>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
+    else hipLaunchKernelGGL(spawn_kernel<false>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
+}
+
 static int launch_reset_list(smr_env *env, float *obs_dev) {
     // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
     LaunchTimer t(env, SMR_K_RESET);
@@ -1222,6 +1248,10 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
             SMR_HIP(hipGetLastError());
             hipLaunchKernelGGL(iota_list_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, B, env->st.refill_list, env->st.refill_count);
             SMR_HIP(hipGetLastError());
+            if (env->hscene.use_ball) {                 // the balls of the new episodes (after the robot states are committed)
+                launch_spawn(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, 1, obs_dev);
+                SMR_HIP(hipGetLastError());
+            }
             return staged_launch_refill(env);
         }
         if ((rc = staged_wait_refill(env))) return rc;
@@ -1231,6 +1261,10 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
         hipLaunchKernelGGL(commit_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, (const int *)env->st.refill_list,
                            (const int *)env->st.refill_count, 0, obs_dev);
         SMR_HIP(hipGetLastError());
+        if (env->hscene.use_ball) {
+            launch_spawn(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, 1, reset_group_stride(), obs_dev);
+            SMR_HIP(hipGetLastError());
+        }
         return staged_launch_refill(env);
     }
     if (!mask_dev) {
@@ -1277,14 +1311,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
                            reward_dev, done_dev, reason_dev, info_dev, staged ? 1 : 0);
     }
     SMR_HIP(hipGetLastError());
-    if (staged) return staged_launch_refill(env);
     if (env->hscene.use_ball) {
         LaunchTimer t(env, SMR_K_SPAWN);
-        const dim3 sgrid(((size_t)B * 8 * reset_group_stride() + 63) / 64);
-        if (scene_extra(env)) hipLaunchKernelGGL(spawn_kernel<true>, sgrid, dim3(64), 0, env->stream, env->dscene, env->st, reset_group_stride(), obs_dev);
-        else hipLaunchKernelGGL(spawn_kernel<false>, sgrid, dim3(64), 0, env->stream, env->dscene, env->st, reset_group_stride(), obs_dev);
+        launch_spawn(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.spawn_list, env->st.spawn_count, 0, 0, reset_group_stride(), obs_dev);
         SMR_HIP(hipGetLastError());
     }
+    if (staged) return staged_launch_refill(env);
     if (env->auto_reset) return launch_reset_list(env, obs_dev);
     return SMR_OK;
 }
