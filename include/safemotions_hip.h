@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 2
+#define SMR_ABI_VERSION 3
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
@@ -76,6 +76,10 @@ typedef struct smr_host_state {
                               ctlp.py:4027-4059) */
     int32_t *ball_i;       /* [B][5] _position_update_step_counter, _max_time_update_step_counter, obstacle_hit_time,
                               active flag, balls spawned so far (ctlp.py:4076,4101,1903-1915) */
+    float *target;         /* [B][5] target point: position, distance at the last observation, distance when sampled
+                              (_target_point_pos_list, _last_target_point_distance_list, _initial_target_point_distance_list,
+                              ctlp.py:236-245) */
+    uint32_t *target_count;/* [B]    target points sampled so far = Philox tag of the next one */
 } smr_host_state_t;
 
 int smr_abi_version(void);

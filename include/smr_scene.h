@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SMR_SCENE_VERSION 5
+#define SMR_SCENE_VERSION 6
 #define SMR_NJ 7          /* manipulator joints (iiwa_joint_1..7, robot.urdf)            */
 #define SMR_NLINK 8       /* chain links iiwa_link_0..7; link k moves with joints 1..k      */
 #define SMR_MAX_BODIES 10 /* collision bodies = the 8 chain links + convex pieces rigidly mounted on one of them
@@ -153,7 +153,20 @@ typedef struct smr_scene {
     double plane_z;                     /* scene.py:172 */
     double table_half_xy[2];            /* ctlp.py:1901-1902 */
 
+    /* ---- target-point reaching task (A14), ctlp.py:1658-1721,2210-2350,2787-2821, rewards.py:217-396, obs.py:313-335 ----
+     * target points are sampled in ball_target_box (= _target_point_cartesian_range) */
+    int32_t use_target_points;
+    int32_t obs_target_pos, obs_target_rel;      /* obs_add_target_point_pos / _relative_pos */
+    int32_t target_normalize;                    /* normalize_reward_to_initial_target_point_distance */
+    double target_min_dist_static;               /* safety + 0.09, ctlp.py:1661-1664 */
+    double target_min_dist_self;                 /* safety, ctlp.py:1665-1666,2220 */
+    double target_radius, target_bonus, target_factor;
+    double target_rel_min[3], target_rel_max[3]; /* _target_point_relative_pos_min_max, ctlp.py:184 */
+
     /* ---- reward (A12/A13), rewards.py ---- */
+    int32_t collision_avoidance_mode;   /* 1: CollisionAvoidanceReward + collision-avoidance start states (rewards.py:399-502,
+                                           ctlp.py:1490-1654); 0: TargetPointReachingReward, start at rest (rewards.py:217-396) */
+    int32_t _pad3;
     int32_t punish_action;
     int32_t terminate_on_self_collision;
     int32_t terminate_on_static_collision;

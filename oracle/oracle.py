@@ -112,19 +112,22 @@ class OracleEnv:
         st = dict(q=np.zeros((B, NJ)), v=np.zeros((B, NJ)), a=np.zeros((B, NJ)),
                   planet_idx=np.zeros((B, 2), dtype=np.int32), step_count=np.zeros(B, dtype=np.int32),
                   moving_hit=np.zeros(B, dtype=np.int32), reset_count=np.zeros(B, dtype=np.uint32),
-                  ball=np.zeros((B, 10)), ball_i=np.zeros((B, 5), dtype=np.int32))
+                  ball=np.zeros((B, 10)), ball_i=np.zeros((B, 5), dtype=np.int32),
+                  target=np.zeros((B, 5)), target_count=np.zeros(B, dtype=np.uint32))
         self.L.smo_get_state(self.h, _p(st["q"]), _p(st["v"]), _p(st["a"]), _p(st["planet_idx"]),
-                             _p(st["step_count"]), _p(st["moving_hit"]), _p(st["reset_count"]), _p(st["ball"]), _p(st["ball_i"]))
+                             _p(st["step_count"]), _p(st["moving_hit"]), _p(st["reset_count"]), _p(st["ball"]), _p(st["ball_i"]),
+                             _p(st["target"]), _p(st["target_count"]))
         return st
 
     def set_state(self, q=None, v=None, a=None, planet_idx=None, step_count=None, moving_hit=None, reset_count=None,
-                  ball=None, ball_i=None):
+                  ball=None, ball_i=None, target=None, target_count=None):
         def f(x, dt, shape):
             return None if x is None else np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=dt), shape))
         B = self.B
         arrs = [f(q, np.float64, (B, NJ)), f(v, np.float64, (B, NJ)), f(a, np.float64, (B, NJ)),
                 f(planet_idx, np.int32, (B, 2)), f(step_count, np.int32, (B,)), f(moving_hit, np.int32, (B,)),
-                f(reset_count, np.uint32, (B,)), f(ball, np.float64, (B, 10)), f(ball_i, np.int32, (B, 5))]
+                f(reset_count, np.uint32, (B,)), f(ball, np.float64, (B, 10)), f(ball_i, np.int32, (B, 5)),
+                f(target, np.float64, (B, 5)), f(target_count, np.uint32, (B,))]
         self.L.smo_set_state(self.h, *[_p(x) for x in arrs])
 
     # ---- component entry points ----

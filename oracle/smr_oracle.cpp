@@ -87,7 +87,7 @@ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
  * streams: 0 start-position attempts, 1..7 joint velocity/acceleration tries, 8 random walk, 9 planet phase,
  * 10 sampling-mode choice; ball streams (tag = the env's ball spawn counter): 11 release point + launch-angle choice,
  * 12 target robot poses, 13 spin rate and initial time step. */
-enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10, S_BALL_RELEASE = 11, S_BALL_POSE = 12, S_BALL_MISC = 13 };
+enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10, S_BALL_RELEASE = 11, S_BALL_POSE = 12, S_BALL_MISC = 13, S_TARGET = 14 };
 
 struct Rng {
     uint64_t seed;
@@ -422,6 +422,9 @@ struct EnvState {
     double ball_p0[3], ball_v0[3], ball_e0[3], ball_omega;
     int32_t ball_k, ball_kmax, ball_khit, ball_active;
     uint32_t ball_spawns;      /* balls spawned so far = Philox tag of the next ball */
+    /* target point (A14): position, distance at the last observation, distance when it was sampled (ctlp.py:2210-2350) */
+    double tp_pos[3], tp_last, tp_init;
+    uint32_t tp_count;         /* target points sampled so far = Philox tag of the next one */
 };
 
 struct Oracle {
@@ -545,12 +548,25 @@ JointLim joint_lim(const smr_scene_t &S, int j) {
 }
 
 /* A15: _get_observation, obs.py:313-351 (+ :17-32, :233-242, :262-292). */
+V3 ee_point(const Oracle &O, const double q[SMR_NJ]);
+
 void observation(const Oracle &O, const EnvState &e, float *obs) {
     const smr_scene_t &S = O.S;
     int o = 0;
     for (int j = 0; j < SMR_NJ; ++j) obs[o++] = (float)(-1 + 2 * (e.q[j] - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j]));
     for (int j = 0; j < SMR_NJ; ++j) obs[o++] = (float)(e.v[j] / S.vel_max[j]);
     for (int j = 0; j < SMR_NJ; ++j) obs[o++] = (float)(e.a[j] / S.acc_max[j]);
+    if (S.use_target_points) {                               /* obs.py:313-335, ctlp.py:2240-2285 */
+        if (S.obs_target_pos)
+            for (int c = 0; c < 3; ++c)
+                obs[o++] = (float)(-1 + 2 * (e.tp_pos[c] - S.ball_target_box[c][0]) / (S.ball_target_box[c][1] - S.ball_target_box[c][0]));
+        if (S.obs_target_rel) {
+            V3 ee = ee_point(O, e.q);
+            double rel[3] = {e.tp_pos[0] - ee.x, e.tp_pos[1] - ee.y, e.tp_pos[2] - ee.z};
+            for (int c = 0; c < 3; ++c)
+                obs[o++] = (float)(-1 + 2 * (rel[c] - S.target_rel_min[c]) / (S.target_rel_max[c] - S.target_rel_min[c]));
+        }
+    }
     for (int p = 0; p < S.obs_num_planets; ++p) {
         int idx = e.planet_idx[p];
         if (S.obs_planet_size_per_planet == 1) {
@@ -625,6 +641,32 @@ bool table_free(const Oracle &O, const double q[SMR_NJ]) {                    /*
             if (d <= thr + 0.005 && d < thr) return false;
         }
     return self_pairs_clear(O, link, S.start_min_dist_self);                                /* ctlp.py:1610-1615 */
+}
+
+/* target link point (scene.py:185-208) of joint vector q */
+V3 ee_point(const Oracle &O, const double q[SMR_NJ]) {
+    Xf link[SMR_MAX_BODIES];
+    forward_kinematics(O.S, q, link);
+    return apply(link[O.S.ee_body], {O.S.ee_offset[0], O.S.ee_offset[1], O.S.ee_offset[2]});
+}
+
+/* A14: _add_target_point, ctlp.py:1658-1721: the target link point of a random valid configuration inside the target box;
+ * attempt m uses draws 7m..7m+6 of stream S_TARGET, tag = target points sampled so far.  Distances of the new point
+ * as the next observation sets them (ctlp.py:2229-2243). */
+void sample_target(const Oracle &O, EnvState &st, int e) {
+    const smr_scene_t &S = O.S;
+    Rng rng = {O.seed, (uint32_t)e, st.tp_count};
+    st.tp_count += 1;
+    V3 target = {0, 0, 0};
+    for (uint32_t m = 0; m < 100000; ++m) {
+        double q[SMR_NJ];
+        for (int j = 0; j < SMR_NJ; ++j) q[j] = rng.uniform(S_TARGET, 7 * m + j, S.pos_lo[j], S.pos_hi[j]);
+        if (pose_is_valid(O, q, S.ball_target_box, S.target_min_dist_static, S.target_min_dist_self, &target)) break;
+    }
+    st.tp_pos[0] = target.x; st.tp_pos[1] = target.y; st.tp_pos[2] = target.z;
+    V3 ee = ee_point(O, st.q);
+    V3 d = target - ee;
+    st.tp_last = st.tp_init = std::sqrt(dot(d, d));
 }
 
 /* ------------------------------------------------------------------------------------------- *
@@ -812,8 +854,10 @@ void reset_env(Oracle &O, int e) {
     double q[SMR_NJ], v[SMR_NJ] = {0}, a[SMR_NJ] = {0};
     uint32_t attempt = 0;
     sample_position(O, rng, attempt, q);
-    /* A17 part 2: get_starting_point_joint_pos_vel_acc, ctlp.py:1490-1654 */
-    if (S.kinematic_state_sampling_mode && rng.uniform01(S_MODE, 0) < S.kinematic_state_sampling_probability) {
+    /* A17 part 2: get_starting_point_joint_pos_vel_acc, ctlp.py:1490-1654 (outside collision_avoidance_mode the episode
+     * starts at rest, ctlp.py:1490-1491) */
+    if (!S.collision_avoidance_mode) {
+    } else if (S.kinematic_state_sampling_mode && rng.uniform01(S_MODE, 0) < S.kinematic_state_sampling_probability) {
         for (uint32_t round = 0;; ++round) {                                                  /* ctlp.py:1499-1556 */
             bool all_found = true;
             for (int j = 0; j < SMR_NJ; ++j) {
@@ -870,6 +914,7 @@ void reset_env(Oracle &O, int e) {
     st.step_count = 0;
     st.moving_hit = 0;
     st.planet_idx[0] = st.planet_idx[1] = 0;
+    if (S.use_target_points) sample_target(O, st, e);                                       /* ctlp.py:1022-1049 */
     if (S.use_ball) {                                                                       /* ctlp.py:1052-1111 */
         spawn_ball(O, e);
         if (S.ball_random_initial_position) {
@@ -957,6 +1002,18 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         }
     }
 
+    /* A14: the target point is reached when the target link point comes within its radius at one of the updates of the
+     * step (ctlp.py:2787-2821; the obstacle client follows the setpoints of the cubic) */
+    bool tp_reached = false;
+    if (S.use_target_points)
+        for (int u = 1; u <= S.updates_per_step && !tp_reached; ++u) {
+            double t = S.dt * u / S.updates_per_step, qu[SMR_NJ];
+            for (int j = 0; j < SMR_NJ; ++j) qu[j] = interp_pos(st.q[j], st.v[j], st.a[j], a1[j], t, S.dt);
+            V3 ee = ee_point(O, qu);
+            V3 d = V3{st.tp_pos[0], st.tp_pos[1], st.tp_pos[2]} - ee;
+            if (std::sqrt(dot(d, d)) < S.target_radius) tp_reached = true;
+        }
+
     /* process_step_outcome: new start state = last setpoint, base.py:1179-1181 */
     for (int j = 0; j < SMR_NJ; ++j) {
         double p1 = interp_pos(st.q[j], st.v[j], st.a[j], a1[j], S.dt, S.dt);
@@ -1015,15 +1072,33 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         double r = std::min(1.0, m / S.low_vel_threshold);
         low_vel_reward = (r - 1) * (r - 1);
     }
+    /* A14: get_target_point_reward, ctlp.py:2309-2350 */
+    double target_reward = 0;
+    if (S.use_target_points) {
+        double norm = 1.0;
+        if (S.target_normalize) { norm = st.tp_init; if (norm == 0) norm += 0.0000001; }
+        if (tp_reached) target_reward = st.tp_last / (S.dt * norm) + S.target_bonus;
+        else {
+            V3 ee = apply(link[S.ee_body], {S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
+            V3 d = V3{st.tp_pos[0], st.tp_pos[1], st.tp_pos[2]} - ee;
+            double cur = std::sqrt(dot(d, d));
+            target_reward = (st.tp_last - cur) / (S.dt * norm);
+            st.tp_last = cur;                                                /* the next observation, ctlp.py:2241-2243 */
+        }
+    }
     bool terminating_collision = (S.terminate_on_self_collision && col_self) ||
                                  (S.terminate_on_static_collision && col_static) ||
                                  (S.terminate_on_moving_collision && col_moving);
     bool finished = st.step_count >= S.episode_steps;                        /* tm.py:187-192 */
     double bonus = (finished && !terminating_collision) ? S.termination_bonus : 0.0;
     double punishment = terminating_collision ? S.early_termination_punishment : 0.0;
-    *reward = (1 - action_punishment) * S.action_max_punishment + r_self * S.self_max_reward +
-              r_static * S.static_max_reward + r_moving * S.moving_max_reward +
-              low_acc_reward * S.low_acc_max_reward + low_vel_reward * S.low_vel_max_reward + bonus + punishment;
+    if (S.collision_avoidance_mode)                                          /* CollisionAvoidanceReward, rewards.py:432-502 */
+        *reward = (1 - action_punishment) * S.action_max_punishment + r_self * S.self_max_reward +
+                  r_static * S.static_max_reward + r_moving * S.moving_max_reward +
+                  low_acc_reward * S.low_acc_max_reward + low_vel_reward * S.low_vel_max_reward + bonus + punishment;
+    else                                                                     /* TargetPointReachingReward, rewards.py:303-396 */
+        *reward = target_reward * S.target_factor - (S.punish_action ? action_punishment : 0.0) * S.action_max_punishment +
+                  r_self * S.self_max_reward + r_static * S.static_max_reward + r_moving * S.moving_max_reward;
 
     /* A16: _check_termination, base.py:1775-1799 */
     int r = SMR_TERMINATION_UNSET;
@@ -1040,7 +1115,10 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         info[INFO_R_STATIC] = r_static; info[INFO_R_MOVING] = r_moving; info[INFO_EPISODE_LENGTH] = st.step_count;
     }
     if (d && S.auto_reset) reset_env(O, e);
-    else if (S.use_ball && !st.ball_active) spawn_ball(O, e);   /* get_moving_object_observation, ctlp.py:2354-2360 */
+    else {
+        if (S.use_ball && !st.ball_active) spawn_ball(O, e);    /* get_moving_object_observation, ctlp.py:2354-2360 */
+        if (S.use_target_points && tp_reached) sample_target(O, st, e);      /* get_target_point_observation, ctlp.py:2217-2232 */
+    }
     observation(O, st, obs);
 }
 
@@ -1103,7 +1181,8 @@ void smo_step(void *h, const double *actions, float *obs, double *reward, uint8_
 }
 
 void smo_get_state(void *h, double *q, double *v, double *a, int32_t *planet_idx, int32_t *step_count,
-                   int32_t *moving_hit, uint32_t *reset_count, double *ball /*[B][10]*/, int32_t *ball_i /*[B][5]*/) {
+                   int32_t *moving_hit, uint32_t *reset_count, double *ball /*[B][10]*/, int32_t *ball_i /*[B][5]*/,
+                   double *target /*[B][5]*/, uint32_t *target_count) {
     Oracle &O = *(Oracle *)h;
     for (int e = 0; e < O.B; ++e) {
         const EnvState &s = O.st[e];
@@ -1125,12 +1204,14 @@ void smo_get_state(void *h, double *q, double *v, double *a, int32_t *planet_idx
             int32_t *b = ball_i + 5 * (size_t)e;
             b[0] = s.ball_k; b[1] = s.ball_kmax; b[2] = s.ball_khit; b[3] = s.ball_active; b[4] = (int32_t)s.ball_spawns;
         }
+        if (target) { double *t = target + 5 * (size_t)e; t[0] = s.tp_pos[0]; t[1] = s.tp_pos[1]; t[2] = s.tp_pos[2]; t[3] = s.tp_last; t[4] = s.tp_init; }
+        if (target_count) target_count[e] = s.tp_count;
     }
 }
 
 void smo_set_state(void *h, const double *q, const double *v, const double *a, const int32_t *planet_idx,
                    const int32_t *step_count, const int32_t *moving_hit, const uint32_t *reset_count, const double *ball,
-                   const int32_t *ball_i) {
+                   const int32_t *ball_i, const double *target, const uint32_t *target_count) {
     Oracle &O = *(Oracle *)h;
     for (int e = 0; e < O.B; ++e) {
         EnvState &s = O.st[e];
@@ -1152,6 +1233,8 @@ void smo_set_state(void *h, const double *q, const double *v, const double *a, c
             const int32_t *b = ball_i + 5 * (size_t)e;
             s.ball_k = b[0]; s.ball_kmax = b[1]; s.ball_khit = b[2]; s.ball_active = b[3]; s.ball_spawns = (uint32_t)b[4];
         }
+        if (target) { const double *t = target + 5 * (size_t)e; s.tp_pos[0] = t[0]; s.tp_pos[1] = t[1]; s.tp_pos[2] = t[2]; s.tp_last = t[3]; s.tp_init = t[4]; }
+        if (target_count) s.tp_count = target_count[e];
     }
 }
 

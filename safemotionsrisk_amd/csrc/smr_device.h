@@ -91,6 +91,10 @@ struct DScene {
     double ball_speed, ball_center[3], ball_sphere_radius, ball_height[2], ball_angle[2], ball_high_prob;   // spawn math runs in float64
     double ball_invalid_min[3], ball_invalid_max[3], ball_final_min[3], ball_final_max[3], plane_z, table_half_xy[2];
     double dt64;
+    // target-point reaching task (A14)
+    int use_target, obs_target_pos, obs_target_rel, obs_target_size, target_normalize, ca_mode;
+    float target_min_static, target_min_self, target_radius, target_bonus, target_factor;
+    float target_rel_min[3], target_rel_max[3];
     int punish_action, term_self, term_static, term_moving;
     float action_thr, action_max_pun;
     float self_max_reward, self_max_dist, static_max_reward, static_max_dist, moving_max_reward, moving_max_dist;
@@ -119,6 +123,10 @@ struct DState {
     int *ball_i;               // [5][B]  update counter k, k_max (passed the robot), k_hit (table/ground), active, spawn counter
     int *spawn_list;           // [B]  envs whose ball was retired in this step
     int *spawn_count;          // [1]
+    float *tp;                 // [5][B] target point: position, distance at the last observation, distance when sampled
+    unsigned *tp_count;        // [B] target points sampled so far = Philox tag of the next one
+    int *tp_list;              // [B] envs that need a new target point (reached, or reset)
+    int *tp_list_count;        // [1]
     // staged start states (scenes without a ball): the start state of every env's NEXT episode, prepared off the
     // critical path on a second stream and committed by the finish kernel when the env is done
     float *next_q, *next_v, *next_a;   // [7][B]
@@ -160,7 +168,7 @@ __device__ __forceinline__ F3 apply(const Xf &X, F3 v) { return rot(X, v) + X.t;
 // "the first valid one" exactly like a sequential loop.  24-bit uniforms are exact in float32.
 // (Reference: numpy's global RNG, base.py:1704-1710.)
 // ---------------------------------------------------------------------------------------------
-enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10, S_BALL_RELEASE = 11, S_BALL_POSE = 12, S_BALL_MISC = 13 };
+enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10, S_BALL_RELEASE = 11, S_BALL_POSE = 12, S_BALL_MISC = 13, S_TARGET = 14 };
 
 struct Rng {
     unsigned k0, k1, env, tag;
@@ -1047,7 +1055,28 @@ __device__ inline void write_observation(const DScene &S, const float q[SMR_NJ],
     for (int j = 0; j < SMR_NJ; ++j) row[SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, v[j] / S.vel_max[j]));
 #pragma unroll
     for (int j = 0; j < SMR_NJ; ++j) row[2 * SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, a[j] / S.acc_max[j]));
-    write_planet_observation(S, idx, row + 3 * SMR_NJ);
+    write_planet_observation(S, idx, row + 3 * SMR_NJ + S.obs_target_size);
+}
+
+// A15: target-point part of the observation (obs.py:313-335, ctlp.py:2240-2285): position in the target box, position
+// relative to the target link point ee
+__device__ inline void write_target_observation(const DScene &S, const float tp[3], F3 ee, float *row) {
+    int o = 3 * SMR_NJ;
+    if (S.obs_target_pos)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (tp[c] - S.ball_target_box[c][0]) / (S.ball_target_box[c][1] - S.ball_target_box[c][0])));
+    if (S.obs_target_rel) {
+        const float rel[3] = {tp[0] - ee.x, tp[1] - ee.y, tp[2] - ee.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            row[o++] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (rel[c] - S.target_rel_min[c]) / (S.target_rel_max[c] - S.target_rel_min[c])));
+    }
+}
+
+// target link point (scene.py:185-208) of joint vector q
+__device__ inline F3 ee_point(const DScene &S, const float q[SMR_NJ]) {
+    return apply(body_frame(S, q, S.ee_body), F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
 }
 
 }  // namespace smr

@@ -196,6 +196,25 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     for (int i = 0; i < S.n_self_pairs; ++i) d_self = fminf(d_self, st.dist[(size_t)(2 * NB + i) * B + e]);
 
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ], amax = 0.f, vrel = 0.f, arel = 0.f;
+    // A14: the target point is reached when the target link point comes within its radius at one of the updates of the
+    // step (ctlp.py:2787-2821; the obstacle client follows the setpoints of the cubic)
+    bool tp_reached = false;
+    float tp[3] = {0.f, 0.f, 0.f}, tp_last = 0.f, tp_init = 0.f;
+    F3 ee_end = {0.f, 0.f, 0.f};
+    if (S.use_target) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tp[c] = st.tp[c * B + e];
+        tp_last = st.tp[3 * B + e]; tp_init = st.tp[4 * B + e];
+        for (int u = 1; u <= S.updates_per_step; ++u) {
+            const float t = u == S.updates_per_step ? S.dt : S.dt * (float)u / (float)S.updates_per_step;
+            float qu[SMR_NJ];
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) qu[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
+            ee_end = ee_point(S, qu);
+            const F3 d = F3{tp[0], tp[1], tp[2]} - ee_end;
+            if (!tp_reached && sqrtf(dot(d, d)) < S.target_radius) tp_reached = true;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < SMR_NJ; ++j) {                                        // base.py:1179-1181
         float q0 = st.q[j * B + e], v0 = st.v[j * B + e], a0 = st.a[j * B + e], a1 = st.a1[j * B + e];
@@ -256,8 +275,25 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     const bool finished = steps >= S.episode_steps;                            // tm.py:187-192
     const float bonus = (finished && !term_col) ? S.term_bonus : 0.f;
     const float pun = term_col ? S.early_term_pun : 0.f;
-    reward[e] = (1.f - action_pun) * S.action_max_pun + r_self * S.self_max_reward + r_static * S.static_max_reward +
-                r_moving * S.moving_max_reward + low_acc * S.low_acc_reward + low_vel * S.low_vel_reward + bonus + pun;
+    // A14: get_target_point_reward, ctlp.py:2309-2350
+    float target_reward = 0.f;
+    if (S.use_target) {
+        float norm = 1.f;
+        if (S.target_normalize) { norm = tp_init; if (norm == 0.f) norm += 0.0000001f; }
+        if (tp_reached) target_reward = tp_last / (S.dt * norm) + S.target_bonus;
+        else {
+            const F3 dd = F3{tp[0], tp[1], tp[2]} - ee_end;
+            const float cur = sqrtf(dot(dd, dd));
+            target_reward = (tp_last - cur) / (S.dt * norm);
+            st.tp[3 * B + e] = cur;                                           // the next observation, ctlp.py:2241-2243
+        }
+    }
+    if (S.ca_mode)                                                            // CollisionAvoidanceReward, rewards.py:432-502
+        reward[e] = (1.f - action_pun) * S.action_max_pun + r_self * S.self_max_reward + r_static * S.static_max_reward +
+                    r_moving * S.moving_max_reward + low_acc * S.low_acc_reward + low_vel * S.low_vel_reward + bonus + pun;
+    else                                                                      // TargetPointReachingReward, rewards.py:303-396
+        reward[e] = target_reward * S.target_factor - (S.punish_action ? action_pun : 0.f) * S.action_max_pun +
+                    r_self * S.self_max_reward + r_static * S.static_max_reward + r_moving * S.moving_max_reward;
 
     // A16: base.py:1775-1799
     int rs = SMR_TERMINATION_UNSET;
@@ -288,15 +324,20 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         commit_staged(S, st, e, obs + (size_t)e * S.obs_size);   // next episode's start state was prepared in the background
         st.refill_list[atomicAdd(st.refill_count, 1)] = e;       // hipcc folds this into one atomic per wave
         if (S.use_ball) st.spawn_list[atomicAdd(st.spawn_count, 1)] = -(e + 1);   // its ball: spawn_kernel, as a reset
+        if (S.use_target) st.tp_list[atomicAdd(st.tp_list_count, 1)] = e;         // its target point: target_kernel
     } else if (d && S.auto_reset) {
         int slot = atomicAdd(st.done_count, 1);
         st.done_list[slot] = e;
     } else {
         float *row = obs + (size_t)e * S.obs_size;
         write_observation(S, q, v, a, idx, row);
+        if (S.use_target) {
+            if (tp_reached) st.tp_list[atomicAdd(st.tp_list_count, 1)] = e;       // a new one, get_target_point_observation ctlp.py:2217-2232
+            else write_target_observation(S, tp, ee_end, row);
+        }
         if (S.use_ball) {
             if (ball_respawn) st.spawn_list[atomicAdd(st.spawn_count, 1)] = e;    // ball columns written by spawn_kernel
-            else write_ball_observation(S, ball, ball_k, row + 3 * SMR_NJ);
+            else write_ball_observation(S, ball, ball_k, row + 3 * SMR_NJ + S.obs_target_size);
         }
     }
 }
@@ -594,7 +635,45 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
     }
     if (g == 0) {
         store_ball(st, B, e, b, k0, spawns + 1u);
-        if (obs) write_ball_observation(S, bs, k0, obs + (size_t)e * S.obs_size + 3 * SMR_NJ);
+        if (obs) write_ball_observation(S, bs, k0, obs + (size_t)e * S.obs_size + 3 * SMR_NJ + S.obs_target_size);
+    }
+}
+
+// A14: a new target point for the envs of the list (reached in this step, or reset): _add_target_point, ctlp.py:1658-1721 -
+// the target link point of a random valid configuration inside the target box (attempt m = draws 7m..7m+6 of stream
+// S_TARGET, tag = target points sampled so far), with the distances the next observation records (ctlp.py:2229-2243).
+template <bool EXTRA>
+__global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
+                                                    const int *__restrict__ count_ptr, int count_fixed, int group_stride,
+                                                    float *__restrict__ obs) {
+    const DScene &S = *Sp;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int grp = t >> 3, g = t & 7;
+    if (grp % group_stride) return;
+    const int i = grp / group_stride;
+    if (i >= (count_ptr ? *count_ptr : count_fixed)) return;
+    const int e = list ? list[i] : i;
+    const int B = S.B;
+    const Group G{g, (int)(threadIdx.x & 63) & ~7};
+    const int jj = g < SMR_NJ ? g : 0;
+    const unsigned count = st.tp_count[e];
+    const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, count};
+    float q[SMR_NJ];
+    for (unsigned m = 0; m < 100000u; ++m) {
+        G.gather(rng.uniform(S_TARGET, 7u * m + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
+        if (group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.target_min_static, S.target_min_self)) break;
+    }
+    if (g == 0) {
+        const F3 target = ee_point(S, q);
+        float qc[SMR_NJ];
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) qc[j] = st.q[j * B + e];
+        const F3 ee = ee_point(S, qc);
+        const F3 d = target - ee;
+        const float dist = sqrtf(dot(d, d));
+        st.tp[e] = target.x; st.tp[B + e] = target.y; st.tp[2 * B + e] = target.z; st.tp[3 * B + e] = dist; st.tp[4 * B + e] = dist;
+        st.tp_count[e] = count + 1u;
+        if (obs) { const float tp[3] = {target.x, target.y, target.z}; write_target_observation(S, tp, ee, obs + (size_t)e * S.obs_size); }
     }
 }
 
@@ -644,7 +723,9 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
     // ---- joint velocity / acceleration.  After this block lane j (< 7) holds joint j in (qj, vj, aj).
     float vj = 0.f, aj = 0.f, qj = 0.f;
     const JointLim L = joint_lim(S, jj);
-    if (S.kin_mode && rng.uniform01(S_MODE, 0) < S.kin_prob) {                          // ctlp.py:1494-1556
+    if (!S.ca_mode) {                                                                   // the episode starts at rest, ctlp.py:1490-1491
+        qj = q[jj];
+    } else if (S.kin_mode && rng.uniform01(S_MODE, 0) < S.kin_prob) {                   // ctlp.py:1494-1556
         for (unsigned round = 0;; ++round) {
             bool found = (g >= SMR_NJ);
             const float qme = q[jj];
@@ -766,13 +847,13 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         st.step_count[e] = 0;
         st.moving_hit[e] = hit;
         st.reset_count[e] = rng.tag + 1u;
-        if (row) write_planet_observation(S, idx, row + 3 * SMR_NJ);
+        if (row) write_planet_observation(S, idx, row + 3 * SMR_NJ + S.obs_target_size);
         if (S.use_ball) {
             store_ball(st, B, e, bsp, ball_k0, ball_spawns + 1u);
             BallState bs;
             for (int c = 0; c < 3; ++c) { bs.p0[c] = bsp.p0[c]; bs.v0[c] = bsp.v0[c]; bs.e0[c] = bsp.e0[c]; }
             bs.omega = bsp.omega;
-            if (row) write_ball_observation(S, bs, ball_k0, row + 3 * SMR_NJ);
+            if (row) write_ball_observation(S, bs, ball_k0, row + 3 * SMR_NJ + S.obs_target_size);
         }
     }
 }
@@ -798,7 +879,11 @@ __global__ void observe_kernel(const DScene *__restrict__ Sp, DState st, float *
     for (int j = 0; j < SMR_NJ; ++j) { q[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; a[j] = st.a[j * B + e]; }
     int idx[SMR_MAX_PLANETS] = {st.planet_idx[e], st.planet_idx[B + e]};
     write_observation(S, q, v, a, idx, obs + (size_t)e * S.obs_size);
-    if (S.use_ball) write_ball_observation(S, load_ball(st, B, e), st.ball_i[e], obs + (size_t)e * S.obs_size + 3 * SMR_NJ);
+    if (S.use_ball) write_ball_observation(S, load_ball(st, B, e), st.ball_i[e], obs + (size_t)e * S.obs_size + 3 * SMR_NJ + S.obs_target_size);
+    if (S.use_target) {
+        float tp[3] = {st.tp[e], st.tp[B + e], st.tp[2 * B + e]};
+        write_target_observation(S, tp, ee_point(S, q), obs + (size_t)e * S.obs_size);
+    }
 }
 
 // ---- component kernels for the parity tests ----
@@ -998,6 +1083,14 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
         d.ball_angle[0] = s.ball_sphere_angle[0]; d.ball_angle[1] = s.ball_sphere_angle[1]; d.ball_high_prob = s.ball_high_angle_prob;
         d.plane_z = s.plane_z; d.table_half_xy[0] = s.table_half_xy[0]; d.table_half_xy[1] = s.table_half_xy[1];
     }
+    d.use_target = s.use_target_points; d.obs_target_pos = s.obs_target_pos; d.obs_target_rel = s.obs_target_rel;
+    d.obs_target_size = s.use_target_points ? 3 * ((s.obs_target_pos ? 1 : 0) + (s.obs_target_rel ? 1 : 0)) : 0;
+    d.target_normalize = s.target_normalize; d.ca_mode = s.collision_avoidance_mode;
+    d.target_min_static = (float)s.target_min_dist_static; d.target_min_self = (float)s.target_min_dist_self;
+    d.target_radius = (float)s.target_radius; d.target_bonus = (float)s.target_bonus; d.target_factor = (float)s.target_factor;
+    copy3(d.target_rel_min, s.target_rel_min); copy3(d.target_rel_max, s.target_rel_max);
+    if (s.use_target_points && !s.use_ball)
+        for (int c = 0; c < 3; ++c) { d.ball_target_box[c][0] = (float)s.ball_target_box[c][0]; d.ball_target_box[c][1] = (float)s.ball_target_box[c][1]; }
     d.punish_action = s.punish_action; d.term_self = s.terminate_on_self_collision; d.term_static = s.terminate_on_static_collision;
     d.term_moving = s.terminate_on_moving_collision;
     d.action_thr = (float)s.action_punishment_min_threshold; d.action_max_pun = (float)s.action_max_punishment;
@@ -1027,7 +1120,8 @@ static int check_scene(const smr_scene_t *s, int32_t num_envs, std::string &err)
     }
     if (s->use_ball && s->n_planets > 0) { err = "ball and planets in one scene are not supported"; return SMR_E_INVALID; }
     if (!s->verts || !s->pieces || s->n_verts <= 0 || s->n_pieces <= 0) { err = "scene has no geometry"; return SMR_E_INVALID; }
-    int expect = 3 * SMR_NJ + s->obs_num_planets * s->obs_planet_size_per_planet + (s->use_ball ? 6 : 0);
+    int expect = 3 * SMR_NJ + s->obs_num_planets * s->obs_planet_size_per_planet + (s->use_ball ? 6 : 0) +
+                 (s->use_target_points ? 3 * ((s->obs_target_pos ? 1 : 0) + (s->obs_target_rel ? 1 : 0)) : 0);
     if (s->obs_size != expect) { err = "obs_size does not match the scene"; return SMR_E_INVALID; }
     if (!(s->dt > 0) || s->episode_steps <= 0) { err = "bad time parameters"; return SMR_E_INVALID; }
     return SMR_OK;
@@ -1085,6 +1179,9 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if ((rc = dev_alloc(env, &st.tp, 5 * B)) || (rc = dev_alloc(env, &st.tp_count, B)) || (rc = dev_alloc(env, &st.tp_list, B)) ||
+        (rc = dev_alloc(env, &st.tp_list_count, 1))) return fail(rc);
+    if (hipMemset(st.tp, 0, 5 * B * 4) || hipMemset(st.tp_count, 0, B * 4) || hipMemset(st.tp_list_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     // staged start states (robot part; in ball scenes spawn_kernel draws the ball at commit time)
     {
         const char *off = std::getenv("SMR_SYNC_RESET");          // debugging / A-B measurement: reset on the critical path
@@ -1187,12 +1284,21 @@ static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *co
     else hipLaunchKernelGGL(spawn_kernel<false>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
 }
 
+static void launch_target(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {
+    if (scene_extra(env)) hipLaunchKernelGGL(target_kernel<true>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+    else hipLaunchKernelGGL(target_kernel<false>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+}
+
 static int launch_reset_list(smr_env *env, float *obs_dev) {
     // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
     LaunchTimer t(env, SMR_K_RESET);
     const int B = env->B;
     launch_reset<false>(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->stream, env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
     SMR_HIP(hipGetLastError());
+    if (env->hscene.use_target) {                       // the target points of the new episodes
+        launch_target(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
+        SMR_HIP(hipGetLastError());
+    }
     return SMR_OK;
 }
 
@@ -1252,6 +1358,10 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
                 launch_spawn(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, 1, obs_dev);
                 SMR_HIP(hipGetLastError());
             }
+            if (env->hscene.use_target) {
+                launch_target(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, obs_dev);
+                SMR_HIP(hipGetLastError());
+            }
             return staged_launch_refill(env);
         }
         if ((rc = staged_wait_refill(env))) return rc;
@@ -1265,12 +1375,20 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
             launch_spawn(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, 1, reset_group_stride(), obs_dev);
             SMR_HIP(hipGetLastError());
         }
+        if (env->hscene.use_target) {
+            launch_target(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, reset_group_stride(), obs_dev);
+            SMR_HIP(hipGetLastError());
+        }
         return staged_launch_refill(env);
     }
     if (!mask_dev) {
         LaunchTimer t(env, SMR_K_RESET);
         launch_reset<false>(env, dim3(((size_t)B * 8 + 63) / 64), env->stream, (const int *)nullptr, (const int *)nullptr, B, 1, obs_dev);
         SMR_HIP(hipGetLastError());
+        if (env->hscene.use_target) {
+            launch_target(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, obs_dev);
+            SMR_HIP(hipGetLastError());
+        }
         return SMR_OK;
     }
     SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));
@@ -1287,6 +1405,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     const int B = env->B;
     if (env->auto_reset) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));
     if (env->hscene.use_ball) SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
+    if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
     {
         LaunchTimer t(env, SMR_K_PLAN);
         hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
@@ -1314,6 +1433,11 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (env->hscene.use_ball) {
         LaunchTimer t(env, SMR_K_SPAWN);
         launch_spawn(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.spawn_list, env->st.spawn_count, 0, 0, reset_group_stride(), obs_dev);
+        SMR_HIP(hipGetLastError());
+    }
+    if (env->hscene.use_target) {                       // reached target points, and those of staged resets
+        LaunchTimer t(env, SMR_K_SPAWN);
+        launch_target(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.tp_list, env->st.tp_list_count, 0, reset_group_stride(), obs_dev);
         SMR_HIP(hipGetLastError());
     }
     if (staged) return staged_launch_refill(env);
@@ -1346,7 +1470,8 @@ int smr_get_state(smr_env_t *env, const smr_host_state_t *h) {
     if ((rc = state_get(env, h->q, env->st.q, 7)) || (rc = state_get(env, h->v, env->st.v, 7)) || (rc = state_get(env, h->a, env->st.a, 7)) ||
         (rc = state_get(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_get(env, h->step_count, env->st.step_count, 1)) ||
         (rc = state_get(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_get(env, h->reset_count, env->st.reset_count, 1)) ||
-        (rc = state_get(env, h->ball, env->st.ball, 10)) || (rc = state_get(env, h->ball_i, env->st.ball_i, 5)))
+        (rc = state_get(env, h->ball, env->st.ball, 10)) || (rc = state_get(env, h->ball_i, env->st.ball_i, 5)) ||
+        (rc = state_get(env, h->target, env->st.tp, 5)) || (rc = state_get(env, h->target_count, env->st.tp_count, 1)))
         return rc;
     return SMR_OK;
 }
@@ -1366,7 +1491,8 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     if ((rc = state_set(env, h->q, env->st.q, 7)) || (rc = state_set(env, h->v, env->st.v, 7)) || (rc = state_set(env, h->a, env->st.a, 7)) ||
         (rc = state_set(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_set(env, h->step_count, env->st.step_count, 1)) ||
         (rc = state_set(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_set(env, h->reset_count, env->st.reset_count, 1)) ||
-        (rc = state_set(env, h->ball, env->st.ball, 10)) || (rc = state_set(env, h->ball_i, env->st.ball_i, 5)))
+        (rc = state_set(env, h->ball, env->st.ball, 10)) || (rc = state_set(env, h->ball_i, env->st.ball_i, 5)) ||
+        (rc = state_set(env, h->target, env->st.tp, 5)) || (rc = state_set(env, h->target_count, env->st.tp_count, 1)))
         return rc;
     SMR_HIP(hipDeviceSynchronize());
     if (env->staged && h->reset_count) {               // the staged start states belong to the old reset counters

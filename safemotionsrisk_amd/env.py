@@ -37,7 +37,8 @@ class VecSafeMotionsEnv:
     TERMINATION_COLLISION_WITH_STATIC_OBSTACLE = 4
     TERMINATION_COLLISION_WITH_MOVING_OBSTACLE = 5
 
-    STATE_KEYS = ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "reset_count", "ball", "ball_i")
+    STATE_KEYS = ("q", "v", "a", "planet_idx", "step_count", "moving_hit", "reset_count", "ball", "ball_i", "target",
+                  "target_count")
 
     INFO_COLUMNS = ("minimum_distance_to_static_obstacles", "minimum_distance_self_collision",
                     "minimum_distance_to_moving_obstacles", "action_punishment", "self_collision_reward",
@@ -136,7 +137,8 @@ class VecSafeMotionsEnv:
         st = dict(q=np.zeros((B, NJ), np.float32), v=np.zeros((B, NJ), np.float32), a=np.zeros((B, NJ), np.float32),
                   planet_idx=np.zeros((B, 2), np.int32), step_count=np.zeros(B, np.int32),
                   moving_hit=np.zeros(B, np.int32), reset_count=np.zeros(B, np.uint32),
-                  ball=np.zeros((B, 10), np.float32), ball_i=np.zeros((B, 5), np.int32))
+                  ball=np.zeros((B, 10), np.float32), ball_i=np.zeros((B, 5), np.int32),
+                  target=np.zeros((B, 5), np.float32), target_count=np.zeros(B, np.uint32))
         hs = _lib.HostState(*[st[k].ctypes.data for k in self.STATE_KEYS])
         _lib.check(self._L, self._h, self._L.smr_get_state(self._h, C.byref(hs)), "smr_get_state")
         return st
@@ -145,7 +147,8 @@ class VecSafeMotionsEnv:
         B = self.num_envs
         spec = dict(q=(np.float32, (B, NJ)), v=(np.float32, (B, NJ)), a=(np.float32, (B, NJ)),
                     planet_idx=(np.int32, (B, 2)), step_count=(np.int32, (B,)), moving_hit=(np.int32, (B,)),
-                    reset_count=(np.uint32, (B,)), ball=(np.float32, (B, 10)), ball_i=(np.int32, (B, 5)))
+                    reset_count=(np.uint32, (B,)), ball=(np.float32, (B, 10)), ball_i=(np.int32, (B, 5)),
+                    target=(np.float32, (B, 5)), target_count=(np.uint32, (B,)))
         keep, ptrs = [], []
         for k in self.STATE_KEYS:
             if kw.get(k) is None:

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "libsmr_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 INFO_N = 8
 K_COUNT = 5
 KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn")
@@ -31,7 +31,7 @@ EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "
 class HostState(C.Structure):
     _fields_ = [("q", C.c_void_p), ("v", C.c_void_p), ("a", C.c_void_p), ("planet_idx", C.c_void_p),
                 ("step_count", C.c_void_p), ("moving_hit", C.c_void_p), ("reset_count", C.c_void_p),
-                ("ball", C.c_void_p), ("ball_i", C.c_void_p)]
+                ("ball", C.c_void_p), ("ball_i", C.c_void_p), ("target", C.c_void_p), ("target_count", C.c_void_p)]
 
 
 def _sources():

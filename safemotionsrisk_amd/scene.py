@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-SCENE_VERSION = 5
+SCENE_VERSION = 6
 NJ = 7
 NLINK = 8
 MAX_BODIES = 10
@@ -83,6 +83,11 @@ class Scene(C.Structure):
         ("ball_obs_pos_min", _D3), ("ball_obs_pos_max", _D3), ("ball_obs_vel_min", _D3), ("ball_obs_vel_max", _D3),
         ("ball_active_xy_radius", C.c_double), ("ball_target_box", (C.c_double * 2) * 3),
         ("ball_target_min_dist_static", C.c_double), ("ball_target_min_dist_self", C.c_double), ("plane_z", C.c_double), ("table_half_xy", C.c_double * 2),
+        ("use_target_points", C.c_int32), ("obs_target_pos", C.c_int32), ("obs_target_rel", C.c_int32), ("target_normalize", C.c_int32),
+        ("target_min_dist_static", C.c_double), ("target_min_dist_self", C.c_double),
+        ("target_radius", C.c_double), ("target_bonus", C.c_double), ("target_factor", C.c_double),
+        ("target_rel_min", _D3), ("target_rel_max", _D3),
+        ("collision_avoidance_mode", C.c_int32), ("_pad3", C.c_int32),
         ("punish_action", C.c_int32), ("terminate_on_self_collision", C.c_int32),
         ("terminate_on_static_collision", C.c_int32), ("terminate_on_moving_collision", C.c_int32),
         ("action_punishment_min_threshold", C.c_double), ("action_max_punishment", C.c_double),
@@ -140,6 +145,23 @@ BALL_ENV_CONFIG = dict(
     moving_object_random_initial_position=True, use_moving_objects=True,
 )
 
+#: the target-point reaching task in the space scene: trained_networks/task_networks/reaching_task/space/state_action/
+#: params.json without its risk network (risk_config_dir) - SafeMotionsEnv with
+#: TargetPointReachingReward, ball machine mounted, 8 s episodes
+REACH_ENV_CONFIG = dict(
+    SPACE_ENV_CONFIG, experiment_name="reaching_task_space", ball_machine_mode=True, collision_avoidance_mode=False,
+    collision_avoidance_kinematic_state_sampling_mode=False, collision_avoidance_kinematic_state_sampling_probability=1.0,
+    collision_avoidance_episode_early_termination_punishment=0.0, collision_avoidance_episode_termination_bonus=0.0,
+    collision_avoidance_low_acceleration_max_reward=1.0, collision_avoidance_low_acceleration_threshold=0.1,
+    collision_avoidance_low_velocity_max_reward=1.0, collision_avoidance_low_velocity_threshold=0.1,
+    collision_avoidance_moving_obstacles_max_reward=0.0, collision_avoidance_moving_obstacles_max_reward_distance=0.3,
+    collision_avoidance_self_collision_max_reward=0.0, collision_avoidance_static_obstacles_max_reward=0.0,
+    use_target_points=True, target_point_cartesian_range_scene=0, target_point_relative_pos_scene=0, target_point_radius=0.065,
+    target_point_sequence=0, target_point_reached_reward_bonus=5.0, obs_add_target_point_pos=True,
+    obs_add_target_point_relative_pos=True, normalize_reward_to_initial_target_point_distance=True,
+    target_point_reward_factor=1.0, trajectory_duration=8.0,
+)
+
 # constructor defaults of the reference for the keys this path reads (base.py:85-207, rewards.py:26-54,409-417,
 # obs.py:48, actions.py:29-44)
 _DEFAULTS = dict(
@@ -167,11 +189,16 @@ _DEFAULTS = dict(
     moving_object_sphere_height_min_max=None, moving_object_sphere_angle_min_max=None,
     moving_object_speed_meter_per_second=1.0, moving_object_aim_at_current_robot_position=False,
     moving_object_check_invalid_target_link_point_positions=False, moving_object_random_initial_position=False,
-    target_point_cartesian_range_scene=0,
+    target_point_cartesian_range_scene=0, use_target_points=False, target_point_relative_pos_scene=0,
+    target_point_radius=0.05, target_point_sequence=0, target_point_reached_reward_bonus=0.0,
+    target_point_use_actual_position=False, obs_add_target_point_pos=False, obs_add_target_point_relative_pos=False,
+    normalize_reward_to_initial_target_point_distance=False, target_point_reward_factor=1.0,
 )
 
 # features of the reference outside the hot-path scope ("out of scope"/"next")
-_UNSUPPORTED_TRUE = ("use_real_robot", "use_target_points", "check_braking_trajectory_collisions",
+_UNSUPPORTED_TRUE = ("use_real_robot", "check_braking_trajectory_collisions", "punish_adaptation", "punish_end_min_distance",
+                     "punish_end_max_torque", "punish_braking_trajectory_min_distance", "punish_braking_trajectory_max_torque",
+                     "target_point_use_actual_position",
                      "check_braking_trajectory_torque_limits", "use_gui", "render_video",
                      "risk_check_initial_backup_trajectory", "risk_store_ground_truth", "static_robot",
                      "moving_object_aim_at_current_robot_position", "normalize_reward_to_frequency",
@@ -197,9 +224,11 @@ def validate_env_config(config):
     for k in _UNSUPPORTED_NOT_NONE:
         if config.get(k) is not None:
             raise NotImplementedError("env_config[%r]=%r is outside the batched hot path" % (k, config[k]))
-    if not config.get("collision_avoidance_mode", False):
-        raise NotImplementedError("only SafeMotionsEnvCollisionAvoidance (collision_avoidance_mode=True) is "
-                                  "implemented; the target-point task is SURVEY section 8f row 1")
+    if not config.get("collision_avoidance_mode", False) and not config.get("use_target_points", False):
+        raise NotImplementedError("SafeMotionsEnv (collision_avoidance_mode=False) without use_target_points: its reward "
+                                  "would be the action punishment alone")
+    if config.get("use_target_points") and _cfg(config, "target_point_sequence") != 0:
+        raise NotImplementedError("target_point_sequence != 0 (one robot: TARGET_POINT_SIMULTANEOUS)")
     if _cfg(config, "robot_scene") != 0:
         raise NotImplementedError("robot_scene=%r: only the single iiwa7 (robot_scene=0)" % config["robot_scene"])
     if _cfg(config, "obstacle_scene") not in (0, 5):
@@ -333,6 +362,13 @@ def _build_ball(config, s, assets, add_piece):
         s.ball_obs_pos_min[c], s.ball_obs_pos_max[c] = pos_rng[c]
         s.ball_obs_vel_min[c], s.ball_obs_vel_max[c] = vel_rng[c]
     s.ball_active_xy_radius = 1.25                                                       # ctlp.py:2830
+    _set_target_box(config, s)
+    s.ball_target_min_dist_static = float(_cfg(config, "closest_point_safety_distance")) + 0.09   # ctlp.py:1725-1726
+    s.ball_target_min_dist_self = float(_cfg(config, "closest_point_safety_distance"))            # ctlp.py:2357
+
+
+def _set_target_box(config, s):
+    """_target_point_cartesian_range, ctlp.py:191-229 (ball targets and target points)"""
     tbox = {0: [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]], 1: [[-0.6, 0.6], [-0.3, 0.3], [0.1, 1]],
             2: [[-0.4, 0.4], [-0.4, 0.4], [0.1, 1]], 3: [[-0.2, 0.8], [-0.9, 0.9], [0.3, 1.45]],
             4: [[-0.8, 0.8], [-0.9, 0.9], [0.3, 1.45]], 5: [[-0.1, 0.8], [-0.9, 0.9], [0.3, 1.45]],
@@ -341,8 +377,6 @@ def _build_ball(config, s, assets, add_piece):
             }.get(_cfg(config, "target_point_cartesian_range_scene"), [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]])  # ctlp.py:191-229
     for c in range(3):
         s.ball_target_box[c][0], s.ball_target_box[c][1] = tbox[c]
-    s.ball_target_min_dist_static = float(_cfg(config, "closest_point_safety_distance")) + 0.09   # ctlp.py:1725-1726
-    s.ball_target_min_dist_self = float(_cfg(config, "closest_point_safety_distance"))            # ctlp.py:2357
 
 
 def _piece_adj(assets, family, i):
@@ -602,6 +636,27 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     else:
         s.moving_link_mask = 0
 
+    # ---- target-point reaching task (A14) ----
+    ca_mode = bool(config.get("collision_avoidance_mode", False))
+    s.collision_avoidance_mode = int(ca_mode)
+    s.use_target_points = int(bool(config.get("use_target_points")))
+    if s.use_target_points:
+        safety_d = float(_cfg(config, "closest_point_safety_distance"))
+        _set_target_box(config, s)
+        s.obs_target_pos = int(bool(_cfg(config, "obs_add_target_point_pos")))
+        s.obs_target_rel = int(bool(_cfg(config, "obs_add_target_point_relative_pos")))
+        s.target_normalize = int(bool(_cfg(config, "normalize_reward_to_initial_target_point_distance")))
+        s.target_min_dist_static = safety_d + 0.09                                        # ctlp.py:1661-1664
+        s.target_min_dist_self = safety_d                                                 # ctlp.py:1665-1666,2220
+        s.target_radius = float(_cfg(config, "target_point_radius"))
+        s.target_bonus = float(_cfg(config, "target_point_reached_reward_bonus"))
+        s.target_factor = float(_cfg(config, "target_point_reward_factor"))
+        if _cfg(config, "target_point_relative_pos_scene") != 0:
+            raise NotImplementedError("target_point_relative_pos_scene != 0")
+        for c, (a, bb) in enumerate(zip([-1.6, -2, -1.5], [1.6, 2, 1.5])):               # ctlp.py:184
+            s.target_rel_min[c], s.target_rel_max[c] = a, bb
+        obs_size += 3 * (s.obs_target_pos + s.obs_target_rel)                             # obs.py:66-75
+
     s.obs_size = obs_size
 
     # ---- reward / termination ----
@@ -631,8 +686,12 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
                                                              [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]])  # ctlp.py:172-183
     for c in range(3):
         s.start_box[c][0], s.start_box[c][1] = box[c]
-    s.start_min_dist_static = 0.001                                                      # ctlp.py:1468-1472
-    s.start_min_dist_self = 0.001
+    if ca_mode:
+        s.start_min_dist_static = 0.001                                                  # ctlp.py:1468-1472
+        s.start_min_dist_self = 0.001
+    else:
+        s.start_min_dist_static = float(_cfg(config, "closest_point_safety_distance")) + 0.09    # ctlp.py:1473-1477
+        s.start_min_dist_self = float(_cfg(config, "closest_point_safety_distance")) + 0.04
     s.kinematic_state_sampling_mode = int(bool(_cfg(config, "collision_avoidance_kinematic_state_sampling_mode")))
     s.kinematic_state_sampling_probability = float(_cfg(config, "collision_avoidance_kinematic_state_sampling_probability"))
     s.stay_in_state_probability = float(_cfg(config, "collision_avoidance_stay_in_state_probability"))

@@ -1,9 +1,10 @@
 """env-steps/s and per-kernel times for the plain robot and the ball-machine variant (GPU box)."""
 import sys, time; sys.path.insert(0, ".")
 import torch
-from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG, BALL_ENV_CONFIG
+from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG, BALL_ENV_CONFIG, REACH_ENV_CONFIG
 for name, cfg in (("space", SPACE_ENV_CONFIG), ("space+ball machine", dict(SPACE_ENV_CONFIG, ball_machine_mode=True)),
-                  ("ball", BALL_ENV_CONFIG), ("ball+ball machine", dict(BALL_ENV_CONFIG, ball_machine_mode=True))):
+                  ("ball", BALL_ENV_CONFIG), ("ball+ball machine", dict(BALL_ENV_CONFIG, ball_machine_mode=True)),
+                  ("reaching task", REACH_ENV_CONFIG)):
     B = 65536
     e = VecSafeMotionsEnv(B, seed=0, auto_reset=True, return_info=False, **cfg)
     e.reset(); act = torch.rand((B, 7), device="cuda") * 2 - 1

@@ -2,7 +2,7 @@
 
 The reference itself cannot produce vectors (pybullet/klimits are not installable), so
 these fixtures pin the oracle against accidental change and give the GPU tests a data-only target that
-needs no oracle build on the box.  Run from the repo root:  python tests/golden/make_golden.py [--bm]
+needs no oracle build on the box.  Run from the repo root:  python tests/golden/make_golden.py [--bm | --reach]
 """
 import os
 import sys
@@ -13,36 +13,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from oracle.oracle import OracleEnv                                   # noqa: E402
-from safemotionsrisk_amd.scene import SPACE_ENV_CONFIG, build_scene   # noqa: E402
+from safemotionsrisk_amd.scene import REACH_ENV_CONFIG, SPACE_ENV_CONFIG, build_scene   # noqa: E402
 
 
-def main(ball_machine=False):
-    """ball_machine: the same scene on robot_ball_machine.urdf (-> space_bm_step.npz; info column 1 = self distance)"""
+def main(ball_machine=False, reach=False):
+    """ball_machine: the same scene on robot_ball_machine.urdf (-> space_bm_step.npz; info column 1 = self distance);
+    reach: the target-point reaching task (-> reach_step.npz; extra state: target [B][5], target_count)"""
     B, T = 512, 6
-    scene = build_scene(dict(SPACE_ENV_CONFIG, ball_machine_mode=ball_machine), auto_reset=False)
+    scene = build_scene(REACH_ENV_CONFIG if reach else dict(SPACE_ENV_CONFIG, ball_machine_mode=ball_machine), auto_reset=False)
     env = OracleEnv(scene, B, seed=11, num_threads=4)
     env.reset()
     st0 = env.get_state()
     # spread the episode counters so that terminations at step 20 occur inside the fixture
     rng = np.random.default_rng(42)
     st0["step_count"] = rng.integers(0, 20, B).astype(np.int32)
+    if reach:                               # every fourth target 7-9 cm from the target link point: reached within the fixture
+        near = np.array([env.body_frames(st0["q"][e])[0][8] for e in range(0, B, 4)]) + np.array([0.0, 0.0, 0.1])
+        off = rng.normal(size=near.shape)
+        off *= (rng.uniform(0.07, 0.09, len(near)) / np.linalg.norm(off, axis=1))[:, None]
+        st0["target"][::4, :3] = (near + off).astype(np.float32)
+        st0["target"][::4, 3] = st0["target"][::4, 4] = np.linalg.norm(st0["target"][::4, :3] - near, axis=1)
+        st0["target"] = st0["target"].astype(np.float32).astype(np.float64)
     env.set_state(**st0)
     out = dict(B=B, T=T, seed=11, q0=st0["q"].astype(np.float32), v0=st0["v"].astype(np.float32),
                a0=st0["a"].astype(np.float32), planet_idx0=st0["planet_idx"], step_count0=st0["step_count"],
-               moving_hit0=st0["moving_hit"])
+               moving_hit0=st0["moving_hit"], target0=st0["target"].astype(np.float32), target_count0=st0["target_count"])
     # the oracle steps from the float32-rounded state the GPU will be given
     env.set_state(q=out["q0"], v=out["v0"], a=out["a0"])
     actions = rng.uniform(-1, 1, (T, B, 7)).astype(np.float32)
     actions[:, ::7] = np.sign(actions[:, ::7])            # some bang-bang envs ride the limits
-    obs, rew, done, reason, info, states = [], [], [], [], [], []
+    obs, rew, done, reason, info, states, targets, tcounts = [], [], [], [], [], [], [], []
     for t in range(T):
         o, r, d, rs, inf = env.step(actions[t].astype(np.float64))
         obs.append(o); rew.append(r); done.append(d); reason.append(rs); info.append(inf)
         st = env.get_state()
         states.append(np.concatenate([st["q"], st["v"], st["a"]], axis=1))
+        targets.append(st["target"]); tcounts.append(st["target_count"])
         # every step restarts from the float32 image of the oracle state: one-step parity, no drift
         env.set_state(q=st["q"].astype(np.float32), v=st["v"].astype(np.float32), a=st["a"].astype(np.float32),
-                      step_count=np.where(d, 0, st["step_count"]), moving_hit=np.where(d, 0, st["moving_hit"]))
+                      step_count=np.where(d, 0, st["step_count"]), moving_hit=np.where(d, 0, st["moving_hit"]),
+                      target=st["target"].astype(np.float32))
+    out.update(target=np.array(targets), target_count=np.array(tcounts))
     out.update(actions=actions, obs=np.array(obs), reward=np.array(rew), done=np.array(done), reason=np.array(reason),
                info=np.array(info), state=np.array(states))
     # component vectors
@@ -59,10 +70,11 @@ def main(ball_machine=False):
     rr = [env.safe_acc_range(p[i].astype(np.float64), v[i].astype(np.float64), a[i].astype(np.float64)) for i in range(256)]
     out.update(comp_p=p, comp_v=v, comp_a=a, comp_lo=np.array([r[0] for r in rr]), comp_hi=np.array([r[1] for r in rr]),
                comp_code=np.array([r[2] for r in rr]))
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "space_bm_step.npz" if ball_machine else "space_step.npz")
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                       "reach_step.npz" if reach else "space_bm_step.npz" if ball_machine else "space_step.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes; done fraction", np.mean(out["done"]), "reasons", np.unique(out["reason"]))
 
 
 if __name__ == "__main__":
-    main(ball_machine="--bm" in sys.argv)
+    main(ball_machine="--bm" in sys.argv, reach="--reach" in sys.argv)

@@ -11,22 +11,30 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "space
 import pytest
 
 
-@pytest.mark.parametrize("name", ["space_step.npz", "space_bm_step.npz"])
+@pytest.mark.parametrize("name", ["space_step.npz", "space_bm_step.npz", "reach_step.npz"])
 def test_oracle_reproduces_golden_step_vectors(built, space_scene, bm_scene, name):
+    from safemotionsrisk_amd.scene import REACH_ENV_CONFIG, build_scene
     g = np.load(os.path.join(os.path.dirname(GOLD), name))
     B, T = int(g["B"]), int(g["T"])
-    env = OracleEnv(bm_scene if "bm" in name else space_scene, B, seed=int(g["seed"]), num_threads=4)
+    reach = "reach" in name
+    scene = build_scene(REACH_ENV_CONFIG, auto_reset=False) if reach else bm_scene if "bm" in name else space_scene
+    env = OracleEnv(scene, B, seed=int(g["seed"]), num_threads=4)
     env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], planet_idx=g["planet_idx0"], step_count=g["step_count0"],
-                  moving_hit=g["moving_hit0"])
+                  moving_hit=g["moving_hit0"], **(dict(target=g["target0"], target_count=g["target_count0"]) if reach else {}))
     for t in range(T):
         o, r, d, rs, inf = env.step(g["actions"][t].astype(np.float64))
         assert np.array_equal(d, g["done"][t]) and np.array_equal(rs, g["reason"][t])
         assert np.allclose(o, g["obs"][t], atol=1e-7) and np.allclose(r, g["reward"][t], atol=1e-12)
         assert np.allclose(inf, g["info"][t], atol=1e-12)
         st = env.get_state()
+        if reach:
+            assert np.allclose(st["target"], g["target"][t], atol=1e-12) and np.array_equal(st["target_count"], g["target_count"][t])
         env.set_state(q=st["q"].astype(np.float32), v=st["v"].astype(np.float32), a=st["a"].astype(np.float32),
-                      step_count=np.where(d, 0, st["step_count"]), moving_hit=np.where(d, 0, st["moving_hit"]))
-    assert g["done"].mean() > 0.02 and set(np.unique(g["reason"])) >= ({-1, 2, 3, 4, 5} if "bm" in name else {-1, 2, 5})
+                      step_count=np.where(d, 0, st["step_count"]), moving_hit=np.where(d, 0, st["moving_hit"]),
+                      **(dict(target=st["target"].astype(np.float32)) if reach else {}))
+    assert g["done"].mean() > 0.02 and set(np.unique(g["reason"])) >= ({-1, 3, 4, 5} if reach else {-1, 2, 3, 4, 5} if "bm" in name else {-1, 2, 5})
+    if reach:
+        assert (g["target_count"][-1] > g["target_count0"]).sum() >= 10     # targets were reached and re-drawn inside the fixture
 
 
 def test_oracle_reproduces_golden_components(built, space_scene):

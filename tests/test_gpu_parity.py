@@ -68,14 +68,15 @@ def test_components_against_golden(built):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["space_step.npz", "space_bm_step.npz"])
+@pytest.mark.parametrize("name", ["space_step.npz", "space_bm_step.npz", "reach_step.npz"])
 def test_step_against_golden(built, name):
     import torch
     g = np.load(os.path.join(os.path.dirname(GOLD), name))
     B, T = int(g["B"]), int(g["T"])
-    env = (_bm_env if "bm" in name else _env)(B, seed=int(g["seed"]))
+    reach = "reach" in name
+    env = (_reach_env if reach else _bm_env if "bm" in name else _env)(B, seed=int(g["seed"]))
     env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], planet_idx=g["planet_idx0"], step_count=g["step_count0"],
-                  moving_hit=g["moving_hit0"])
+                  moving_hit=g["moving_hit0"], **(dict(target=g["target0"], target_count=g["target_count0"]) if reach else {}))
     from oracle.oracle import OracleEnv
     ora = OracleEnv(env.scene, 1)
     excluded = 0
@@ -89,8 +90,14 @@ def test_step_against_golden(built, name):
         excluded += int(tie.sum())
         ok = ~tie
         assert np.array_equal(done[ok], g["done"][t][ok]) and np.array_equal(reason[ok], g["reason"][t][ok])
-        assert (np.abs(obs[ok] - g["obs"][t][ok]) < OBS_TOL).all()
-        assert np.abs(rew[ok] - g["reward"][t][ok]).max() < 5e-5
+        tol = np.broadcast_to(REACH_OBS_TOL if reach else OBS_TOL, obs.shape)
+        if reach:                                   # a freshly drawn target comes from float32 FK of a random pose
+            prev = g["target_count"][t - 1] if t else g["target_count0"]
+            tol = np.where((g["target_count"][t] != prev)[:, None], 5e-5, tol)
+        assert (np.abs(obs[ok] - g["obs"][t][ok]) < tol[ok]).all()
+        assert np.abs(rew[ok] - g["reward"][t][ok]).max() < (2e-4 if reach else 5e-5)
+        if reach:
+            assert np.array_equal(st["target_count"][ok], g["target_count"][t][ok]) and np.abs(st["target"] - g["target"][t])[ok].max() < 2e-5
         assert np.abs(vals[ok, :3] - g["info"][t][ok, :3]).max() < 5e-6
         gs = g["state"][t]
         A = np.array(env.scene.struct.acc_max)
@@ -98,7 +105,8 @@ def test_step_against_golden(built, name):
         assert np.abs((st["a"] - gs[:, 14:]) / A).max() < 2e-5
         # golden protocol: continue from the float32 image of the ORACLE state
         env.set_state(q=gs[:, :7].astype(np.float32), v=gs[:, 7:14].astype(np.float32), a=gs[:, 14:].astype(np.float32),
-                      step_count=np.where(g["done"][t], 0, st["step_count"]), moving_hit=np.where(g["done"][t], 0, st["moving_hit"]))
+                      step_count=np.where(g["done"][t], 0, st["step_count"]), moving_hit=np.where(g["done"][t], 0, st["moving_hit"]),
+                      **(dict(target=g["target"][t].astype(np.float32), target_count=g["target_count"][t]) if reach else {}))
     assert excluded <= 0.01 * B * T
     env.close()
 
@@ -443,4 +451,68 @@ def test_ball_machine_rollout_and_reset_against_oracle(built):
             env.reset(mask=torch.from_numpy(done).cuda())
     assert mism <= 2, "%d unexplained mismatches" % mism      # contact ties inside a step are not excluded here
     assert reasons.count(3) > 20 and reasons.count(4) > 20 and reasons.count(5) > 20     # self / static / moving terminations
+    env.close()
+
+
+# ---- target-point reaching task (A14): SafeMotionsEnv with TargetPointReachingReward, shipped task config minus its risk network ----
+
+REACH_OBS_TOL = np.concatenate([np.full(7, 2e-6), np.full(7, 1e-5), np.full(7, 2e-5), np.full(6, 2e-6), np.full(2, 1e-6)])
+
+
+def _reach_env(B, **kw):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from safemotionsrisk_amd import VecSafeMotionsEnv, REACH_ENV_CONFIG
+    kw.setdefault("auto_reset", False)
+    return VecSafeMotionsEnv(B, device=0, **kw, **REACH_ENV_CONFIG)
+
+
+@pytest.mark.gpu
+def test_reaching_task_rollout_and_reset_against_oracle(built):
+    """target points: sampled at reset and when reached, observed (position + relative position), rewarded by the decrease of
+    the distance normalised to the initial one + bonus; episodes start at rest; 4096 envs x 14 steps with state injection.
+    To see targets reached within 14 steps, a quarter of the envs get their target put 8 cm from the target link point."""
+    import torch
+    from oracle.oracle import OracleEnv
+    B, T = 4096, 14
+    env = _reach_env(B, seed=5)
+    obs0 = env.reset().cpu().numpy()
+    assert obs0.shape == (B, 29)
+    ora = OracleEnv(env.scene, B, seed=5, num_threads=16)
+    ora.reset()
+    st, ost = env.get_state(), ora.get_state()
+    same = np.abs(ost["q"] - st["q"]).max(axis=1) < 1e-3
+    assert same.mean() > 0.97 and (st["v"] == 0).all() and (st["a"] == 0).all()          # episodes start at rest
+    assert np.abs(ost["target"] - st["target"])[same].max() < 1e-4 and (st["target_count"] == 1).all()
+    pos, _ = zip(*[ora.body_frames(st["q"][e].astype(np.float64)) for e in range(0, B, 4)])
+    near = st["target"].copy()
+    near[::4, :3] = np.array([p[8] for p in pos]) + np.array([0.0, 0.0, 0.18])            # ee = ball_machine frame + (0, 0, 0.1)
+    near[::4, 3] = near[::4, 4] = 0.08
+    env.set_state(target=near)
+    rng = np.random.default_rng(9)
+    mism, reached, reasons = 0, 0, []
+    for t in range(T):
+        st = env.get_state()
+        ora.set_state(**{k: st[k] for k in env.STATE_KEYS})
+        act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        o_obs, o_rew, o_done, o_reason, o_info = ora.step(act.astype(np.float64))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        reason = info["termination_reason"].cpu().numpy()
+        st1, ost1 = env.get_state(), ora.get_state()
+        bad = (done != o_done) | (reason != o_reason) | (st1["target_count"] != ost1["target_count"])
+        tie = (np.abs(o_info[:, :3] - 0.001) < TIE).any(axis=1) | (np.abs(o_info[:, 2] - 0.02) < TIE)
+        mism += int((bad & ~tie).sum())
+        good = ~bad
+        new = good & (st1["target_count"] != st["target_count"])
+        reached += int(new.sum())
+        assert (np.abs(obs[good] - o_obs[good]) < 5e-5).all()                             # a fresh target: float32 FK of a random pose
+        assert (np.abs(obs[good & ~new] - o_obs[good & ~new]) < REACH_OBS_TOL).all()
+        assert np.abs(rew[good] - o_rew[good]).max() < 2e-4                               # distance differences / (0.1 s x initial distance)
+        assert np.abs(st1["target"][good] - ost1["target"][good]).max() < 2e-5
+        reasons += o_reason[o_done.astype(bool)].tolist()
+        if done.any():
+            env.reset(mask=torch.from_numpy(done).cuda())
+    assert mism <= 3, "%d unexplained mismatches" % mism
+    assert reached > 30 and len(reasons) > 100
     env.close()

@@ -51,7 +51,7 @@ def test_obs_planet_size_variants():
 
 
 @pytest.mark.parametrize("key,value,exc", [
-    ("use_target_points", True, NotImplementedError),
+    ("punish_end_min_distance", True, NotImplementedError),
     ("check_braking_trajectory_collisions", True, NotImplementedError), ("use_real_robot", True, NotImplementedError),
     ("human_network_checkpoint", "human_network/checkpoint/checkpoint", NotImplementedError),
     ("risk_config_dir", "risk_networks/state_action/space", NotImplementedError),
@@ -62,6 +62,24 @@ def test_obs_planet_size_variants():
 def test_unsupported_options_fail_loudly(key, value, exc):
     with pytest.raises(exc):
         build_scene(dict(SPACE_ENV_CONFIG, **{key: value}))
+
+
+def test_reaching_task_scene_fields():
+    """target points: the target link point is observed absolutely and relatively (2 x 3 values,
+    behind the 21 joint values), episodes start at rest outside collision_avoidance_mode, and the start pose keeps the
+    larger distances of safe_motions_base.py:930-950."""
+    from safemotionsrisk_amd.scene import REACH_ENV_CONFIG
+    b = build_scene(REACH_ENV_CONFIG)
+    s = b.struct
+    assert s.use_target_points == 1 and s.collision_avoidance_mode == 0 and b.obs_size == 29
+    assert s.obs_target_pos == 1 and s.obs_target_rel == 1 and s.target_radius == pytest.approx(0.065)
+    assert all(hi > lo for lo, hi in zip(s.target_rel_min, s.target_rel_max))
+    with pytest.raises(NotImplementedError):
+        build_scene(dict(REACH_ENV_CONFIG, use_target_points=False))       # collision_avoidance_mode=False needs a task
+    with pytest.raises(NotImplementedError):
+        build_scene(dict(REACH_ENV_CONFIG, target_point_sequence=1))       # alternating targets: multi-robot scenes only
+    assert build_scene(dict(SPACE_ENV_CONFIG, use_target_points=True)).obs_size == 23       # observation flags default to off
+    assert build_scene(dict(SPACE_ENV_CONFIG, use_target_points=True, obs_add_target_point_relative_pos=True)).obs_size == 23 + 3
 
 
 def test_missing_experiment_name():
