@@ -67,7 +67,7 @@ def test_unsupported_options_fail_loudly(key, value, exc):
 def test_reaching_task_scene_fields():
     """target points: the target link point is observed absolutely and relatively (2 x 3 values,
     behind the 21 joint values), episodes start at rest outside collision_avoidance_mode, and the start pose keeps the
-    larger distances of safe_motions_base.py:930-950."""
+    larger clearances of ctlp.py:1468-1477 (safety distance + 0.09 m to obstacles, + 0.04 m to the robot itself)."""
     from safemotionsrisk_amd.scene import REACH_ENV_CONFIG
     b = build_scene(REACH_ENV_CONFIG)
     s = b.struct
