@@ -48,9 +48,11 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
 // SELF: the scene has self-collision pairs (ball machine); the plain robot runs the instantiation without that code
-template <bool SELF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
+// AUTO: lane-autonomous planet queries (planet_queries_auto); four wavefronts then share the LDS copies
+template <bool SELF, bool AUTO>
+__global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
+    constexpr int kBlock = AUTO ? 256 : 64;
     // grid z: first the self-collision pairs (SELF; they only work at the end-of-step sample), then the bodies, outer ones
     // (most planet work) first
     const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
@@ -66,19 +68,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_
     __shared__ uint32_t lds_span[kMaxPieceVerts];
     __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
     __shared__ uint32_t lds_start[kStartCells / 4];
+    __shared__ float lds_pv[AUTO ? 4 * kMaxPlanetVerts : 4];
+    __shared__ float lds_pd[AUTO ? kPlanetDescDwords * kMaxPlanetPieces : 4];
     const int pl = S.link_piece[l];
     const DPiece LP = load_piece(S.pieces, pl);
     {
         const SMR_GLOBAL float4 *gv = (const SMR_GLOBAL float4 *)S.verts + LP.begin;
         const SMR_GLOBAL uint32_t *gs = (const SMR_GLOBAL uint32_t *)S.span + LP.begin, *gi = (const SMR_GLOBAL uint32_t *)S.ids4 + LP.ids_begin,
                                   *gm = (const SMR_GLOBAL uint32_t *)S.start + (kStartCells / 4) * (size_t)pl;
-        for (int i = threadIdx.x; i < LP.count; i += 64) {
+        for (int i = threadIdx.x; i < LP.count; i += kBlock) {
             const SMR_GLOBAL float *f = (const SMR_GLOBAL float *)(gv + i);
             lds_v[4 * i] = f[0]; lds_v[4 * i + 1] = f[1]; lds_v[4 * i + 2] = f[2]; lds_v[4 * i + 3] = 0.f;
             lds_span[i] = gs[i];
         }
-        for (int i = threadIdx.x; i < LP.ids_count; i += 64) lds_ids[i] = gi[i];
+        for (int i = threadIdx.x; i < LP.ids_count; i += kBlock) lds_ids[i] = gi[i];
         if (threadIdx.x < kStartCells / 4) lds_start[threadIdx.x] = gm[threadIdx.x];
+        if (AUTO && !pair_block) stage_planets(S, threadIdx.x, kBlock, lds_pv, lds_pd);
     }
     __syncthreads();
     const LocalHull hull{lds_v, lds_span, lds_ids, (const uint8_t *)lds_start};
@@ -140,7 +145,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
-        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact);
+        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, nullptr, AUTO);
+        if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, LP, hull, T, idx, want_moving, want_contact, r);
     }
     res[e] = r.contact ? 1.f : 0.f;
     if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving; }
@@ -1067,6 +1073,8 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     }
     copy3(d.planet_obs_min, s.planet_obs_pos_min); copy3(d.planet_obs_max, s.planet_obs_pos_max);
     d.use_ball = s.use_ball; d.dt64 = s.dt;
+    planet_ranges(pieces, d);
+    if (const char *v = getenv("SMR_LOCKSTEP_PLANETS")) if (atoi(v)) d.planets_auto = 0;     // A/B switch
     if (s.use_ball) {
         if (!piece_ok(s.ball_piece)) { env->err = "bad ball_piece"; return SMR_E_INVALID; }
         d.ball_piece = s.ball_piece; d.ball_check_invalid = s.ball_check_invalid_target; d.ball_random_initial = s.ball_random_initial_position;
@@ -1413,9 +1421,13 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipGetLastError());
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
-        const dim3 grid((B + 63) / 64, env->N, env->hscene.n_bodies + env->hscene.n_self_pairs);
-        if (env->hscene.n_self_pairs > 0) hipLaunchKernelGGL(collide_kernel<true>, grid, dim3(64), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL(collide_kernel<false>, grid, dim3(64), 0, env->stream, env->dscene, env->st);
+        const bool self = env->hscene.n_self_pairs > 0, autop = env->hscene.planets_auto != 0;
+        const int block = autop ? 256 : 64;
+        const dim3 grid((B + block - 1) / block, env->N, env->hscene.n_bodies + env->hscene.n_self_pairs);
+        if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
     }
     SMR_HIP(hipGetLastError());
     const bool staged = env->staged && env->auto_reset;

@@ -30,6 +30,62 @@ inline void start_cell_direction(int m, int ia, int ib, double d[3]) {
     else { d[0] = a; d[1] = b; d[2] = sgn; }
 }
 
+// bounding capsule of n points (float4 xyz): axis = principal axis of the points through their mean (power iteration on the
+// covariance), end points pulled in from the extreme projections on a grid, radius = largest distance from the segment
+inline void fit_capsule(const float4 *v, int n, float a_out[3], float b_out[3], float &r_out) {
+    double m[3] = {0, 0, 0}, C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int k = 0; k < n; ++k) { m[0] += v[k].x; m[1] += v[k].y; m[2] += v[k].z; }
+    for (int c = 0; c < 3; ++c) m[c] /= n;
+    for (int k = 0; k < n; ++k) {
+        const double d[3] = {v[k].x - m[0], v[k].y - m[1], v[k].z - m[2]};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) C[i][j] += d[i] * d[j];
+    }
+    double ax[3] = {1.0, 0.7, 0.4};
+    for (int it = 0; it < 200; ++it) {
+        double y[3], nn = 0;
+        for (int i = 0; i < 3; ++i) { y[i] = C[i][0] * ax[0] + C[i][1] * ax[1] + C[i][2] * ax[2]; nn += y[i] * y[i]; }
+        if (nn < 1e-300) break;
+        nn = std::sqrt(nn);
+        for (int i = 0; i < 3; ++i) ax[i] = y[i] / nn;
+    }
+    { double nn = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]); for (int i = 0; i < 3; ++i) ax[i] /= nn; }
+    double t0 = 1e300, t1 = -1e300;
+    for (int k = 0; k < n; ++k) {
+        const double t = (v[k].x - m[0]) * ax[0] + (v[k].y - m[1]) * ax[1] + (v[k].z - m[2]) * ax[2];
+        t0 = std::min(t0, t); t1 = std::max(t1, t);
+    }
+    double best = 1e300;
+    const int G = 20;
+    for (int i0 = 0; i0 <= G; ++i0)
+        for (int i1 = 0; i1 <= G; ++i1) {
+            const double L = t1 - t0, s0 = t0 + 0.5 * L * i0 / G, s1 = t1 - 0.5 * L * i1 / G;
+            const double a[3] = {m[0] + ax[0] * s0, m[1] + ax[1] * s0, m[2] + ax[2] * s0}, len = s1 - s0;
+            double r = 0;
+            for (int k = 0; k < n; ++k) {
+                const double d[3] = {v[k].x - a[0], v[k].y - a[1], v[k].z - a[2]};
+                double t = d[0] * ax[0] + d[1] * ax[1] + d[2] * ax[2];
+                t = std::min(std::max(t, 0.0), len);
+                const double e[3] = {d[0] - t * ax[0], d[1] - t * ax[1], d[2] - t * ax[2]};
+                r = std::max(r, std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]));
+            }
+            if (r < best) {
+                best = r;
+                for (int c = 0; c < 3; ++c) { a_out[c] = (float)a[c]; b_out[c] = (float)(a[c] + ax[c] * len); }
+            }
+        }
+    // radius re-measured against the float32 end points, slightly inflated: the bound stays conservative
+    double r = 0;
+    const double a[3] = {a_out[0], a_out[1], a_out[2]}, e[3] = {b_out[0] - a[0], b_out[1] - a[1], b_out[2] - a[2]};
+    const double ee = std::max(e[0] * e[0] + e[1] * e[1] + e[2] * e[2], 1e-300);
+    for (int k = 0; k < n; ++k) {
+        const double d[3] = {v[k].x - a[0], v[k].y - a[1], v[k].z - a[2]};
+        const double t = std::min(std::max((d[0] * e[0] + d[1] * e[1] + d[2] * e[2]) / ee, 0.0), 1.0);
+        const double f[3] = {d[0] - t * e[0], d[1] - t * e[1], d[2] - t * e[2]};
+        r = std::max(r, std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]));
+    }
+    r_out = (float)(r * 1.00001 + 1e-6);
+}
+
 // returns nullptr on success, else a message
 inline const char *build_host_geometry(const smr_scene_t &s, HostGeometry &G) {
     if (!s.adj_offsets || !s.adj) return "scene has no hull adjacency (adj_offsets / adj)";
@@ -59,6 +115,7 @@ inline const char *build_host_geometry(const smr_scene_t &s, HostGeometry &G) {
             hx = std::max(hx, std::fabs(dx)); hy = std::max(hy, std::fabs(dy)); hz = std::max(hz, std::fabs(dz));
         }
         q.radius = r * 1.00001f + 1e-7f; q.hx = hx + 1e-7f; q.hy = hy + 1e-7f; q.hz = hz + 1e-7f;
+        fit_capsule(&G.verts[(size_t)q.begin], p.vert_count, q.cap_a, q.cap_b, q.cap_r);
         // an axis-aligned box given as its 8 corners (the table): every vertex is a corner of the vertices' bounding box
         q.bx0 = q.bx1 = q.by0 = q.by1 = q.btop = 0.f;
         if (p.kind == SMR_PIECE_HULL && p.vert_count == 8) {
@@ -161,6 +218,22 @@ inline const char *scene_bodies(const smr_scene_t &s, DScene &d) {
         d.self_pair[i][0] = a; d.self_pair[i][1] = b;
     }
     return nullptr;
+}
+
+// the range of pieces / vertex slots the planets occupy, when it fits the budget of the lane-autonomous planet queries
+inline void planet_ranges(const std::vector<DPiece> &pieces, DScene &d) {
+    d.planets_auto = 0; d.planet_p0 = d.planet_pn = d.planet_v0 = d.planet_vn = 0;
+    if (d.n_planets <= 0 || d.use_ball) return;
+    int p0 = 1 << 30, p1 = 0;
+    for (int p = 0; p < d.n_planets; ++p) { p0 = std::min(p0, d.planet[p].piece_begin); p1 = std::max(p1, d.planet[p].piece_begin + d.planet[p].piece_count); }
+    int covered = 0;
+    for (int p = 0; p < d.n_planets; ++p) covered += d.planet[p].piece_count;
+    if (covered != p1 - p0 || p1 - p0 > kMaxPlanetPieces) return;               // contiguous piece range, one key byte each
+    if (d.n_planets > 1 && d.planet[1].piece_begin < d.planet[0].piece_begin) return;
+    int v0 = 1 << 30, v1 = 0;
+    for (int i = p0; i < p1; ++i) { v0 = std::min(v0, pieces[i].begin); v1 = std::max(v1, pieces[i].begin + pieces[i].count); }
+    if (v1 - v0 > kMaxPlanetVerts) return;
+    d.planets_auto = 1; d.planet_p0 = p0; d.planet_pn = p1 - p0; d.planet_v0 = v0; d.planet_vn = v1 - v0;
 }
 
 // bounding sphere of a whole planet: centre = mean of the piece centres, radius covers every piece sphere + margin

@@ -20,6 +20,8 @@ static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }   
 static inline unsigned __lane_id() { return 0u; }
 template <class T> static inline T __shfl(T x, int) { return x; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline bool __any(bool p) { return p; }
 static inline void sincosf_(float x, float *s, float *c) { *s = std::sin(x); *c = std::cos(x); }
 #define sincosf sincosf_
 #include <math.h>
@@ -95,6 +97,7 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
         planet_bounds(H->G.pieces, q);
     }
     d.use_ball = s.use_ball; d.ball_piece = s.ball_piece; d.ball_radius = (float)s.ball_radius;
+    planet_ranges(H->G.pieces, d);
     d.term_moving = s.terminate_on_moving_collision; d.collision_dist = (float)s.collision_distance;
     return H;
 }
@@ -121,13 +124,23 @@ extern "C" int emul_piece_count(void *h, int pi) { return ((HostScene *)h)->d.pi
 extern "C" int emul_piece_kind(void *h, int pi) { return ((HostScene *)h)->d.pieces[pi].kind; }
 
 // planets: the end-of-step query set of one (env, link) lane of the collide kernel
+// want_moving / want_contact bit 1 (value 2): lane-autonomous planet queries (planet_queries_auto) instead of the lockstep loop
 extern "C" void emul_link_query(void *h, const float *q, const int *idx, int l, int want_static, int want_moving, int want_contact, float *out) {
     HostScene *H = (HostScene *)h;
     const DScene &S = H->d;
     Xf T = fk_base(S);
     for (int j = 0; j < l; ++j) fk_advance(S, j, q[j], T);
     const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
-    Sample r = collide_link(S, l, LP, global_hull(S, S.link_piece[l], LP), T, idx, nullptr, want_static != 0, want_moving != 0, want_contact != 0);
+    const bool autop = ((want_moving | want_contact) & 2) && S.planets_auto;
+    want_moving &= 1; want_contact &= 1;
+    Sample r = collide_link(S, l, LP, global_hull(S, S.link_piece[l], LP), T, idx, nullptr, want_static != 0, want_moving != 0, want_contact != 0, nullptr, autop);
+    if (autop) {
+        static std::vector<float> pv, pd;
+        pv.assign(4 * kMaxPlanetVerts, 0.f); pd.assign(kPlanetDescDwords * kMaxPlanetPieces, 0.f);
+        stage_planets(S, 0, 1, pv.data(), pd.data());
+        planet_queries_auto(S, pv.data(), pd.data(), LP, global_hull(S, S.link_piece[l], LP), T, idx,
+                            want_moving && ((S.moving_mask >> l) & 1u), want_contact && ((S.contact_mask >> l) & 1u), r);
+    }
     out[0] = r.d_static; out[1] = r.d_moving; out[2] = r.contact ? 1.f : 0.f;
 }
 
