@@ -90,7 +90,9 @@ struct DScene {
     DPlanet planet[SMR_MAX_PLANETS];
     // all planet pieces [planet_p0, +planet_pn) and their vertex slots [planet_v0, +planet_vn): what the step kernel stages
     // in LDS for the lane-autonomous planet queries (planets_auto = 0: does not fit, wave-lockstep queries)
-    int planets_auto, planet_p0, planet_pn, planet_v0, planet_vn;
+    int planets_auto, planet_p0, planet_pn, planet_vn;   // planet_vn: vertex slots of auto_verts (4 floats each)
+    const float *auto_verts;   // the planet pieces' vertices, every piece padded to a multiple of 4 with its last vertex
+    const float *auto_desc;    // kPlanetDescDwords per piece: first slot, padded count, margin, planet (0 / 1), centre xyz
     float planet_obs_min[3], planet_obs_max[3];
     // ball (A10)
     int use_ball, ball_piece, ball_check_invalid, ball_random_initial;
@@ -169,6 +171,16 @@ __device__ __forceinline__ F3 rot_t(const Xf &X, F3 v) {
             fmaf(X.r[8], v.z, fmaf(X.r[5], v.y, X.r[2] * v.x))};
 }
 __device__ __forceinline__ F3 apply(const Xf &X, F3 v) { return rot(X, v) + X.t; }
+// T^-1 o X: the frame X seen from the frame T (rigid transforms)
+__device__ __forceinline__ Xf inv_compose(const Xf &T, const Xf &X) {
+    Xf R;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R.r[3 * i + j] = fmaf(T.r[6 + i], X.r[6 + j], fmaf(T.r[3 + i], X.r[3 + j], T.r[i] * X.r[j]));
+    R.t = rot_t(T, F3{X.t.x - T.t.x, X.t.y - T.t.y, X.t.z - T.t.z});
+    return R;
+}
 
 // ---------------------------------------------------------------------------------------------
 // RNG: Philox4x32-10.  Stateless addressing: draw d of (env, stream, tag) is word d&3 of
@@ -773,12 +785,14 @@ __device__ __forceinline__ bool gjk_iterate(GjkRun &g, const SA &sa, const SB &s
 __device__ __forceinline__ float seg_seg_dist2(F3 p1, F3 q1, F3 p2, F3 q2) {
     const F3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
     const float a = fmaxf(dot(d1, d1), 1e-12f), e = fmaxf(dot(d2, d2), 1e-12f), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2);
-    const float den = a * e - b * b;
-    float s = den > 1e-9f * a * e ? fminf(fmaxf((b * f - c * e) / den, 0.f), 1.f) : 0.f;
+    const float den = a * e - b * b, ra = __builtin_amdgcn_rcpf(a);
+    // reciprocals to 1 ulp: any parameters in [0, 1] give points ON the segments, the error of the distance stays at
+    // rounding level (callers shave 1e-5 relative + 1e-6 off before they use it as a lower bound)
+    float s = den > 1e-9f * a * e ? fminf(fmaxf((b * f - c * e) * __builtin_amdgcn_rcpf(den), 0.f), 1.f) : 0.f;
     float t = b * s + f;
-    if (t < 0.f) { t = 0.f; s = fminf(fmaxf(-c / a, 0.f), 1.f); }
-    else if (t > e) { t = 1.f; s = fminf(fmaxf((b - c) / a, 0.f), 1.f); }
-    else t = t / e;
+    if (t < 0.f) { t = 0.f; s = fminf(fmaxf(-c * ra, 0.f), 1.f); }
+    else if (t > e) { t = 1.f; s = fminf(fmaxf((b - c) * ra, 0.f), 1.f); }
+    else t = t * __builtin_amdgcn_rcpf(e);
     const F3 diff = {r.x + d1.x * s - d2.x * t, r.y + d1.y * s - d2.y * t, r.z + d1.z * s - d2.z * t};
     return dot(diff, diff);
 }
@@ -1118,46 +1132,61 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
 // The lanes' pieces differ, so the obstacle side is scanned per lane from an LDS copy of the planets' vertices.
 // ---------------------------------------------------------------------------------------------
 __device__ inline void stage_planets(const DScene &S, int tid, int nthreads, float *pv, float *pd) {
-    const SMR_GLOBAL float *gv = (const SMR_GLOBAL float *)S.verts + 4 * (size_t)S.planet_v0;
+    const SMR_GLOBAL float *gv = (const SMR_GLOBAL float *)S.auto_verts, *gd = (const SMR_GLOBAL float *)S.auto_desc;
     for (int i = tid; i < 4 * S.planet_vn; i += nthreads) pv[i] = gv[i];
-    for (int i = tid; i < S.planet_pn; i += nthreads) {
-        const DPiece P = load_piece_lane(S.pieces, S.planet_p0 + i);
-        float *w = pd + kPlanetDescDwords * i;
-        w[0] = __int_as_float(P.begin - S.planet_v0); w[1] = __int_as_float(P.count); w[2] = P.margin;
-        w[3] = __int_as_float((S.n_planets > 1 && S.planet_p0 + i >= S.planet[1].piece_begin) ? 1 : 0);
-        w[4] = P.cx; w[5] = P.cy; w[6] = P.cz; w[7] = 0.f;
-    }
+    for (int i = tid; i < kPlanetDescDwords * S.planet_pn; i += nthreads) pd[i] = gd[i];
 }
 
 template <class HB>
-__device__ inline void planet_queries_auto(const DScene &S, const float *pv, const float *pd, const DPiece &LP, const HB &hull,
-                                           const Xf &T, const int idx[SMR_MAX_PLANETS], bool mov, bool want_contact, Sample &out) {
+__device__ inline void planet_queries_auto(const DScene &S, const float *pv, const float *pd, uint32_t *keys, int kstride,
+                                           const DPiece &LP, const HB &hull, const Xf &T, const int idx[SMR_MAX_PLANETS], bool mov,
+                                           bool want_contact, Sample &out) {
     const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
     const F3 lc = apply(T, F3{LP.cx, LP.cy, LP.cz});
     bool finished = !(mov || want_contact);
-    // pass 1 (lockstep, scalar piece loads): the key of every piece
-    uint32_t keys[7];
-    {
-        const F3 l0 = apply(T, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), l1 = apply(T, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
-        const Xf X0 = planet_pose(S, 0, idx[0]);
-        const Xf X1 = planet_pose(S, S.n_planets > 1 ? 1 : 0, idx[S.n_planets > 1 ? 1 : 0]);
+    // pass 1 (lockstep, scalar piece loads): the key of every piece.  Whole-planet and piece bounding spheres first; a
+    // wavefront none of whose lanes passes them skips the capsule arithmetic (nearly always at the contact-only samples).
+    // The lane's 28 key bytes live in LDS (keys[w * kstride], w < 7): registers are what limits this kernel.
 #pragma unroll
+    for (int w = 0; w < 7; ++w) keys[w * kstride] = 0xFFFFFFFFu;
+    if (__any(!finished)) {
+        float cutoff_max = mov ? S.moving_max : S.contact_dist;
+        if (want_contact) cutoff_max = fmaxf(cutoff_max, S.contact_dist);
+        const F3 l0 = apply(T, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), l1 = apply(T, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
+        const int second_planet = S.n_planets > 1 ? 1 : 0;
+        const Xf X0 = planet_pose(S, 0, idx[0]);
+        const Xf X1 = planet_pose(S, second_planet, idx[second_planet]);
+        const F3 e0 = apply(X0, F3{S.planet[0].bx, S.planet[0].by, S.planet[0].bz}) - lc,
+                 e1 = apply(X1, F3{S.planet[second_planet].bx, S.planet[second_planet].by, S.planet[second_planet].bz}) - lc;
+        const bool near0 = !finished && sqrtf(dot(e0, e0)) - S.planet[0].bradius - LP.radius - LP.margin <= cutoff_max;
+        const bool near1 = !finished && sqrtf(dot(e1, e1)) - S.planet[second_planet].bradius - LP.radius - LP.margin <= cutoff_max;
+#pragma unroll 1
         for (int w = 0; w < 7; ++w) {
             uint32_t word = 0xFFFFFFFFu;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 const int i = 4 * w + b;
+                uint32_t key = 255u;
                 if (i < S.planet_pn) {
                     const DPiece PP = load_piece(S.pieces, S.planet_p0 + i);
                     const bool second = S.n_planets > 1 && S.planet_p0 + i >= S.planet[1].piece_begin;
-                    const F3 ca = {PP.cap_a[0], PP.cap_a[1], PP.cap_a[2]}, cb = {PP.cap_b[0], PP.cap_b[1], PP.cap_b[2]};
-                    const F3 a0 = second ? apply(X1, ca) : apply(X0, ca), a1 = second ? apply(X1, cb) : apply(X0, cb);
-                    const float lb = sqrtf(seg_seg_dist2(a0, a1, l0, l1)) * 0.99999f - 1e-6f - PP.cap_r - LP.cap_r - PP.margin - LP.margin;
-                    const uint32_t key = (uint32_t)fminf(fmaxf(lb * (1.0f / kKeyStep), 0.f), 254.f);
-                    word = (word & ~(0xFFu << (8 * b))) | (key << (8 * b));
+                    if (second ? near1 : near0) {
+                        const float margins = PP.margin + LP.margin;
+                        const F3 cen = {PP.cx, PP.cy, PP.cz};
+                        const F3 dc = (second ? apply(X1, cen) : apply(X0, cen)) - lc;
+                        const float lb_s = sqrtf(dot(dc, dc)) - PP.radius - LP.radius - margins;
+                        if (lb_s <= cutoff_max) {
+                            const F3 ca = {PP.cap_a[0], PP.cap_a[1], PP.cap_a[2]}, cb = {PP.cap_b[0], PP.cap_b[1], PP.cap_b[2]};
+                            const F3 a0 = second ? apply(X1, ca) : apply(X0, ca), a1 = second ? apply(X1, cb) : apply(X0, cb);
+                            const float lb_c = sqrtf(seg_seg_dist2(a0, a1, l0, l1)) * 0.99999f - 1e-6f - PP.cap_r - LP.cap_r - margins;
+                            const float lb = fmaxf(lb_s, lb_c);
+                            if (lb <= cutoff_max) key = (uint32_t)fminf(fmaxf(lb * (1.0f / kKeyStep), 0.f), 254.f);
+                        }
+                    }
                 }
+                word = (word >> 8) | (key << 24);
             }
-            keys[w] = word;
+            keys[w * kstride] = word;
         }
     }
     // pass 2: lane-autonomous GJK, best candidate first
@@ -1168,20 +1197,26 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
     const float *av = pv;
     int ac = 1;
     float margins = 0.f;
-    const auto sb = [&](F3 d, int &hint, bool first) { return apply(T, hull.support(rot_t(T, d), hint, first)); };
+    // pass 2 works in the LINK frame (XA = the obstacle piece's frame seen from it): the link-side support needs no
+    // transform and the link's world frame T leaves the loop's registers
+    const F3 lcl = {LP.cx, LP.cy, LP.cz};
+    const auto sb = [&](F3 d, int &hint, bool first) { return hull.support(d, hint, first); };
     const auto sa = [&](F3 d, int &, bool) {
         const F3 dl = rot_t(XA, d);
         float best = -3.0e38f;
         F3 bp = {0.f, 0.f, 0.f};
-        for (int i = 0; i < ac; i += 4) {
+        int bi = 0;
+        for (int i = 0; i < ac; i += 4) {                   // ac is a multiple of 4 (padded with copies of the last vertex)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int j = i + u < ac ? i + u : ac - 1;
-                const F3 q = {av[4 * j], av[4 * j + 1], av[4 * j + 2]};
-                const float sq = fmaf(q.z, dl.z, fmaf(q.y, dl.y, q.x * dl.x));
-                if (sq > best) { best = sq; bp = q; }
+                const float *q = av + 4 * (i + u);
+                const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
+                const bool gt = sq > best;
+                best = gt ? sq : best;
+                bi = gt ? i + u : bi;
             }
         }
+        bp = {av[4 * bi], av[4 * bi + 1], av[4 * bi + 2]};
         return apply(XA, bp);
     };
     for (int trip = 0; trip < 33 * kMaxPlanetPieces; ++trip) {
@@ -1189,27 +1224,28 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
             con_cur = want_contact && !out.contact;
             float cutoff = mov ? fminf(out.d_moving, S.moving_max) : S.contact_dist;
             if (con_cur) cutoff = fmaxf(cutoff, S.contact_dist);
-            uint32_t best = 0xFFFFFFFFu;
+            uint32_t best = 0xFFFFFFFFu, kw[7];
+#pragma unroll
+            for (int w = 0; w < 7; ++w) kw[w] = keys[w * kstride];
 #pragma unroll
             for (int w = 0; w < 7; ++w)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const uint32_t cand = (((keys[w] >> (8 * b)) & 0xFFu) << 5) | (uint32_t)(4 * w + b);
+                    const uint32_t cand = (((kw[w] >> (8 * b)) & 0xFFu) << 5) | (uint32_t)(4 * w + b);
                     best = cand < best ? cand : best;
                 }
             const int key = (int)(best >> 5), c = (int)(best & 31u);
             if (!(mov || con_cur) || key == 255 || (float)key * kKeyStep > cutoff) finished = true;
             else {
-#pragma unroll
-                for (int w = 0; w < 7; ++w) keys[w] = (c >> 2) == w ? keys[w] | (0xFFu << (8 * (c & 3))) : keys[w];
+                keys[(c >> 2) * kstride] |= 0xFFu << (8 * (c & 3));
                 const float *d = pd + kPlanetDescDwords * c;
                 av = pv + 4 * __float_as_int(d[0]);
                 ac = __float_as_int(d[1]);
                 margins = d[2] + LP.margin;
                 const int p = __float_as_int(d[3]);
-                XA = quat_pose((const SMR_GLOBAL float *)(p ? S.planet[1].orbit_pose : S.planet[0].orbit_pose) + 8 * (size_t)(p ? idx[1] : idx[0]));
+                XA = inv_compose(T, quat_pose((const SMR_GLOBAL float *)(p ? S.planet[1].orbit_pose : S.planet[0].orbit_pose) + 8 * (size_t)(p ? idx[1] : idx[0])));
                 SMR_CNT_SLOT(S.planet_p0 + c);
-                g.start(apply(XA, F3{d[4], d[5], d[6]}) - lc, cutoff + margins, stop_moving + margins);
+                g.start(apply(XA, F3{d[4], d[5], d[6]}) - lcl, cutoff + margins, stop_moving + margins);
                 active = true;
             }
         }

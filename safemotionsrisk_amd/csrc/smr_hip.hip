@@ -70,6 +70,7 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     __shared__ uint32_t lds_start[kStartCells / 4];
     __shared__ float lds_pv[AUTO ? 4 * kMaxPlanetVerts : 4];
     __shared__ float lds_pd[AUTO ? kPlanetDescDwords * kMaxPlanetPieces : 4];
+    __shared__ uint32_t lds_keys[AUTO ? 7 * kBlock : 4];
     const int pl = S.link_piece[l];
     const DPiece LP = load_piece(S.pieces, pl);
     {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
         r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, nullptr, AUTO);
-        if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, LP, hull, T, idx, want_moving, want_contact, r);
+        if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock, LP, hull, T, idx, want_moving, want_contact, r);
     }
     res[e] = r.contact ? 1.f : 0.f;
     if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving; }
@@ -1037,7 +1038,7 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     if (const char *msg = scene_bodies(s, d)) { env->err = msg; return SMR_E_INVALID; }
     for (int l = 0; l < s.n_bodies; ++l)
         if (G.pieces[s.link_piece[l]].ids_count > kMaxPieceIdGroups) { env->err = "link hull adjacency exceeds the LDS budget"; return SMR_E_INVALID; }
-    const std::vector<DPiece> &pieces = G.pieces;
+    std::vector<DPiece> &pieces = G.pieces;
     float4 *dverts; DPiece *dpieces; uint32_t *dspan, *dids; uint8_t *dstart;
     int rc;
     while (G.start.size() % 4) G.start.push_back(0);
@@ -1073,8 +1074,13 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     }
     copy3(d.planet_obs_min, s.planet_obs_pos_min); copy3(d.planet_obs_max, s.planet_obs_pos_max);
     d.use_ball = s.use_ball; d.dt64 = s.dt;
-    planet_ranges(pieces, d);
+    planet_tables(G, d);
     if (const char *v = getenv("SMR_LOCKSTEP_PLANETS")) if (atoi(v)) d.planets_auto = 0;     // A/B switch
+    if (d.planets_auto) {
+        float4 *dav; float *dad;
+        if ((rc = dev_upload(env, &dav, G.auto_verts)) || (rc = dev_upload(env, &dad, G.auto_desc))) return rc;
+        d.auto_verts = (const float *)dav; d.auto_desc = dad;
+    }
     if (s.use_ball) {
         if (!piece_ok(s.ball_piece)) { env->err = "bad ball_piece"; return SMR_E_INVALID; }
         d.ball_piece = s.ball_piece; d.ball_check_invalid = s.ball_check_invalid_target; d.ball_random_initial = s.ball_random_initial_position;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "smr_device.h"
@@ -20,6 +21,8 @@ struct HostGeometry {
     std::vector<uint32_t> span;    // per vertex slot (indexed like verts): first id group relative to the piece | groups << 16
     std::vector<uint32_t> ids4;    // groups of 4 neighbour ids (one byte each, local to the piece), padded with the vertex itself
     std::vector<uint8_t> start;    // kStartCells per piece: the support vertex of each cube-map cell centre
+    std::vector<float4> auto_verts; // lane-autonomous planet queries (planet_tables): padded vertex lists of the planets' pieces + table
+    std::vector<float> auto_desc;   // ... and their descriptors
 };
 
 // direction of start-map cell (m, ia, ib): see climb_start() in smr_device.h
@@ -220,20 +223,32 @@ inline const char *scene_bodies(const smr_scene_t &s, DScene &d) {
     return nullptr;
 }
 
-// the range of pieces / vertex slots the planets occupy, when it fits the budget of the lane-autonomous planet queries
-inline void planet_ranges(const std::vector<DPiece> &pieces, DScene &d) {
-    d.planets_auto = 0; d.planet_p0 = d.planet_pn = d.planet_v0 = d.planet_vn = 0;
+// Tables of the lane-autonomous planet queries (planet_queries_auto in smr_device.h), when the planets fit their budget:
+// the pieces' vertex lists padded to multiples of 4 (copies of the last vertex: the scan needs no bounds test) and
+// one descriptor per piece.  d.auto_verts / d.auto_desc are left to the caller (device copies of G.auto_verts / G.auto_desc).
+inline void planet_tables(HostGeometry &G, DScene &d) {
+    const std::vector<DPiece> &pieces = G.pieces;
+    d.planets_auto = 0; d.planet_p0 = d.planet_pn = d.planet_vn = 0;
+    G.auto_verts.clear(); G.auto_desc.clear();
     if (d.n_planets <= 0 || d.use_ball) return;
-    int p0 = 1 << 30, p1 = 0;
-    for (int p = 0; p < d.n_planets; ++p) { p0 = std::min(p0, d.planet[p].piece_begin); p1 = std::max(p1, d.planet[p].piece_begin + d.planet[p].piece_count); }
-    int covered = 0;
-    for (int p = 0; p < d.n_planets; ++p) covered += d.planet[p].piece_count;
+    int p0 = 1 << 30, p1 = 0, covered = 0;
+    for (int p = 0; p < d.n_planets; ++p) {
+        p0 = std::min(p0, d.planet[p].piece_begin); p1 = std::max(p1, d.planet[p].piece_begin + d.planet[p].piece_count);
+        covered += d.planet[p].piece_count;
+    }
     if (covered != p1 - p0 || p1 - p0 > kMaxPlanetPieces) return;               // contiguous piece range, one key byte each
     if (d.n_planets > 1 && d.planet[1].piece_begin < d.planet[0].piece_begin) return;
-    int v0 = 1 << 30, v1 = 0;
-    for (int i = p0; i < p1; ++i) { v0 = std::min(v0, pieces[i].begin); v1 = std::max(v1, pieces[i].begin + pieces[i].count); }
-    if (v1 - v0 > kMaxPlanetVerts) return;
-    d.planets_auto = 1; d.planet_p0 = p0; d.planet_pn = p1 - p0; d.planet_v0 = v0; d.planet_vn = v1 - v0;
+    auto add = [&](int pi, int frame) {
+        const DPiece &P = pieces[pi];
+        const int first = (int)G.auto_verts.size(), padded = (P.count + 3) / 4 * 4;
+        for (int k = 0; k < padded; ++k) G.auto_verts.push_back(G.verts[(size_t)P.begin + std::min(k, P.count - 1)]);
+        float w[kPlanetDescDwords] = {0, 0, P.margin, 0, P.cx, P.cy, P.cz, 0};
+        std::memcpy(&w[0], &first, 4); std::memcpy(&w[1], &padded, 4); std::memcpy(&w[3], &frame, 4);
+        G.auto_desc.insert(G.auto_desc.end(), w, w + kPlanetDescDwords);
+    };
+    for (int i = p0; i < p1; ++i) add(i, (d.n_planets > 1 && i >= d.planet[1].piece_begin) ? 1 : 0);
+    if ((int)G.auto_verts.size() > kMaxPlanetVerts) { G.auto_verts.clear(); G.auto_desc.clear(); return; }
+    d.planets_auto = 1; d.planet_p0 = p0; d.planet_pn = p1 - p0; d.planet_vn = (int)G.auto_verts.size();
 }
 
 // bounding sphere of a whole planet: centre = mean of the piece centres, radius covers every piece sphere + margin

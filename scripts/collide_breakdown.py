@@ -27,5 +27,6 @@ run('no moving distance', moving_link_mask=0)
 run('no contact', contact_link_mask=0)
 run('no moving, no contact', moving_link_mask=0, contact_link_mask=0)
 run('only contact', moving_link_mask=0, static_link_mask=0)
+run('only static', moving_link_mask=0, contact_link_mask=0)
 run('N=1', N=1)
 run('N=1 no contact', N=1, contact_link_mask=0)

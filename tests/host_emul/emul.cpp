@@ -22,6 +22,7 @@ template <class T> static inline T __shfl(T x, int) { return x; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline bool __any(bool p) { return p; }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline void sincosf_(float x, float *s, float *c) { *s = std::sin(x); *c = std::cos(x); }
 #define sincosf sincosf_
 #include <math.h>
@@ -97,7 +98,8 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
         planet_bounds(H->G.pieces, q);
     }
     d.use_ball = s.use_ball; d.ball_piece = s.ball_piece; d.ball_radius = (float)s.ball_radius;
-    planet_ranges(H->G.pieces, d);
+    planet_tables(H->G, d);
+    d.auto_verts = (const float *)H->G.auto_verts.data(); d.auto_desc = H->G.auto_desc.data();
     d.term_moving = s.terminate_on_moving_collision; d.collision_dist = (float)s.collision_distance;
     return H;
 }
@@ -138,7 +140,8 @@ extern "C" void emul_link_query(void *h, const float *q, const int *idx, int l, 
         static std::vector<float> pv, pd;
         pv.assign(4 * kMaxPlanetVerts, 0.f); pd.assign(kPlanetDescDwords * kMaxPlanetPieces, 0.f);
         stage_planets(S, 0, 1, pv.data(), pd.data());
-        planet_queries_auto(S, pv.data(), pd.data(), LP, global_hull(S, S.link_piece[l], LP), T, idx,
+        uint32_t keys[7];
+        planet_queries_auto(S, pv.data(), pd.data(), keys, 1, LP, global_hull(S, S.link_piece[l], LP), T, idx,
                             want_moving && ((S.moving_mask >> l) & 1u), want_contact && ((S.contact_mask >> l) & 1u), r);
     }
     out[0] = r.d_static; out[1] = r.d_moving; out[2] = r.contact ? 1.f : 0.f;
