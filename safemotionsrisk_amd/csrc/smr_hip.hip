@@ -684,9 +684,12 @@ __global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ S
     }
 }
 
-static int reset_group_stride() {      // every n-th 8-lane group works (tuning knob SMR_RESET_GROUP_STRIDE: 1, 2, 4 or 8)
-    static const int v = [] { const char *e = std::getenv("SMR_RESET_GROUP_STRIDE"); int x = e ? std::atoi(e) : 4; return (x == 1 || x == 2 || x == 4 || x == 8) ? x : 4; }();
-    return v;
+// every n-th 8-lane group works (tuning knob SMR_RESET_GROUP_STRIDE: 1, 2, 4 or 8).  On the critical path (synchronous reset)
+// sparse wavefronts finish soonest: 4.  The staged refill runs beside the step kernels and competes with them for vector
+// issue, where denser wavefronts cost fewer instructions: 2 (measured: 74.7M -> 76.1M env-steps/s).
+static int reset_group_stride(bool staged = false) {
+    static const int v = [] { const char *e = std::getenv("SMR_RESET_GROUP_STRIDE"); int x = e ? std::atoi(e) : 0; return (x == 1 || x == 2 || x == 4 || x == 8) ? x : 0; }();
+    return v ? v : (staged ? 2 : 4);
 }
 
 // env.reset() for the envs in list[0..count): obs.py:144-149 -> base.py:913-1022.
@@ -1330,7 +1333,7 @@ static int staged_launch_refill(smr_env *env) {        // side stream: prepare n
     {
         LaunchTimer t(env, SMR_K_RESET, env->side);
         const int B = env->B;
-        launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(), (float *)nullptr);
+        launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), env->side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(true), (float *)nullptr);
     }
     SMR_HIP(hipGetLastError());
     SMR_HIP(hipEventRecord(env->ev_refill, env->side));

@@ -4,9 +4,12 @@ import torch
 from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG, BALL_ENV_CONFIG, REACH_ENV_CONFIG
 for name, cfg in (("space", SPACE_ENV_CONFIG), ("space+ball machine", dict(SPACE_ENV_CONFIG, ball_machine_mode=True)),
                   ("ball", BALL_ENV_CONFIG), ("ball+ball machine", dict(BALL_ENV_CONFIG, ball_machine_mode=True)),
-                  ("reaching task", REACH_ENV_CONFIG)):
+                  ("reaching task", REACH_ENV_CONFIG),
+                  ("space, N=24 contact samples", dict(SPACE_ENV_CONFIG, collision_checks_per_step=24)),
+                  ("space, N=1", dict(SPACE_ENV_CONFIG, collision_checks_per_step=1))):
     B = 65536
-    e = VecSafeMotionsEnv(B, seed=0, auto_reset=True, return_info=False, **cfg)
+    cfg = dict(cfg); extra = {k: cfg.pop(k) for k in ("collision_checks_per_step",) if k in cfg}
+    e = VecSafeMotionsEnv(B, seed=0, auto_reset=True, return_info=False, **extra, **cfg)
     e.reset(); act = torch.rand((B, 7), device="cuda") * 2 - 1
     for _ in range(10): e.step(act)
     e.synchronize(); e.set_profiling(True); torch.cuda.synchronize()

@@ -21,12 +21,13 @@ def run(name, N=None, **patch):
     for _ in range(40): e.step(act)
     pr = e.get_profile(); e.close()
     print(name, {k: round(v['ms'] / max(v['launches'], 1), 3) for k, v in pr.items()}, flush=True)
-run('baseline')
-run('no static', static_link_mask=0)
-run('no moving distance', moving_link_mask=0)
-run('no contact', contact_link_mask=0)
-run('no moving, no contact', moving_link_mask=0, contact_link_mask=0)
-run('only contact', moving_link_mask=0, static_link_mask=0)
-run('only static', moving_link_mask=0, contact_link_mask=0)
-run('N=1', N=1)
-run('N=1 no contact', N=1, contact_link_mask=0)
+VARIANTS = {
+    'baseline': {}, 'no static': dict(static_link_mask=0), 'no moving distance': dict(moving_link_mask=0),
+    'no contact': dict(contact_link_mask=0), 'no moving, no contact': dict(moving_link_mask=0, contact_link_mask=0),
+    'only contact': dict(moving_link_mask=0, static_link_mask=0), 'only static': dict(moving_link_mask=0, contact_link_mask=0),
+    'nothing': dict(moving_link_mask=0, contact_link_mask=0, static_link_mask=0),
+    'only moving': dict(static_link_mask=0, contact_link_mask=0),
+    'N=1': dict(N=1), 'N=1 no contact': dict(N=1, contact_link_mask=0),
+}
+for name in (sys.argv[1:] or list(VARIANTS)):        # e.g. under rocprofv3: one variant per run
+    run(name, **VARIANTS[name])

@@ -54,6 +54,42 @@ def test_device_distances_on_host(emul, space_scene):
     assert worst < 2e-6
 
 
+def test_lane_autonomous_planet_queries_equal_lockstep(emul, space_scene):
+    """planet_queries_auto (every lane takes its own candidate pieces best first, keys from capsule bounds, GJK in the
+    link frame) against the wave-lockstep loop of collide_link and against the oracle: per-link moving distance and the
+    contact flag, for the end-of-step sample (distance + contact) and for a contact-only sample."""
+    s = space_scene.struct
+    ora = O.OracleEnv(space_scene, 1)
+    H = C.c_void_p(emul.emul_scene_create(C.cast(space_scene.pointer(), C.c_void_p)))
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    hits = 0
+    for _ in range(400):
+        q = rng.uniform(np.array(s.pos_lo), np.array(s.pos_hi)).astype(np.float32)
+        i0 = int(rng.integers(1200))
+        idx = np.array([i0, (i0 - 480) % 1200], dtype=np.int32)
+        d = ora.distances(q.astype(np.float64), idx)
+        per_link = []
+        for l in range(8):
+            lock, auto, con_l, con_a, dist_a = (np.zeros(3, np.float32) for _ in range(5))
+            args = (H, q.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p), l, 0)
+            emul.emul_link_query(*args, 1, 1, lock.ctypes.data_as(C.c_void_p))
+            emul.emul_link_query(*args, 3, 3, auto.ctypes.data_as(C.c_void_p))
+            emul.emul_link_query(*args, 0, 1, con_l.ctypes.data_as(C.c_void_p))
+            emul.emul_link_query(*args, 0, 3, con_a.ctypes.data_as(C.c_void_p))
+            emul.emul_link_query(*args, 3, 0, dist_a.ctypes.data_as(C.c_void_p))      # distance only: refined below 0.02 too
+            near = lambda x: abs(x - 0.02) < 2e-5 or abs(x - 0.001) < 2e-5
+            if not near(lock[1]):
+                assert abs(min(lock[1], 0.6) - min(auto[1], 0.6)) < 1e-6 or (lock[1] < 0.001 and auto[1] < 0.001)
+                assert lock[2] == auto[2] and con_l[2] == con_a[2]
+            per_link.append(dist_a[1])
+            hits += int(auto[2])
+        if d[2] < 0.6 and abs(d[2] - 0.001) > 2e-5:
+            got = min(per_link)
+            worst = max(worst, abs((0.0 if got < 0.001 else got) - (0.0 if d[2] < 0.001 else d[2])))
+    assert worst < 2e-6 and hits > 10
+
+
 def test_device_distances_with_ball_machine_on_host(emul, bm_scene):
     """robot_ball_machine.urdf: the two convex pieces mounted on iiwa_link_7 take part in the table / planet queries and
     pair with the base adapter's cylinder and iiwa_link_0..5 for the self-collision distance (A7 self)."""
