@@ -725,6 +725,8 @@ __device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff,
     return sqrtf(vv);
 }
 
+__device__ __forceinline__ F3 sel3(bool c, F3 a, F3 b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+
 // One GJK run as resumable state: gjk_iterate() advances it by one iteration, so that the lanes of a wavefront can each
 // work on their OWN pair and move on to their next pair as soon as it is settled (planet_queries_auto).
 struct GjkRun {
@@ -761,8 +763,10 @@ __device__ __forceinline__ bool gjk_iterate(GjkRun &g, const SA &sa, const SB &s
     if (!settled) {
         {   // selects, not an if / else-if chain: hipcc 7.2 dropped the x component of `g.w3 = w` in that form when this
             // function was inlined into a per-lane trip loop (seen in an ISA-level trace, gfx950 -O3)
+            // ... and component by component: a select between two F3 OBJECTS is lowered to a select between their addresses,
+            // which pins the whole run state in scratch memory (seen in the ISA: ~70 scratch accesses per trip)
             const int slot = g.n;
-            g.w0 = slot == 0 ? w : g.w0; g.w1 = slot == 1 ? w : g.w1; g.w2 = slot == 2 ? w : g.w2; g.w3 = slot >= 3 ? w : g.w3;
+            g.w0 = sel3(slot == 0, w, g.w0); g.w1 = sel3(slot == 1, w, g.w1); g.w2 = sel3(slot == 2, w, g.w2); g.w3 = sel3(slot >= 3, w, g.w3);
         }
         ++g.n;
         F3 vn;
