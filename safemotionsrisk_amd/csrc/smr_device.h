@@ -619,7 +619,8 @@ __device__ __forceinline__ F3 tri_closest(F3 a, F3 b, F3 c, int &mask) {
     return bv;
 }
 
-__device__ __forceinline__ F3 pick_lowest(int m, F3 a, F3 b, F3 c, F3 d) { return (m & 1) ? a : (m & 2) ? b : (m & 4) ? c : d; }
+__device__ __forceinline__ F3 sel3(bool c, F3 a, F3 b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }   // never `c ? a : b` on objects
+__device__ __forceinline__ F3 pick_lowest(int m, F3 a, F3 b, F3 c, F3 d) { return sel3(m & 1, a, sel3(m & 2, b, sel3(m & 4, c, d))); }
 
 // Closest point of the simplex {w0..w(n-1)} to the origin; the simplex is reduced to the vertices
 // supporting it.  Returns true when the origin is enclosed (n == 4 and inside).
@@ -724,8 +725,6 @@ __device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff,
     }
     return sqrtf(vv);
 }
-
-__device__ __forceinline__ F3 sel3(bool c, F3 a, F3 b) { return {c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 
 // One GJK run as resumable state: gjk_iterate() advances it by one iteration, so that the lanes of a wavefront can each
 // work on their OWN pair and move on to their next pair as soon as it is settled (planet_queries_auto).
