@@ -2,7 +2,9 @@
 
 Host mirror of the reference's env surface over a C-ABI library of HIP kernels (gfx950):
 ``VecSafeMotionsEnv`` (env.py), scene construction from ``env_config`` (scene.py), the ctypes binding
-(lib.py), rollout sharding over the GPUs of a node (dist.py).
+(lib.py), rollout sharding over the GPUs of a node (dist.py), episode metrics and the RLlib-style vector
+interface (metrics.py).
 """
 from .scene import SPACE_ENV_CONFIG, BALL_ENV_CONFIG, REACH_ENV_CONFIG, build_scene  # noqa: F401
 from .env import VecSafeMotionsEnv, SafeMotionsEnvCollisionAvoidance  # noqa: F401
+from .metrics import EpisodeMetrics, RllibVectorEnv  # noqa: F401

@@ -1,0 +1,186 @@
+"""Episode metrics and the RLlib-style vector interface on top of VecSafeMotionsEnv (first half).
+
+The reference returns, with every step, an ``info`` dictionary of per-step scalars grouped by the operator that
+aggregates them over an episode (``info['average'|'max'|'min'][key]``: safe_motions_base.py:1350-1365,
+observations.py:365-413, rewards.py:172-207,490-498), and ``CustomTrainCallbacks`` (train.py:40-117) folds them into one
+custom metric ``<key>_<op>`` per finished episode plus ``episode_length``, ``success_rate`` and the
+``*_termination_rate`` flags.  ``EpisodeMetrics`` is that pipeline for B environments at once: running sum / max / min
+per (env, key) on the env's device, emitted for the envs that finished in a step.  Host logic only - it reads the
+tensors ``step()`` returned and launches torch element-wise kernels; nothing here is on the hot path of the library.
+
+``RllibVectorEnv`` exposes the three calls RLlib's ``VectorEnv`` is driven by (``vector_reset``, ``reset_at``,
+``vector_step``; ray/rllib/env/vector_env.py) with per-env python ``info`` dictionaries shaped like the reference's.
+Ray is not a dependency: the class is duck-typed, a maintainer registers it with ``VectorEnv.register`` or subclasses.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+NJ = 7
+
+# safe_motions_base.py:63-70
+TERMINATION_JOINT_LIMITS = 1
+TERMINATION_TRAJECTORY_LENGTH = 2
+TERMINATION_SELF_COLLISION = 3
+TERMINATION_COLLISION_WITH_STATIC_OBSTACLE = 4
+TERMINATION_COLLISION_WITH_MOVING_OBSTACLE = 5
+
+# train.py:106-117
+TERMINATION_RATE_KEYS = {
+    TERMINATION_TRAJECTORY_LENGTH: "trajectory_length_termination_rate",
+    TERMINATION_JOINT_LIMITS: "joint_limit_violation_termination_rate",
+    TERMINATION_SELF_COLLISION: "collision_self_termination_rate",
+    TERMINATION_COLLISION_WITH_STATIC_OBSTACLE: "collision_static_obstacles_termination_rate",
+    TERMINATION_COLLISION_WITH_MOVING_OBSTACLE: "collision_moving_obstacles_termination_rate",
+}
+
+
+def step_scalar_names(info_columns):
+    """Names of the per-step scalars, in the order of the columns of EpisodeMetrics' accumulators.
+    obs-derived: observations.py:376-403 (joint_{j}_{pos,vel,acc}[_abs], joint_vel_norm); info-derived: the library's
+    info columns except episode_length (rewards.py:490-498), collision rates (safe_motions_base.py:1290-1295), reward."""
+    names = []
+    for kind in ("pos", "vel", "acc"):
+        names += ["joint_%d_%s" % (j, kind) for j in range(NJ)]
+    for kind in ("pos", "vel", "acc"):
+        names += ["joint_%d_%s_abs" % (j, kind) for j in range(NJ)]
+    names += ["joint_vel_norm"]
+    names += [c for c in info_columns if c != "episode_length"]
+    names += ["collision_rate_self", "collision_rate_static_obstacles", "collision_rate_moving_obstacles", "reward"]
+    return names
+
+
+class FinishedEpisodes:
+    """Metrics of the episodes that ended in one step: ``env_index`` [n], ``episode_length`` [n], ``termination_reason``
+    [n] and ``metrics[name]`` [n] for every ``<key>_<op>`` / rate of CustomTrainCallbacks.on_episode_end."""
+
+    def __init__(self, env_index, episode_length, termination_reason, metrics):
+        self.env_index, self.episode_length, self.termination_reason, self.metrics = env_index, episode_length, termination_reason, metrics
+
+    def __len__(self):
+        return int(self.env_index.shape[0])
+
+    def mean(self):
+        """What RLlib reports: the mean of every custom metric over these episodes (python floats)."""
+        return {k: float(v.float().mean()) for k, v in self.metrics.items()} if len(self) else {}
+
+
+class EpisodeMetrics:
+    def __init__(self, num_envs, info_columns, device=None, auto_reset=True, trajectory_length=None):
+        """trajectory_length: round(trajectory_duration / trajectory_time_step) + 1 (trajectory_manager.py:87), reported as is."""
+        import torch
+        self._t = torch
+        self.trajectory_length = trajectory_length
+        self.num_envs, self.auto_reset = int(num_envs), bool(auto_reset)
+        self.info_columns = tuple(info_columns)
+        self.names = step_scalar_names(self.info_columns)
+        self._info_sel = [i for i, c in enumerate(self.info_columns) if c != "episode_length"]
+        self._len_col = self.info_columns.index("episode_length")
+        self._d_cols = [self.info_columns.index(c) for c in ("minimum_distance_self_collision", "minimum_distance_to_static_obstacles",
+                                                             "minimum_distance_to_moving_obstacles")]
+        K = len(self.names)
+        self.n_obs = 6 * NJ + 1                                    # the obs-derived scalars come first
+        kw = dict(device=device, dtype=torch.float32)
+        self.sum = torch.zeros((self.num_envs, K), **kw)
+        self.max = torch.full((self.num_envs, K), -float("inf"), **kw)
+        self.min = torch.full((self.num_envs, K), float("inf"), **kw)
+        self.count = torch.zeros((self.num_envs, K), **kw)
+
+    def step_scalars(self, obs, reward, info_values):
+        """[B, K] per-step scalars (the values of the reference's info['average'] entries of this step)."""
+        t = self._t
+        jo = obs[:, :3 * NJ].float()
+        vel = jo[:, NJ:2 * NJ]
+        d = info_values[:, self._d_cols]
+        return t.cat([jo, jo.abs(), t.linalg.vector_norm(vel, dim=1, keepdim=True), info_values[:, self._info_sel].float(),
+                      (d == 0).float(), reward.float().unsqueeze(1)], dim=1)
+
+    def update(self, obs, reward, done, info):
+        """Fold one step in; returns FinishedEpisodes for the envs with done set (their accumulators restart).
+        With auto_reset the obs of a finished env already belongs to its next episode, so the obs-derived scalars of
+        terminal steps are left out there (every other scalar covers all steps)."""
+        t = self._t
+        x = self.step_scalars(obs, reward, info["values"])
+        valid = t.ones_like(x, dtype=t.bool)
+        d = done.bool()
+        if self.auto_reset:
+            valid[:, :self.n_obs] = ~d.unsqueeze(1)
+        xs = t.where(valid, x, t.zeros_like(x))
+        self.sum += xs
+        self.count += valid.float()
+        self.max = t.where(valid, t.maximum(self.max, x), self.max)
+        self.min = t.where(valid, t.minimum(self.min, x), self.min)
+        idx = d.nonzero(as_tuple=True)[0]
+        if idx.numel() == 0:
+            e = idx.new_zeros((0,))
+            return FinishedEpisodes(idx, e, e, {})
+        reason = info["termination_reason"][idx].long()
+        length = info["values"][idx, self._len_col].long()
+        cnt = self.count[idx].clamp(min=1)
+        avg, mx, mn = self.sum[idx] / cnt, self.max[idx], self.min[idx]
+        metrics = {}
+        for k, name in enumerate(self.names):
+            metrics[name + "_average"] = avg[:, k]
+            metrics[name + "_max"] = mx[:, k]
+            metrics[name + "_min"] = mn[:, k]
+        metrics["episode_length"] = length.float()
+        # trajectory_successful: True unless a joint limit was violated (actions.py:382-385, base.py:930,1368-1371)
+        metrics["success_rate"] = (reason != TERMINATION_JOINT_LIMITS).float()
+        if self.trajectory_length is not None:
+            metrics["trajectory_length"] = t.full_like(metrics["episode_length"], float(self.trajectory_length))
+        for code, name in TERMINATION_RATE_KEYS.items():
+            metrics[name] = (reason == code).float()
+        self.sum[idx] = 0
+        self.count[idx] = 0
+        self.max[idx] = -float("inf")
+        self.min[idx] = float("inf")
+        return FinishedEpisodes(idx, length, reason, metrics)
+
+
+class RllibVectorEnv:
+    """vector_reset / reset_at / vector_step over a VecSafeMotionsEnv built with auto_reset=False (RLlib resets finished
+    sub-environments itself through reset_at).  Observations, rewards and dones come back as python lists of numpy values;
+    infos as one dictionary per env shaped like the reference's (``average`` / ``max`` / ``min`` sub-dicts of the step,
+    and at the end of an episode ``episode_length``, ``trajectory_length``, ``termination_reason``,
+    ``trajectory_successful``: safe_motions_base.py:1367-1377)."""
+
+    def __init__(self, env):
+        if getattr(env, "scene", None) is not None and env.scene.struct.auto_reset:
+            raise ValueError("RllibVectorEnv needs an env built with auto_reset=False")
+        self.env = env
+        self.num_envs = env.num_envs
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+        self._names = step_scalar_names(env.INFO_COLUMNS)
+        self.trajectory_length = int(env.scene.struct.episode_steps) + 1                   # trajectory_manager.py:87
+        self._metrics = EpisodeMetrics(env.num_envs, env.INFO_COLUMNS, device=getattr(env, "device", None), auto_reset=False)
+        self._len_col = env.INFO_COLUMNS.index("episode_length")
+
+    def get_sub_environments(self):
+        return []
+
+    def vector_reset(self):
+        obs = self.env.reset()
+        return list(obs.detach().cpu().numpy())
+
+    def reset_at(self, index=None):
+        import torch
+        mask = torch.zeros(self.num_envs, dtype=torch.uint8)
+        mask[0 if index is None else int(index)] = 1
+        obs = self.env.reset(mask=mask)
+        return obs[0 if index is None else int(index)].detach().cpu().numpy()
+
+    def vector_step(self, actions):
+        obs, reward, done, info = self.env.step(np.asarray(actions, dtype=np.float32))
+        x = self._metrics.step_scalars(obs, reward, info["values"]).detach().cpu().numpy()
+        o, r, d = obs.detach().cpu().numpy(), reward.detach().cpu().numpy(), done.detach().cpu().numpy().astype(bool)
+        reason = info["termination_reason"].detach().cpu().numpy()
+        length = info["values"][:, self._len_col].detach().cpu().numpy()
+        infos = []
+        for e in range(self.num_envs):
+            step = dict(zip(self._names, x[e].tolist()))
+            ie = {"average": step, "max": dict(step), "min": dict(step)}
+            if d[e]:
+                ie.update(episode_length=int(length[e]), trajectory_length=self.trajectory_length, termination_reason=int(reason[e]),
+                          trajectory_successful=0.0 if reason[e] == TERMINATION_JOINT_LIMITS else 1.0)
+            infos.append(ie)
+        return list(o), r.tolist(), d.tolist(), infos

@@ -516,3 +516,34 @@ def test_reaching_task_rollout_and_reset_against_oracle(built):
     assert mism <= 3, "%d unexplained mismatches" % mism
     assert reached > 30 and len(reasons) > 100
     env.close()
+
+
+@pytest.mark.gpu
+def test_episode_metrics_on_the_gpu_env(built):
+    """EpisodeMetrics over the real env (auto-reset): every env finishes at least one episode in 25 steps, episode lengths
+    are those of the info column, the termination rates partition the episodes, distances feed the min metrics."""
+    import torch
+    from safemotionsrisk_amd import EpisodeMetrics
+    B = 2048
+    env = _env(B, seed=2, auto_reset=True)
+    env.reset()
+    m = EpisodeMetrics(B, env.INFO_COLUMNS, device=env.device, auto_reset=True, trajectory_length=21)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    n, agg = 0, {}
+    for _ in range(25):
+        act = torch.rand((B, 7), device="cuda", generator=gen) * 2 - 1
+        obs, rew, done, info = env.step(act)
+        fin = m.update(obs, rew, done, info)
+        if len(fin):
+            n += len(fin)
+            for k, v in fin.metrics.items():
+                agg[k] = agg.get(k, 0.0) + float(v.sum())
+            assert (fin.episode_length >= 1).all() and (fin.episode_length <= 20).all()
+            assert (fin.metrics["joint_0_pos_abs_max"] <= 1.0001).all()
+            assert (fin.metrics["minimum_distance_to_moving_obstacles_min"] <= fin.metrics["minimum_distance_to_moving_obstacles_average"] + 1e-6).all()
+    assert n >= B
+    rates = sum(agg[k] for k in agg if k.endswith("_termination_rate")) / n
+    assert abs(rates - 1.0) < 1e-6 and agg["success_rate"] / n == 1.0 and 1.0 < agg["episode_length"] / n <= 20.0
+    moving = agg["collision_moving_obstacles_termination_rate"] / n
+    assert 0.0 < moving < 1.0 and agg["collision_rate_moving_obstacles_max"] / n >= moving - 1e-6
+    env.close()

@@ -1,0 +1,118 @@
+"""Episode metrics and the RLlib-style vector interface (host logic; CPU tensors and a fake env stand in for the GPU env)."""
+import numpy as np
+import pytest
+import torch
+
+from safemotionsrisk_amd.env import VecSafeMotionsEnv
+from safemotionsrisk_amd.metrics import EpisodeMetrics, RllibVectorEnv, step_scalar_names
+
+COLS = VecSafeMotionsEnv.INFO_COLUMNS
+
+
+def _random_rollout(B, T, rng, p_done=0.15):
+    obs = rng.uniform(-1, 1, (T, B, 23)).astype(np.float32)
+    rew = rng.uniform(0, 5, (T, B)).astype(np.float32)
+    vals = rng.uniform(0, 1, (T, B, 8)).astype(np.float32)
+    vals[..., 0][rng.random((T, B)) < 0.1] = 0.0                      # static collisions
+    done = rng.random((T, B)) < p_done
+    reason = np.where(done, rng.choice([1, 2, 4, 5], (T, B)), -1).astype(np.int8)
+    length = np.zeros((T, B), np.float32)
+    run = np.zeros(B)
+    for t in range(T):
+        run += 1
+        length[t] = run
+        run[done[t]] = 0
+    vals[..., 7] = length
+    return obs, rew, vals, done, reason
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_episode_metrics_match_a_per_env_python_fold(auto_reset):
+    """the same fold CustomTrainCallbacks does per episode (train.py:47-79): append per step, then average / max / min"""
+    rng = np.random.default_rng(0)
+    B, T = 16, 60
+    obs, rew, vals, done, reason = _random_rollout(B, T, rng)
+    m = EpisodeMetrics(B, COLS, auto_reset=auto_reset, trajectory_length=21)
+    names = step_scalar_names(COLS)
+    assert len(names) == len(set(names)) and "joint_3_vel_abs" in names and "collision_rate_static_obstacles" in names
+    hist = [[] for _ in range(B)]
+    checked = 0
+    for t in range(T):
+        info = {"values": torch.from_numpy(vals[t]), "termination_reason": torch.from_numpy(reason[t])}
+        fin = m.update(torch.from_numpy(obs[t]), torch.from_numpy(rew[t]), torch.from_numpy(done[t]), info)
+        x = m.step_scalars(torch.from_numpy(obs[t]), torch.from_numpy(rew[t]), info["values"]).numpy()
+        for e in range(B):
+            hist[e].append((x[e], bool(done[t, e])))
+        assert sorted(fin.env_index.tolist()) == sorted(np.nonzero(done[t])[0].tolist())
+        for i, e in enumerate(fin.env_index.tolist()):
+            rows = np.array([h[0] for h in hist[e]])
+            obs_rows = rows[:-1] if auto_reset else rows            # auto_reset: the terminal obs belongs to the next episode
+            for k, name in enumerate(names):
+                r = obs_rows if k < m.n_obs else rows
+                if len(r) == 0:
+                    continue
+                assert fin.metrics[name + "_average"][i].item() == pytest.approx(r[:, k].mean(), abs=1e-5)
+                assert fin.metrics[name + "_max"][i].item() == pytest.approx(r[:, k].max(), abs=1e-6)
+                assert fin.metrics[name + "_min"][i].item() == pytest.approx(r[:, k].min(), abs=1e-6)
+            assert fin.episode_length[i].item() == len(rows) and fin.metrics["trajectory_length"][i].item() == 21
+            assert fin.metrics["success_rate"][i].item() == (0.0 if reason[t, e] == 1 else 1.0)
+            assert fin.metrics["collision_static_obstacles_termination_rate"][i].item() == float(reason[t, e] == 4)
+            hist[e] = []
+            checked += 1
+        if len(fin):
+            assert set(fin.mean()) == set(fin.metrics)
+    assert checked > 50
+
+
+class _FakeEnv:
+    """stands in for VecSafeMotionsEnv(auto_reset=False): deterministic tensors, episodes of 3 steps"""
+    INFO_COLUMNS = COLS
+
+    class _S:
+        class struct:
+            auto_reset = 0
+            episode_steps = 20
+    scene = _S()
+
+    def __init__(self, B):
+        from safemotionsrisk_amd.env import Box
+        self.num_envs, self.device = B, None
+        self.observation_space, self.action_space = Box(-1, 1, (23,)), Box(-1, 1, (7,))
+        self.k = torch.zeros(B)
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.k[:] = 0
+        else:
+            self.k[mask.bool()] = 0
+        return self.k.unsqueeze(1).repeat(1, 23) * 0.01
+
+    def step(self, action):
+        self.k += 1
+        done = self.k >= 3
+        vals = torch.zeros(self.num_envs, 8)
+        vals[:, 7] = self.k
+        vals[:, 2] = 0.5
+        info = {"values": vals, "termination_reason": torch.where(done, 2, -1).to(torch.int8)}
+        return self.k.unsqueeze(1).repeat(1, 23) * 0.01, torch.ones(self.num_envs), done, info
+
+
+def test_rllib_vector_interface_shapes_and_episode_end_info():
+    v = RllibVectorEnv(_FakeEnv(4))
+    obs = v.vector_reset()
+    assert len(obs) == 4 and obs[0].shape == (23,)
+    for step in range(3):
+        obs, rew, done, infos = v.vector_step(np.zeros((4, 7), np.float32))
+        assert len(obs) == len(rew) == len(done) == len(infos) == 4
+        assert set(infos[0]) >= {"average", "max", "min"} and infos[0]["average"]["minimum_distance_to_moving_obstacles"] == 0.5
+    assert all(done) and infos[1]["episode_length"] == 3 and infos[1]["trajectory_length"] == 21
+    assert infos[1]["termination_reason"] == 2 and infos[1]["trajectory_successful"] == 1.0
+    o = v.reset_at(2)
+    assert o.shape == (23,) and float(o[0]) == 0.0
+    with pytest.raises(ValueError):
+        e = _FakeEnv(2)
+        e.scene.struct.auto_reset = 1
+        try:
+            RllibVectorEnv(e)
+        finally:
+            e.scene.struct.auto_reset = 0
