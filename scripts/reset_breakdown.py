@@ -11,9 +11,13 @@ def run(name, **over):
     for _ in range(40): e.step(act)
     pr=e.get_profile(); e.close()
     print(name, {k:round(v['ms']/max(v['launches'],1),3) for k,v in pr.items()})
-run('baseline')
-run('kin_prob=1 (no walks)', collision_avoidance_kinematic_state_sampling_probability=1.0)
-run('kin_prob=0 (all walks)', collision_avoidance_kinematic_state_sampling_probability=0.0)
-run('stay=1 (walk ends at once)', collision_avoidance_kinematic_state_sampling_probability=0.0, collision_avoidance_stay_in_state_probability=1.0)
-run('no planets', planet_mode=False, terminate_on_collision_with_moving_obstacle=False)
-run('no planets, kin=1', planet_mode=False, terminate_on_collision_with_moving_obstacle=False, collision_avoidance_kinematic_state_sampling_probability=1.0)
+VARIANTS = {
+    'baseline': {},
+    'kin_prob=1 (no walks)': dict(collision_avoidance_kinematic_state_sampling_probability=1.0),
+    'kin_prob=0 (all walks)': dict(collision_avoidance_kinematic_state_sampling_probability=0.0),
+    'stay=1 (walk ends at once)': dict(collision_avoidance_kinematic_state_sampling_probability=0.0, collision_avoidance_stay_in_state_probability=1.0),
+    'no planets': dict(planet_mode=False, terminate_on_collision_with_moving_obstacle=False),
+    'no planets, kin=1': dict(planet_mode=False, terminate_on_collision_with_moving_obstacle=False, collision_avoidance_kinematic_state_sampling_probability=1.0),
+}
+for name in (sys.argv[1:] or list(VARIANTS)):
+    run(name, **VARIANTS[name])

@@ -547,3 +547,49 @@ def test_episode_metrics_on_the_gpu_env(built):
     moving = agg["collision_moving_obstacles_termination_rate"] / n
     assert 0.0 < moving < 1.0 and agg["collision_rate_moving_obstacles_max"] / n >= moving - 1e-6
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_ragged_batches_give_the_same_envs(built, auto_reset):
+    """Batch sizes that fill neither a wavefront nor a 256-lane block (1, 63, 257, 1000): env i is the same env in every batch
+    (Philox streams are keyed by the env index) through resets - bit for bit where its wavefront holds the same 64 envs,
+    to rounding where the last wavefront is partly empty (the cooperative root finder of the plan kernel places its
+    evaluation points by the number of open brackets in the wavefront); and the oracle agrees on the small one."""
+    import torch
+    from oracle.oracle import OracleEnv
+    T = 24
+    rng = np.random.default_rng(4)
+    acts = rng.uniform(-1, 1, (T, 1000, 7)).astype(np.float32)
+    outs = {}
+    for B in (1000, 257, 63, 1):
+        env = _env(B, seed=11, auto_reset=auto_reset)
+        rec = [env.reset().cpu().numpy().copy()]
+        for t in range(T):
+            obs, rew, done, info = env.step(torch.from_numpy(acts[t, :B]).cuda())
+            rec.append(np.concatenate([obs.cpu().numpy(), rew.cpu().numpy()[:, None], done.cpu().numpy()[:, None].astype(np.float32),
+                                       info["termination_reason"].cpu().numpy()[:, None].astype(np.float32), info["values"].cpu().numpy()], axis=1))
+            if not auto_reset and done.any():
+                env.reset(mask=done)
+        outs[B] = rec
+        env.close()
+    for B in (257, 63, 1):
+        full = (B // 64) * 64
+        assert np.array_equal(outs[B][0], outs[1000][0][:B])
+        close = []
+        for t in range(1, T + 1):
+            assert np.array_equal(outs[B][t][:full], outs[1000][t][:full]), (B, t)
+            close.append(np.abs(outs[B][t][full:] - outs[1000][t][full:B]).max(axis=1) < 1e-4)
+        assert np.mean(close) > 0.97, (B, np.mean(close))
+    assert sum(r[:, 24].sum() for r in outs[1000][1:]) > 900            # every env finished about once
+    ora = OracleEnv(_scene_of(auto_reset), 63, seed=11, num_threads=8)
+    o0 = ora.reset()
+    same = np.abs(o0 - outs[63][0]).max(axis=1) < 1e-4                  # start states: accept/reject ties aside
+    assert same.mean() > 0.95
+    o1, r1, d1, rs1, _ = ora.step(acts[0, :63].astype(np.float64))
+    assert (np.abs(o1[same] - outs[63][1][same, :23]) < 1e-4).mean() > 0.99
+
+
+def _scene_of(auto_reset):
+    from safemotionsrisk_amd import SPACE_ENV_CONFIG, build_scene
+    return build_scene(SPACE_ENV_CONFIG, auto_reset=auto_reset)
