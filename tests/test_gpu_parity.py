@@ -593,3 +593,52 @@ def test_ragged_batches_give_the_same_envs(built, auto_reset):
 def _scene_of(auto_reset):
     from safemotionsrisk_amd import SPACE_ENV_CONFIG, build_scene
     return build_scene(SPACE_ENV_CONFIG, auto_reset=auto_reset)
+
+
+PLANET_VARIANTS = {
+    "iss_only": dict(planet_two_center=None, planet_two_time_shift=None),
+    "asteroid_only": dict(planet_one_center=None),
+    "uncoupled": dict(planet_two_time_shift=None, planet_two_period=4.0),
+    "no_termination": dict(terminate_on_collision_with_moving_obstacle=False),
+    "pos_obs": dict(obs_planet_size_per_planet=3),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", sorted(PLANET_VARIANTS))
+def test_planet_scene_variants_against_oracle(built, variant):
+    """one planet (either), two uncoupled planets with different periods, planets that do not end the episode, planet
+    positions in the observation: 1024 envs x 8 steps with state injection, as the rollout test above."""
+    import torch
+    from oracle.oracle import OracleEnv
+    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
+    B, T = 1024, 8
+    cfg = dict(SPACE_ENV_CONFIG, **PLANET_VARIANTS[variant])
+    env = VecSafeMotionsEnv(B, device=0, seed=8, auto_reset=False, **cfg)
+    o0 = env.reset().cpu().numpy()
+    ora = OracleEnv(env.scene, B, seed=8, num_threads=16)
+    same = np.abs(ora.reset() - o0).max(axis=1) < 1e-4
+    assert same.mean() > 0.95
+    rng = np.random.default_rng(1)
+    mism, n_done = 0, 0
+    for t in range(T):
+        st = env.get_state()
+        ora.set_state(**{k: st[k] for k in STATE_KEYS})
+        act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        o_obs, o_rew, o_done, o_reason, o_info = ora.step(act.astype(np.float64))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        vals = info["values"].cpu().numpy()
+        bad = (done != o_done) | (info["termination_reason"].cpu().numpy() != o_reason)
+        tie = (np.abs(o_info[:, :3] - 0.001) < TIE).any(axis=1) | (np.abs(o_info[:, 2] - 0.02) < 10 * TIE)
+        mism += int((bad & ~tie).sum())
+        good = ~bad
+        assert np.abs(obs[good] - o_obs[good]).max() < 2e-5 and np.abs(rew[good] - o_rew[good]).max() < 5e-5
+        ok = good & ~tie
+        assert np.abs(vals[ok, :3] - o_info[ok, :3]).max() < 5e-6
+        n_done += int(o_done.sum())
+        if done.any():
+            env.reset(mask=torch.from_numpy(done).cuda())
+    assert mism <= 4, "%d unexplained mismatches" % mism
+    assert n_done > (0 if variant == "no_termination" else 20)
+    env.close()
