@@ -6,7 +6,7 @@ import sys, time; sys.path.insert(0, ".")
 import torch
 from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG, BALL_ENV_CONFIG, REACH_ENV_CONFIG
 cfg = {"space": SPACE_ENV_CONFIG, "bm": dict(SPACE_ENV_CONFIG, ball_machine_mode=True), "ball": BALL_ENV_CONFIG, "reach": REACH_ENV_CONFIG}[sys.argv[1]]
-B = 65536
+B = int(__import__('os').environ.get('SMR_BENCH_B', 65536))
 e = VecSafeMotionsEnv(B, seed=0, auto_reset=True, return_info=False, **cfg)
 e.reset(); act = torch.rand((B, 7), device="cuda") * 2 - 1
 for _ in range(10): e.step(act)
