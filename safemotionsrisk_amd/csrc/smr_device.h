@@ -518,16 +518,16 @@ __device__ __forceinline__ int climb_start_cell(F3 d) {
 
 template <class FP, class UP, class BP>
 struct ClimbHull {
-    FP v;        // vertices of the piece, 4 floats each
-    UP span;     // per vertex
+    FP v;        // vertices of the piece, 4 floats each: x, y, z and - as bits - the vertex's span into ids4 (first group |
+                 // groups << 16): it arrives with the coordinates, one dependent read less per step of the climb
     UP ids4;     // the piece's id groups
     BP start;    // the piece's start map
     __device__ __forceinline__ F3 support(F3 dl, int &cur, bool first) const {
         if (first) cur = (int)start[climb_start_cell(dl)];
         F3 pv = {v[4 * cur], v[4 * cur + 1], v[4 * cur + 2]};
+        uint32_t sp = (uint32_t)__float_as_int(v[4 * cur + 3]);
         float best = fmaf(pv.z, dl.z, fmaf(pv.y, dl.y, pv.x * dl.x));
         for (int guard = 0; guard < 256; ++guard) {
-            const uint32_t sp = span[cur];
             const int g0 = (int)(sp & 0xffffu), g1 = g0 + (int)(sp >> 16);
             int nb = cur;
             for (int g = g0; g < g1; ++g) {
@@ -536,8 +536,9 @@ struct ClimbHull {
                 for (int k = 0; k < 4; ++k) {
                     const int id = (int)((four >> (8 * k)) & 255u);
                     const F3 q = {v[4 * id], v[4 * id + 1], v[4 * id + 2]};
+                    const float qw = v[4 * id + 3];
                     const float sq = fmaf(q.z, dl.z, fmaf(q.y, dl.y, q.x * dl.x));
-                    if (sq > best) { best = sq; nb = id; pv = q; }
+                    if (sq > best) { best = sq; nb = id; pv = q; sp = (uint32_t)__float_as_int(qw); }
                 }
             }
             if (nb == cur) break;
@@ -580,7 +581,7 @@ __device__ __forceinline__ DPiece load_piece_lane(const DPiece *pieces, int idx)
 
 // the link hull of piece index pi (already loaded as P) read from the global tables
 __device__ __forceinline__ GlobalHull global_hull(const DScene &S, int pi, const DPiece &P) {
-    return GlobalHull{(const SMR_GLOBAL float *)S.verts + 4 * (size_t)P.begin, (const SMR_GLOBAL uint32_t *)S.span + P.begin,
+    return GlobalHull{(const SMR_GLOBAL float *)S.verts + 4 * (size_t)P.begin,
                       (const SMR_GLOBAL uint32_t *)S.ids4 + P.ids_begin, (const SMR_GLOBAL uint8_t *)S.start + kStartCells * (size_t)pi};
 }
 

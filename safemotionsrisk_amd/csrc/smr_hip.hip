@@ -65,7 +65,6 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                              : S.n_bodies - 1 - ((int)blockIdx.z - n_pair_blocks);
     // the hull, edge graph and start map staged in LDS: every support call of this block climbs over them
     __shared__ float lds_v[4 * kMaxPieceVerts];
-    __shared__ uint32_t lds_span[kMaxPieceVerts];
     __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
     __shared__ uint32_t lds_start[kStartCells / 4];
     __shared__ float lds_pv[AUTO ? 4 * kMaxPlanetVerts : 4];
@@ -75,19 +74,18 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     const DPiece LP = load_piece(S.pieces, pl);
     {
         const SMR_GLOBAL float4 *gv = (const SMR_GLOBAL float4 *)S.verts + LP.begin;
-        const SMR_GLOBAL uint32_t *gs = (const SMR_GLOBAL uint32_t *)S.span + LP.begin, *gi = (const SMR_GLOBAL uint32_t *)S.ids4 + LP.ids_begin,
+        const SMR_GLOBAL uint32_t *gi = (const SMR_GLOBAL uint32_t *)S.ids4 + LP.ids_begin,
                                   *gm = (const SMR_GLOBAL uint32_t *)S.start + (kStartCells / 4) * (size_t)pl;
         for (int i = threadIdx.x; i < LP.count; i += kBlock) {
             const SMR_GLOBAL float *f = (const SMR_GLOBAL float *)(gv + i);
-            lds_v[4 * i] = f[0]; lds_v[4 * i + 1] = f[1]; lds_v[4 * i + 2] = f[2]; lds_v[4 * i + 3] = 0.f;
-            lds_span[i] = gs[i];
+            lds_v[4 * i] = f[0]; lds_v[4 * i + 1] = f[1]; lds_v[4 * i + 2] = f[2]; lds_v[4 * i + 3] = f[3];
         }
         for (int i = threadIdx.x; i < LP.ids_count; i += kBlock) lds_ids[i] = gi[i];
         if (threadIdx.x < kStartCells / 4) lds_start[threadIdx.x] = gm[threadIdx.x];
         if (AUTO && !pair_block) stage_planets(S, threadIdx.x, kBlock, lds_pv, lds_pd);
     }
     __syncthreads();
-    const LocalHull hull{lds_v, lds_span, lds_ids, (const uint8_t *)lds_start};
+    const LocalHull hull{lds_v, lds_ids, (const uint8_t *)lds_start};
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
     const int B = S.B, N = S.checks_per_step;

@@ -175,6 +175,7 @@ inline const char *build_host_geometry(const smr_scene_t &s, HostGeometry &G) {
                 G.ids4.push_back(word);
             }
             G.span.push_back((uint32_t)first | ((uint32_t)groups << 16));
+            std::memcpy(&G.verts[(size_t)q.begin + k].w, &G.span.back(), 4);        // the climb reads it with the coordinates
         }
         q.ids_count = (int)G.ids4.size() - q.ids_begin;
         // start map: exhaustive support of the cell-centre directions
