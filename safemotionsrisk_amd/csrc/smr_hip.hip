@@ -63,6 +63,19 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     // piece is then the scanned A side; with the base adapter as partner the piece itself is staged)
     const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0])
                              : S.n_bodies - 1 - ((int)blockIdx.z - n_pair_blocks);
+    if (!pair_block) {                                   // nothing to do for this (sample, body): leave before anything is staged
+        const bool fin = (int)blockIdx.y == 0;
+        const bool any = (fin && (((S.static_mask | S.moving_mask) >> l) & 1u)) || ((S.contact_mask >> l) & 1u) || (fin && SELF);
+        if (!any) {
+            if (fin) {                                   // finish reads these
+                const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+                if (e0 < S.B) { st.dist[(size_t)l * S.B + e0] = S.static_max; st.dist[(size_t)(S.n_bodies + l) * S.B + e0] = S.moving_max + 0.002f; }
+            }
+            const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+            if (e0 < S.B) st.res[((size_t)(S.checks_per_step - (int)blockIdx.y - 1) * S.n_bodies + l) * S.B + e0] = 0.f;
+            return;
+        }
+    }
     // the hull, edge graph and start map staged in LDS: every support call of this block climbs over them
     __shared__ float lds_v[4 * kMaxPieceVerts];
     __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
@@ -1051,7 +1064,7 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     d.n_static = s.n_static;
     for (int i = 0; i < s.n_static; ++i) { if (!piece_ok(s.static_piece[i])) { env->err = "bad static_piece"; return SMR_E_INVALID; } d.static_piece[i] = s.static_piece[i]; }
     d.static_mask = s.static_link_mask; d.static_max = (float)s.static_max_distance;
-    d.moving_mask = s.moving_link_mask; d.contact_mask = s.contact_link_mask;
+    d.moving_mask = s.moving_link_mask; d.contact_mask = reachable_contact_mask(s);
     d.moving_max = (float)s.moving_max_distance; d.contact_dist = (float)s.contact_distance;
     if (s.n_planets < 0 || s.n_planets > SMR_MAX_PLANETS) { env->err = "bad n_planets"; return SMR_E_INVALID; }
     d.n_planets = s.n_planets; d.obs_planet_size = s.obs_planet_size_per_planet; d.obs_num_planets = s.obs_num_planets;

@@ -224,6 +224,67 @@ inline const char *scene_bodies(const smr_scene_t &s, DScene &d) {
     return nullptr;
 }
 
+// Links that can NEVER come within contact distance of a planet are dropped from the contact queries (their blocks of the
+// step kernel would stage their tables, run FK and find nothing, at every sample).  Conservative test per chain link l:
+// when the axes of all joints before it pass through its frame origin c (iiwa: links 0, 1, 2 - the shoulder), every point
+// of the link keeps its distance from c whatever the joints do, so the link stays inside the ball (c, max |v - c| + margin);
+// the link is dropped when that ball stays clear of every planet piece's bounding sphere at every orbit index.
+inline uint32_t reachable_contact_mask(const smr_scene_t &s) {
+    uint32_t mask = s.contact_link_mask;
+    if (s.use_ball || s.n_planets <= 0) return mask;
+    double o[SMR_NLINK][3];
+    for (int c = 0; c < 3; ++c) o[0][c] = s.base_xyz[c];
+    for (int k = 0; k + 1 < SMR_NLINK; ++k)
+        for (int c = 0; c < 3; ++c) o[k + 1][c] = o[k][c] + s.joint_xyz[k][c];       // link frames at q = 0 (fk_advance)
+    for (int l = 0; l < SMR_NLINK && l < s.n_bodies; ++l) {
+        if (!((mask >> l) & 1u)) continue;
+        bool fixed_centre = true;
+        for (int k = 0; k + 1 < l; ++k) {                   // joint k turns about joint_axis[k] through o[k + 1]
+            const double d[3] = {o[l][0] - o[k + 1][0], o[l][1] - o[k + 1][1], o[l][2] - o[k + 1][2]};
+            const double *a = s.joint_axis[k];
+            const double cx = d[1] * a[2] - d[2] * a[1], cy = d[2] * a[0] - d[0] * a[2], cz = d[0] * a[1] - d[1] * a[0];
+            if (std::sqrt(cx * cx + cy * cy + cz * cz) > 1e-9) fixed_centre = false;
+        }
+        if (!fixed_centre) continue;
+        const smr_piece_t &lp = s.pieces[s.link_piece[l]];
+        double rl = 0;
+        for (int k = 0; k < lp.vert_count; ++k) {
+            const double *v = s.verts + 3 * (size_t)(lp.vert_begin + k);
+            rl = std::max(rl, std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+        }
+        rl += lp.margin;
+        bool reach = false;
+        for (int p = 0; p < s.n_planets && !reach; ++p) {
+            const smr_planet_t &pl = s.planet[p];
+            for (int c = 0; c < pl.piece_count && !reach; ++c) {
+                const smr_piece_t &pp = s.pieces[pl.piece_begin + c];
+                double rp = 0;
+                for (int k = 0; k < pp.vert_count; ++k) {
+                    const double *v = s.verts + 3 * (size_t)(pp.vert_begin + k);
+                    const double dx = v[0] - pp.center[0], dy = v[1] - pp.center[1], dz = v[2] - pp.center[2];
+                    rp = std::max(rp, std::sqrt(dx * dx + dy * dy + dz * dz));
+                }
+                rp += pp.margin;
+                for (int i = 0; i < pl.n_orbit && !reach; ++i) {
+                    const double *row = pl.orbit_pose + 7 * (size_t)i;
+                    const double x = row[3], y = row[4], z = row[5], w = row[6], *m = pp.center;
+                    const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+                    double dd = 0;
+                    for (int r = 0; r < 3; ++r) {
+                        const double cw = R[3 * r] * m[0] + R[3 * r + 1] * m[1] + R[3 * r + 2] * m[2] + row[r] - o[l][r];
+                        dd += cw * cw;
+                    }
+                    if (std::sqrt(dd) - rp - rl <= s.contact_distance + 1e-3) reach = true;
+                }
+            }
+        }
+        if (!reach) mask &= ~(1u << l);
+    }
+    return mask;
+}
+
 // Tables of the lane-autonomous planet queries (planet_queries_auto in smr_device.h), when the planets fit their budget:
 // the pieces' vertex lists padded to multiples of 4 (copies of the last vertex: the scan needs no bounds test) and
 // one descriptor per piece.  d.auto_verts / d.auto_desc are left to the caller (device copies of G.auto_verts / G.auto_desc).

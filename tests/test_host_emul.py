@@ -90,6 +90,28 @@ def test_lane_autonomous_planet_queries_equal_lockstep(emul, space_scene):
     assert worst < 2e-6 and hits > 10
 
 
+def test_links_dropped_from_the_contact_queries_never_reach_a_planet(emul, space_scene, ball_scene):
+    """reachable_contact_mask (smr_tables.h) drops iiwa_link_0..2 in the space scene - the shoulder never gets within the
+    contact distance of a planet - and nothing in a ball scene; brute force over random poses and orbit phases agrees."""
+    H = C.c_void_p(emul.emul_scene_create(C.cast(space_scene.pointer(), C.c_void_p)))
+    mask = emul.emul_contact_mask(H)
+    assert mask == 0b11111000
+    Hb = C.c_void_p(emul.emul_scene_create(C.cast(ball_scene.pointer(), C.c_void_p)))
+    assert emul.emul_contact_mask(Hb) == ball_scene.struct.contact_link_mask
+    s = space_scene.struct
+    ora = O.OracleEnv(space_scene, 1)
+    rng = np.random.default_rng(5)
+    closest = np.inf
+    for _ in range(80):
+        q = rng.uniform(np.array(s.pos_lo), np.array(s.pos_hi))
+        i0 = int(rng.integers(1200))
+        for link in range(3):
+            for p, n in ((0, s.planet[0].piece_count), (1, s.planet[1].piece_count)):
+                for c in range(n):
+                    closest = min(closest, ora.link_planet_piece_distance(q, link, p, c, i0 if p == 0 else (i0 - 480) % 1200))
+    assert closest > 0.05
+
+
 def test_device_distances_with_ball_machine_on_host(emul, bm_scene):
     """robot_ball_machine.urdf: the two convex pieces mounted on iiwa_link_7 take part in the table / planet queries and
     pair with the base adapter's cylinder and iiwa_link_0..5 for the self-collision distance (A7 self)."""
