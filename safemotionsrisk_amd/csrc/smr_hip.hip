@@ -1063,7 +1063,7 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     if (s.n_static < 0 || s.n_static > SMR_MAX_STATIC) { env->err = "bad n_static"; return SMR_E_INVALID; }
     d.n_static = s.n_static;
     for (int i = 0; i < s.n_static; ++i) { if (!piece_ok(s.static_piece[i])) { env->err = "bad static_piece"; return SMR_E_INVALID; } d.static_piece[i] = s.static_piece[i]; }
-    d.static_mask = s.static_link_mask; d.static_max = (float)s.static_max_distance;
+    d.static_mask = reachable_static_mask(s); d.static_max = (float)s.static_max_distance;
     d.moving_mask = s.moving_link_mask; d.contact_mask = reachable_contact_mask(s);
     d.moving_max = (float)s.moving_max_distance; d.contact_dist = (float)s.contact_distance;
     if (s.n_planets < 0 || s.n_planets > SMR_MAX_PLANETS) { env->err = "bad n_planets"; return SMR_E_INVALID; }

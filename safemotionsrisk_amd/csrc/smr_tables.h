@@ -285,6 +285,51 @@ inline uint32_t reachable_contact_mask(const smr_scene_t &s) {
     return mask;
 }
 
+// ... and the same for the static pieces (the table): a link whose ball (c, r) stays farther from every static piece's
+// bounding box than the largest distance the queries report leaves the static queries (iiwa_link_2: the shoulder is 0.36 m up).
+inline uint32_t reachable_static_mask(const smr_scene_t &s) {
+    uint32_t mask = s.static_link_mask;
+    double o[SMR_NLINK][3];
+    for (int c = 0; c < 3; ++c) o[0][c] = s.base_xyz[c];
+    for (int k = 0; k + 1 < SMR_NLINK; ++k)
+        for (int c = 0; c < 3; ++c) o[k + 1][c] = o[k][c] + s.joint_xyz[k][c];
+    for (int l = 0; l < SMR_NLINK && l < s.n_bodies; ++l) {
+        if (!((mask >> l) & 1u)) continue;
+        bool fixed_centre = true;
+        for (int k = 0; k + 1 < l; ++k) {
+            const double d[3] = {o[l][0] - o[k + 1][0], o[l][1] - o[k + 1][1], o[l][2] - o[k + 1][2]};
+            const double *a = s.joint_axis[k];
+            const double cx = d[1] * a[2] - d[2] * a[1], cy = d[2] * a[0] - d[0] * a[2], cz = d[0] * a[1] - d[1] * a[0];
+            if (std::sqrt(cx * cx + cy * cy + cz * cz) > 1e-9) fixed_centre = false;
+        }
+        if (!fixed_centre) continue;
+        const smr_piece_t &lp = s.pieces[s.link_piece[l]];
+        double rl = 0;
+        for (int k = 0; k < lp.vert_count; ++k) {
+            const double *v = s.verts + 3 * (size_t)(lp.vert_begin + k);
+            rl = std::max(rl, std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));
+        }
+        rl += lp.margin;
+        bool reach = false;
+        for (int i = 0; i < s.n_static && !reach; ++i) {
+            const smr_piece_t &pp = s.pieces[s.static_piece[i]];
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            if (pp.kind == SMR_PIECE_HULL && pp.vert_count > 0) {
+                for (int k = 0; k < pp.vert_count; ++k)
+                    for (int c = 0; c < 3; ++c) { const double x = s.verts[3 * (size_t)(pp.vert_begin + k) + c]; lo[c] = std::min(lo[c], x); hi[c] = std::max(hi[c], x); }
+            } else { reach = true; break; }              // no cheap box for other kinds: keep the link
+            double dd = 0;
+            for (int c = 0; c < 3; ++c) { const double e = std::max(std::max(lo[c] - o[l][c], o[l][c] - hi[c]), 0.0); dd += e * e; }
+            // the largest distance any static query asks about: the reported range, and the clearances of start states / targets
+            const double ask = std::max(std::max(s.static_max_distance, s.start_min_dist_static),
+                                        std::max(s.use_ball ? s.ball_target_min_dist_static : 0.0, s.use_target_points ? s.target_min_dist_static : 0.0)) + 0.006;
+            if (std::sqrt(dd) - rl - pp.margin <= ask) reach = true;
+        }
+        if (!reach) mask &= ~(1u << l);
+    }
+    return mask;
+}
+
 // Tables of the lane-autonomous planet queries (planet_queries_auto in smr_device.h), when the planets fit their budget:
 // the pieces' vertex lists padded to multiples of 4 (copies of the last vertex: the scan needs no bounds test) and
 // one descriptor per piece.  d.auto_verts / d.auto_desc are left to the caller (device copies of G.auto_verts / G.auto_desc).

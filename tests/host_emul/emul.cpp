@@ -85,7 +85,7 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
     d.verts = H->G.verts.data(); d.pieces = H->G.pieces.data(); d.span = H->G.span.data(); d.ids4 = H->G.ids4.data(); d.start = H->G.start.data();
     if (const char *msg = scene_bodies(s, d)) { std::fprintf(stderr, "emul_scene_create: %s\n", msg); delete H; return nullptr; }
     d.n_static = s.n_static; for (int i = 0; i < s.n_static; ++i) d.static_piece[i] = s.static_piece[i];
-    d.static_mask = s.static_link_mask; d.static_max = (float)s.static_max_distance; d.moving_mask = s.moving_link_mask; d.contact_mask = reachable_contact_mask(s);
+    d.static_mask = reachable_static_mask(s); d.static_max = (float)s.static_max_distance; d.moving_mask = s.moving_link_mask; d.contact_mask = reachable_contact_mask(s);
     d.moving_max = (float)s.moving_max_distance; d.contact_dist = (float)s.contact_distance; d.n_planets = s.n_planets;
     for (int p = 0; p < s.n_planets; ++p) {
         const smr_planet_t &pl = s.planet[p];
@@ -123,6 +123,7 @@ extern "C" void emul_support_check(void *h, int pi, const float *dir, int warm_s
     out[0] = dot(a, d); out[1] = dot(b, d); out[2] = (float)hint;
 }
 extern "C" unsigned emul_contact_mask(void *h) { return ((HostScene *)h)->d.contact_mask; }
+extern "C" unsigned emul_static_mask(void *h) { return ((HostScene *)h)->d.static_mask; }
 extern "C" int emul_piece_count(void *h, int pi) { return ((HostScene *)h)->d.pieces[pi].count; }
 extern "C" int emul_piece_kind(void *h, int pi) { return ((HostScene *)h)->d.pieces[pi].kind; }
 

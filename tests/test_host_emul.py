@@ -96,6 +96,7 @@ def test_links_dropped_from_the_contact_queries_never_reach_a_planet(emul, space
     H = C.c_void_p(emul.emul_scene_create(C.cast(space_scene.pointer(), C.c_void_p)))
     mask = emul.emul_contact_mask(H)
     assert mask == 0b11111000
+    assert emul.emul_static_mask(H) == 0b11111000 and space_scene.struct.static_link_mask == 0b11111100    # iiwa_link_2 stays 0.16 m up
     Hb = C.c_void_p(emul.emul_scene_create(C.cast(ball_scene.pointer(), C.c_void_p)))
     assert emul.emul_contact_mask(Hb) == ball_scene.struct.contact_link_mask
     s = space_scene.struct
