@@ -145,7 +145,8 @@ struct DState {
     int *next_hit;                     // [B]
     unsigned *staged_tag;              // [B]  reset_count value the staged state belongs to (~0u: none)
     int *refill_list;                  // [B]  envs whose staged state was consumed
-    int *refill_count;                 // [1]
+    int *refill_count;                 // the counter of THIS step's list: two slots alternate, finish clears the other one
+    int *refill_zero;                  // ... (refill_zero, or null) so that no memset sits between the step's kernels
     int *stale_commits;                // [1]  commits that found no matching staged state (must stay 0)
 };
 

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
                                                      int8_t *__restrict__ reason, float *__restrict__ info, int staged) {
     const DScene &S = *Sp;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e == 0 && st.refill_zero) *st.refill_zero = 0;                        // the list counter of the NEXT step
     if (e >= S.B) return;
     const int B = S.B, N = S.checks_per_step;
     const int steps = st.step_count[e] + 1;                                   // base.py:1044
@@ -988,6 +989,8 @@ struct smr_env {
     hipStream_t side = nullptr;
     hipEvent_t ev_commit = nullptr, ev_refill = nullptr;
     DScene hscene;              // host copy (device pointers inside)
+    int *refill_slots = nullptr; // two list counters: step s uses slot s & 1, its finish kernel clears the other
+    int parity = 0;
     DScene *dscene = nullptr;
     DState st;
     std::vector<void *> allocs;
@@ -1218,10 +1221,11 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     if (env->staged) {
         if ((rc = dev_alloc(env, &st.next_q, 7 * B)) || (rc = dev_alloc(env, &st.next_v, 7 * B)) || (rc = dev_alloc(env, &st.next_a, 7 * B)) ||
             (rc = dev_alloc(env, &st.next_planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.next_hit, B)) || (rc = dev_alloc(env, &st.staged_tag, B)) ||
-            (rc = dev_alloc(env, &st.refill_list, B)) || (rc = dev_alloc(env, &st.refill_count, 1)) || (rc = dev_alloc(env, &st.stale_commits, 1)))
+            (rc = dev_alloc(env, &st.refill_list, B)) || (rc = dev_alloc(env, &env->refill_slots, 2)) || (rc = dev_alloc(env, &st.stale_commits, 1)))
             return fail(rc);
-        if (hipMemset(st.staged_tag, 0xFF, B * 4) || hipMemset(st.refill_count, 0, 4) || hipMemset(st.stale_commits, 0, 4) ||
+        if (hipMemset(st.staged_tag, 0xFF, B * 4) || hipMemset(env->refill_slots, 0, 8) || hipMemset(st.stale_commits, 0, 4) ||
             hipMemset(st.next_planet_idx, 0, 2 * B * 4) || hipMemset(st.next_hit, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+        st.refill_count = env->refill_slots; st.refill_zero = nullptr;
         if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_commit, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&env->ev_refill, hipEventDisableTiming) != hipSuccess) { env->err = "could not create the side stream"; return fail(SMR_E_HIP); }
         if (hipEventRecord(env->ev_refill, env->side) != hipSuccess) { env->err = "hipEventRecord failed"; return fail(SMR_E_HIP); }
@@ -1374,6 +1378,8 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     const int B = env->B;
     int rc;
     if (env->staged) {
+        // list counter: the slot the NEXT step does not use (that step's finish kernel clears it again, after this refill)
+        env->st.refill_count = env->refill_slots + (1 - env->parity); env->st.refill_zero = nullptr;
         if (!mask_dev) {
             // every env: prepare for the current tags, commit, and refill all in the background
             if ((rc = staged_prepare_all(env))) return rc;
@@ -1431,7 +1437,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !reason_dev) { env->err = "smr_step: NULL buffer"; return SMR_E_INVALID; }
     SMR_HIP(hipSetDevice(env->device));
     const int B = env->B;
-    if (env->auto_reset) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));
+    if (env->auto_reset && !(env->staged && env->auto_reset)) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));   // staged: unused
     if (env->hscene.use_ball) SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
     if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
     {
@@ -1454,8 +1460,10 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (staged) {
         int rc = staged_wait_refill(env);
         if (rc) return rc;
-        SMR_HIP(hipMemsetAsync(env->st.refill_count, 0, sizeof(int), env->stream));
-    }
+        env->st.refill_count = env->refill_slots + env->parity;             // cleared by the previous step's finish kernel
+        env->st.refill_zero = env->refill_slots + (1 - env->parity);
+        env->parity ^= 1;
+    } else env->st.refill_zero = nullptr;
     {
         LaunchTimer t(env, SMR_K_FINISH);
         hipLaunchKernelGGL(finish_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, obs_dev,
