@@ -53,18 +53,20 @@ template <bool SELF, bool AUTO>
 __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = AUTO ? 256 : 64;
-    // grid z: first the self-collision pairs (SELF; they only work at the end-of-step sample), then the bodies, outer ones
+    // grid (env block, body, sample), the sample slowest: ALL end-of-step blocks - the long ones - are dispatched before the
+    // contact-only samples, which then fill the machine while the last heavy wavefronts finish.
+    // grid y: first the self-collision pairs (SELF; they only work at the end-of-step sample), then the bodies, outer ones
     // (most planet work) first
     const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
-    const bool pair_block = SELF && (int)blockIdx.z < n_pair_blocks;
-    const int pair = pair_block ? (int)blockIdx.z : 0;
-    if (pair_block && blockIdx.y != 0) return;
+    const bool pair_block = SELF && (int)blockIdx.y < n_pair_blocks;
+    const int pair = pair_block ? (int)blockIdx.y : 0;
+    if (pair_block && blockIdx.z != 0) return;
     // the body whose hull this block climbs over: its own body, or for a pair block the partner link (the ball machine
     // piece is then the scanned A side; with the base adapter as partner the piece itself is staged)
     const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0])
-                             : S.n_bodies - 1 - ((int)blockIdx.z - n_pair_blocks);
+                             : S.n_bodies - 1 - ((int)blockIdx.y - n_pair_blocks);
     if (!pair_block) {                                   // nothing to do for this (sample, body): leave before anything is staged
-        const bool fin = (int)blockIdx.y == 0;
+        const bool fin = (int)blockIdx.z == 0;
         const bool any = (fin && (((S.static_mask | S.moving_mask) >> l) & 1u)) || ((S.contact_mask >> l) & 1u) || (fin && SELF);
         if (!any) {
             if (fin) {                                   // finish reads these
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                 if (e0 < S.B) { st.dist[(size_t)l * S.B + e0] = S.static_max; st.dist[(size_t)(S.n_bodies + l) * S.B + e0] = S.moving_max + 0.002f; }
             }
             const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
-            if (e0 < S.B) st.res[((size_t)(S.checks_per_step - (int)blockIdx.y - 1) * S.n_bodies + l) * S.B + e0] = 0.f;
+            if (e0 < S.B) st.res[((size_t)(S.checks_per_step - (int)blockIdx.z - 1) * S.n_bodies + l) * S.B + e0] = 0.f;
             return;
         }
     }
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
         st.dist[(size_t)(2 * NB + pair) * B + e] = d <= S.static_max ? d : S.static_max;
         return;
     }
-    const int k = N - (int)blockIdx.y;                 // sample k of N, t_k = k dt / N; the end-of-step sample (distances) first
+    const int k = N - (int)blockIdx.z;                 // sample k of N, t_k = k dt / N; the end-of-step sample (distances) first
     const bool final_sample = (k == N);
     const int upd = S.updates_per_step / N;
     float *res = st.res + ((size_t)(k - 1) * NB + l) * B;
@@ -1449,7 +1451,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         LaunchTimer t(env, SMR_K_COLLIDE);
         const bool self = env->hscene.n_self_pairs > 0, autop = env->hscene.planets_auto != 0;
         const int block = autop ? 256 : 64;
-        const dim3 grid((B + block - 1) / block, env->N, env->hscene.n_bodies + env->hscene.n_self_pairs);
+        const dim3 grid((B + block - 1) / block, env->hscene.n_bodies + env->hscene.n_self_pairs, env->N);
         if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
