@@ -91,6 +91,7 @@ struct DScene {
     // all planet pieces [planet_p0, +planet_pn) and their vertex slots [planet_v0, +planet_vn): what the step kernel stages
     // in LDS for the lane-autonomous planet queries (planets_auto = 0: does not fit, wave-lockstep queries)
     int planets_auto, planet_p0, planet_pn, planet_vn;   // planet_vn: vertex slots of auto_verts (4 floats each)
+    int body_order[SMR_MAX_BODIES];   // dispatch order of the bodies in the collide grid (longest-running first)
     const float *auto_verts;   // the planet pieces' vertices, every piece padded to a multiple of 4 with its last vertex
     const float *auto_desc;    // kPlanetDescDwords per piece: first slot, padded count, margin, planet (0 / 1), centre xyz
     float planet_obs_min[3], planet_obs_max[3];
