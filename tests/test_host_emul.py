@@ -103,7 +103,7 @@ def test_links_dropped_from_the_contact_queries_never_reach_a_planet(emul, space
     ora = O.OracleEnv(space_scene, 1)
     rng = np.random.default_rng(5)
     closest = np.inf
-    for _ in range(80):
+    for _ in range(25):
         q = rng.uniform(np.array(s.pos_lo), np.array(s.pos_hi))
         i0 = int(rng.integers(1200))
         for link in range(3):
