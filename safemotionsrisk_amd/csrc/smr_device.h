@@ -233,7 +233,13 @@ __device__ __forceinline__ float interp_vel(float v0, float a0, float a1, float 
 // profile; see DESIGN.md "safe acceleration range".  Accelerations are piecewise linear with knots
 // every dt, |a| <= A, knot-to-knot change <= D = J dt.
 // ---------------------------------------------------------------------------------------------
-struct JointLim { float plo, phi, V, A, J, dt, plo_res, phi_res, V_res; };   // *_res: float64 limit - float32 image
+struct JointLim {
+    float plo, phi, V, A, J, dt, plo_res, phi_res, V_res;   // *_res: float64 limit - float32 image
+    // 1 / dt and 1 / J for the inner loops of the range computation (an IEEE division is ten instructions; the braking profiles
+    // below run seven of them per knot otherwise)
+    float idt, iJ;
+    __device__ __forceinline__ void derive() { idt = 1.0f / dt; iJ = 1.0f / J; }
+};
 
 constexpr float kNoBound = 3.0e38f;
 
@@ -249,21 +255,39 @@ __device__ __forceinline__ float vel_upper_a1max(float v0, float a0, float V, fl
     const float head = (V - v0) + (tol + L.V_res);
     const float c = head - 0.5f * a0 * dt;
     if (c >= 0.f) {
-        float x = L.J * (-0.5f * dt + sqrtf(0.25f * dt * dt + 2.0f * c / L.J));
+        float x = L.J * (-0.5f * dt + sqrtf(0.25f * dt * dt + 2.0f * c * L.iJ));
         if (D > L.A) {
-            float K = 2.0f * c / dt;
+            float K = 2.0f * c * L.idt;
             float xa = ((K - L.A) + sqrtf((L.A - K) * (L.A - K) + 8.0f * K * L.A)) * 0.25f;
             if (xa < D - L.A) x = xa;
         }
         return x;
     }
-    if (a0 > 0.f && head > 0.f) return a0 - a0 * a0 * dt / (2.0f * head);
+    if (a0 > 0.f && head > 0.f) return a0 - a0 * a0 * dt * (0.5f * __builtin_amdgcn_rcpf(head));
     return -kNoBound;
 }
 
 // displacement of the constant-jerk segment after time t (interp_pos without the start position)
 __device__ __forceinline__ float seg_disp(float v0, float a0, float a1, float t, float dt) {
     return v0 * t + 0.5f * a0 * t * t + (1.0f / 6.0f) * ((a1 - a0) / dt) * t * t * t;
+}
+
+// the same with 1 / dt given, for the knot loops
+__device__ __forceinline__ float seg_disp_i(float v0, float a0, float a1, float t, float idt) {
+    return v0 * t + 0.5f * a0 * t * t + (1.0f / 6.0f) * ((a1 - a0) * idt) * t * t * t;
+}
+__device__ __forceinline__ float seg_dmax_i(float v0, float a0, float a1, float dt, float idt) {
+    float m = seg_disp_i(v0, a0, a1, dt, idt);
+    float j = (a1 - a0) * idt;
+    float disc = a0 * a0 - 2.0f * j * v0;
+    if (disc >= 0.f) {
+        float sq = sqrtf(disc);
+        float qq = -(a0 + (a0 >= 0.f ? sq : -sq));
+        float r0 = qq * __builtin_amdgcn_rcpf(j), r1 = 2.0f * v0 * __builtin_amdgcn_rcpf(qq);   // inf/nan when a divisor is 0: rejected below
+        if (r0 > 0.f && r0 < dt) m = fmaxf(m, seg_disp_i(v0, a0, a1, r0, idt));
+        if (r1 > 0.f && r1 < dt) m = fmaxf(m, seg_disp_i(v0, a0, a1, r1, idt));
+    }
+    return m;
 }
 
 // largest displacement reached inside (0, dt] of a segment
@@ -287,8 +311,8 @@ __device__ __forceinline__ float seg_dmax(float v0, float a0, float a1, float dt
 // few-micrometre margins that decide the bound near a limit.  Continuous and decreasing in a1.
 __device__ inline float pos_margin(float gap, float v0, float a0, float a1, float Vtol, const JointLim &L) {
     SMR_CNT(0);
-    float dmax = seg_dmax(v0, a0, a1, L.dt);
-    float d = seg_disp(v0, a0, a1, L.dt, L.dt);
+    float dmax = seg_dmax_i(v0, a0, a1, L.dt, L.idt);
+    float d = seg_disp_i(v0, a0, a1, L.dt, L.idt);
     float v = v0 + 0.5f * (a0 + a1) * L.dt, a = a1;
     const float D = L.J * L.dt;
     for (int it = 0; it < 4096; ++it) {
@@ -297,8 +321,8 @@ __device__ inline float pos_margin(float gap, float v0, float a0, float a1, floa
         if (dmax > gap + 1.0f) break;                           // hopeless (also bounds the loop for absurd inputs)
         float floor_v = -vel_upper_a1max(-v, -a, L.V, Vtol, L);
         float an = fmaxf(fmaxf(a - D, -L.A), fminf(floor_v, fminf(a + D, L.A)));
-        dmax = fmaxf(dmax, d + seg_dmax(v, a, an, L.dt));
-        d += seg_disp(v, a, an, L.dt, L.dt);
+        dmax = fmaxf(dmax, d + seg_dmax_i(v, a, an, L.dt, L.idt));
+        d += seg_disp_i(v, a, an, L.dt, L.idt);
         v += 0.5f * (a + an) * L.dt;
         a = an;
     }
@@ -340,6 +364,7 @@ __device__ inline float coop_pos_upper_end(bool need, float gap, float v, float 
     float tlo = __shfl(lo, owner), thi = __shfl(hi, owner);
     JointLim TL = L;
     TL.V = __shfl(L.V, owner); TL.A = __shfl(L.A, owner); TL.J = __shfl(L.J, owner); TL.V_res = __shfl(L.V_res, owner);
+    TL.iJ = __shfl(L.iJ, owner);
     const float xtol = 2e-7f * TL.A;
     bool tinf = false;
     for (int round = 0; round < 48; ++round) {
@@ -418,7 +443,9 @@ __device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v,
 }
 
 __device__ __forceinline__ JointLim joint_lim(const DScene &S, int j) {
-    return {S.pos_lo[j], S.pos_hi[j], S.vel_max[j], S.acc_max[j], S.jerk_max[j], S.dt, S.pos_lo_res[j], S.pos_hi_res[j], S.vel_max_res[j]};
+    JointLim L = {S.pos_lo[j], S.pos_hi[j], S.vel_max[j], S.acc_max[j], S.jerk_max[j], S.dt, S.pos_lo_res[j], S.pos_hi_res[j], S.vel_max_res[j], 0.f, 0.f};
+    L.derive();
+    return L;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -58,7 +58,8 @@ float emul_gjk(const float *va, int na, const float *vb, int nb, const float *Rb
     return gjk_distance<false>((const float *)verts, A, XA, hb, XB, d, cutoff, stop_below);
 }
 void emul_safe_acc_range(double plo, double phi, double V, double A, double J, double dt, float p, float v, float a, float *lo, float *hi, int *code) {
-    JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f};
+    JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f, 0.f, 0.f};
+    L.derive();
     L.plo_res = (float)(plo - (double)L.plo); L.phi_res = (float)(phi - (double)L.phi); L.V_res = (float)(V - (double)L.V);
     safe_acc_range_joint<1>(L, p, v, a, *lo, *hi, *code);
 }
@@ -176,7 +177,8 @@ extern "C" int emul_simplex(float *w /*4x3 in/out*/, int n, float *v_out) {
     return inside ? -1 : n;
 }
 extern "C" float emul_pos_margin(double plo, double phi, double V, double A, double J, double dt, float gap, float v, float a, float a1) {
-    JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f};
+    JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f, 0.f, 0.f};
+    L.derive();
     L.V_res = (float)(V - (double)L.V);
     return pos_margin(gap, v, a, a1, 1e-5f * L.V, L);
 }
