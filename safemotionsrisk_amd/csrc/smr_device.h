@@ -255,10 +255,10 @@ __device__ __forceinline__ float vel_upper_a1max(float v0, float a0, float V, fl
     const float head = (V - v0) + (tol + L.V_res);
     const float c = head - 0.5f * a0 * dt;
     if (c >= 0.f) {
-        float x = L.J * (-0.5f * dt + sqrtf(0.25f * dt * dt + 2.0f * c * L.iJ));
+        float x = L.J * (-0.5f * dt + __builtin_amdgcn_sqrtf(0.25f * dt * dt + 2.0f * c * L.iJ));      // 1-ulp square roots: the tolerances are 1e-5 V
         if (D > L.A) {
             float K = 2.0f * c * L.idt;
-            float xa = ((K - L.A) + sqrtf((L.A - K) * (L.A - K) + 8.0f * K * L.A)) * 0.25f;
+            float xa = ((K - L.A) + __builtin_amdgcn_sqrtf((L.A - K) * (L.A - K) + 8.0f * K * L.A)) * 0.25f;
             if (xa < D - L.A) x = xa;
         }
         return x;
@@ -281,7 +281,7 @@ __device__ __forceinline__ float seg_dmax_i(float v0, float a0, float a1, float 
     float j = (a1 - a0) * idt;
     float disc = a0 * a0 - 2.0f * j * v0;
     if (disc >= 0.f) {
-        float sq = sqrtf(disc);
+        float sq = __builtin_amdgcn_sqrtf(disc);
         float qq = -(a0 + (a0 >= 0.f ? sq : -sq));
         float r0 = qq * __builtin_amdgcn_rcpf(j), r1 = 2.0f * v0 * __builtin_amdgcn_rcpf(qq);   // inf/nan when a divisor is 0: rejected below
         if (r0 > 0.f && r0 < dt) m = fmaxf(m, seg_disp_i(v0, a0, a1, r0, idt));

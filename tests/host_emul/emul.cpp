@@ -23,6 +23,7 @@ static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); ret
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline bool __any(bool p) { return p; }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 static inline void sincosf_(float x, float *s, float *c) { *s = std::sin(x); *c = std::cos(x); }
 #define sincosf sincosf_
 #include <math.h>
