@@ -1191,8 +1191,8 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
         const Xf X1 = planet_pose(S, second_planet, idx[second_planet]);
         const F3 e0 = apply(X0, F3{S.planet[0].bx, S.planet[0].by, S.planet[0].bz}) - lc,
                  e1 = apply(X1, F3{S.planet[second_planet].bx, S.planet[second_planet].by, S.planet[second_planet].bz}) - lc;
-        const bool near0 = !finished && sqrtf(dot(e0, e0)) - S.planet[0].bradius - LP.radius - LP.margin <= cutoff_max;
-        const bool near1 = !finished && sqrtf(dot(e1, e1)) - S.planet[second_planet].bradius - LP.radius - LP.margin <= cutoff_max;
+        const bool near0 = !finished && __builtin_amdgcn_sqrtf(dot(e0, e0)) - S.planet[0].bradius - LP.radius - LP.margin <= cutoff_max;
+        const bool near1 = !finished && __builtin_amdgcn_sqrtf(dot(e1, e1)) - S.planet[second_planet].bradius - LP.radius - LP.margin <= cutoff_max;
 #pragma unroll 1
         for (int w = 0; w < 7; ++w) {
             uint32_t word = 0xFFFFFFFFu;
@@ -1207,11 +1207,11 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
                         const float margins = PP.margin + LP.margin;
                         const F3 cen = {PP.cx, PP.cy, PP.cz};
                         const F3 dc = (second ? apply(X1, cen) : apply(X0, cen)) - lc;
-                        const float lb_s = sqrtf(dot(dc, dc)) - PP.radius - LP.radius - margins;
+                        const float lb_s = __builtin_amdgcn_sqrtf(dot(dc, dc)) - PP.radius - LP.radius - margins;
                         if (lb_s <= cutoff_max) {
                             const F3 ca = {PP.cap_a[0], PP.cap_a[1], PP.cap_a[2]}, cb = {PP.cap_b[0], PP.cap_b[1], PP.cap_b[2]};
                             const F3 a0 = second ? apply(X1, ca) : apply(X0, ca), a1 = second ? apply(X1, cb) : apply(X0, cb);
-                            const float lb_c = sqrtf(seg_seg_dist2(a0, a1, l0, l1)) * 0.99999f - 1e-6f - PP.cap_r - LP.cap_r - margins;
+                            const float lb_c = __builtin_amdgcn_sqrtf(seg_seg_dist2(a0, a1, l0, l1)) * 0.99999f - 1e-6f - PP.cap_r - LP.cap_r - margins;
                             const float lb = fmaxf(lb_s, lb_c);
                             if (lb <= cutoff_max) key = (uint32_t)fminf(fmaxf(lb * (1.0f / kKeyStep), 0.f), 254.f);
                         }
