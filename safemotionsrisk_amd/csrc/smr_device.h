@@ -139,6 +139,13 @@ struct DState {
     unsigned *tp_count;        // [B] target points sampled so far = Philox tag of the next one
     int *tp_list;              // [B] envs that need a new target point (reached, or reset)
     int *tp_list_count;        // [1]
+    // staged target points (scenes with staged start states): the NEXT target of every env - a pure function of (seed, env,
+    // targets drawn so far) - is prepared on the side stream; finish installs it when a target is reached / an env restarts
+    float *next_tp;            // [3][B]
+    unsigned *next_tp_tag;     // [B] the target count the staged point was drawn for
+    int *tp_refill_list;       // [B] envs whose staged point was consumed in this step
+    int *tp_refill_count;      // this step's counter; two slots alternate like refill_count
+    int *tp_refill_zero;
     // staged start states (scenes without a ball): the start state of every env's NEXT episode, prepared off the
     // critical path on a second stream and committed by the finish kernel when the env is done
     float *next_q, *next_v, *next_a;   // [7][B]

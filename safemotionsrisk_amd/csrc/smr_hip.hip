@@ -195,12 +195,32 @@ __global__ void commit_kernel(const DScene *__restrict__ Sp, DState st, const in
     commit_staged(S, st, e, obs ? obs + (size_t)e * S.obs_size : nullptr);
 }
 
+// A14: the next target point of env e, installed from the staged one (drawn ahead on the side stream for tag tp_count[e]) with
+// the distances and the observation the synchronous target_kernel writes; falls back to that kernel when nothing matching is staged
+__device__ inline void install_target(const DScene &S, const DState &st, int e, F3 ee, float *row, bool staged) {
+    const int B = S.B;
+    const unsigned count = st.tp_count[e];
+    if (!staged || st.next_tp_tag[e] != count) {
+        st.tp_list[atomicAdd(st.tp_list_count, 1)] = e;
+        if (staged) st.tp_refill_list[atomicAdd(st.tp_refill_count, 1)] = e;   // nothing matching staged: drawn now, staged again behind it
+        return;
+    }
+    const float tp[3] = {st.next_tp[e], st.next_tp[B + e], st.next_tp[2 * B + e]};
+    const F3 d = F3{tp[0], tp[1], tp[2]} - ee;
+    const float dist = sqrtf(dot(d, d));
+    st.tp[e] = tp[0]; st.tp[B + e] = tp[1]; st.tp[2 * B + e] = tp[2]; st.tp[3 * B + e] = dist; st.tp[4 * B + e] = dist;
+    st.tp_count[e] = count + 1u;
+    write_target_observation(S, tp, ee, row);
+    st.tp_refill_list[atomicAdd(st.tp_refill_count, 1)] = e;
+}
+
 __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions,
                                                      float *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ done,
                                                      int8_t *__restrict__ reason, float *__restrict__ info, int staged) {
     const DScene &S = *Sp;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e == 0 && st.refill_zero) *st.refill_zero = 0;                        // the list counter of the NEXT step
+    if (e == 0 && st.refill_zero) *st.refill_zero = 0;                        // the list counters of the NEXT step
+    if (e == 0 && st.tp_refill_zero) *st.tp_refill_zero = 0;
     if (e >= S.B) return;
     const int B = S.B, N = S.checks_per_step;
     const int steps = st.step_count[e] + 1;                                   // base.py:1044
@@ -345,7 +365,12 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         commit_staged(S, st, e, obs + (size_t)e * S.obs_size);   // next episode's start state was prepared in the background
         st.refill_list[atomicAdd(st.refill_count, 1)] = e;       // hipcc folds this into one atomic per wave
         if (S.use_ball) st.spawn_list[atomicAdd(st.spawn_count, 1)] = -(e + 1);   // its ball: spawn_kernel, as a reset
-        if (S.use_target) st.tp_list[atomicAdd(st.tp_list_count, 1)] = e;         // its target point: target_kernel
+        if (S.use_target) {                                                       // its target point, seen from the new start pose
+            float qn[SMR_NJ];
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) qn[j] = st.q[j * B + e];
+            install_target(S, st, e, ee_point(S, qn), obs + (size_t)e * S.obs_size, st.next_tp != nullptr);
+        }
     } else if (d && S.auto_reset) {
         int slot = atomicAdd(st.done_count, 1);
         st.done_list[slot] = e;
@@ -353,7 +378,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         float *row = obs + (size_t)e * S.obs_size;
         write_observation(S, q, v, a, idx, row);
         if (S.use_target) {
-            if (tp_reached) st.tp_list[atomicAdd(st.tp_list_count, 1)] = e;       // a new one, get_target_point_observation ctlp.py:2217-2232
+            if (tp_reached) install_target(S, st, e, ee_end, row, staged && st.next_tp != nullptr);   // a new one, ctlp.py:2217-2232
             else write_target_observation(S, tp, ee_end, row);
         }
         if (S.use_ball) {
@@ -663,7 +688,8 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
 // A14: a new target point for the envs of the list (reached in this step, or reset): _add_target_point, ctlp.py:1658-1721 -
 // the target link point of a random valid configuration inside the target box (attempt m = draws 7m..7m+6 of stream
 // S_TARGET, tag = target points sampled so far), with the distances the next observation records (ctlp.py:2229-2243).
-template <bool EXTRA>
+// STAGED: the point for the env's CURRENT target count goes to next_tp / next_tp_tag and nothing of the live env is touched
+template <bool EXTRA, bool STAGED>
 __global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                     const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                     float *__restrict__ obs) {
@@ -684,7 +710,12 @@ __global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ S
         G.gather(rng.uniform(S_TARGET, 7u * m + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
         if (group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.target_min_static, S.target_min_self)) break;
     }
-    if (g == 0) {
+    if (g == 0 && STAGED) {
+        const F3 target = ee_point(S, q);
+        st.next_tp[e] = target.x; st.next_tp[B + e] = target.y; st.next_tp[2 * B + e] = target.z;
+        st.next_tp_tag[e] = count;
+    }
+    if (g == 0 && !STAGED) {
         const F3 target = ee_point(S, q);
         float qc[SMR_NJ];
 #pragma unroll
@@ -989,9 +1020,12 @@ struct smr_env {
     int auto_reset = 0;
     bool staged = false;        // start states are prepared on `side` and committed by finish (no ball in the scene)
     hipStream_t side = nullptr;
+    hipStream_t side2 = nullptr;      // staged target points run beside the staged start states (forked from / joined into `side`)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_commit = nullptr, ev_refill = nullptr;
     DScene hscene;              // host copy (device pointers inside)
     int *refill_slots = nullptr; // two list counters: step s uses slot s & 1, its finish kernel clears the other
+    int *tp_refill_slots = nullptr;   // the same for the staged target points (null: not staged)
     int parity = 0;
     DScene *dscene = nullptr;
     DState st;
@@ -1186,6 +1220,9 @@ int smr_destroy(smr_env_t *env) {
     (void)hipSetDevice(env->device);
     (void)hipStreamSynchronize(env->stream);
     if (env->side) { (void)hipStreamSynchronize(env->side); (void)hipStreamDestroy(env->side); }
+    if (env->side2) { (void)hipStreamSynchronize(env->side2); (void)hipStreamDestroy(env->side2); }
+    if (env->ev_fork) (void)hipEventDestroy(env->ev_fork);
+    if (env->ev_join) (void)hipEventDestroy(env->ev_join);
     if (env->ev_commit) (void)hipEventDestroy(env->ev_commit);
     if (env->ev_refill) (void)hipEventDestroy(env->ev_refill);
     for (auto &p : env->pending) { env->event_pool.push_back(p.a); env->event_pool.push_back(p.b); }
@@ -1242,9 +1279,18 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
         if (hipMemset(st.staged_tag, 0xFF, B * 4) || hipMemset(env->refill_slots, 0, 8) || hipMemset(st.stale_commits, 0, 4) ||
             hipMemset(st.next_planet_idx, 0, 2 * B * 4) || hipMemset(st.next_hit, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         st.refill_count = env->refill_slots; st.refill_zero = nullptr;
+        if (scene->use_target_points) {
+            if ((rc = dev_alloc(env, &st.next_tp, 3 * B)) || (rc = dev_alloc(env, &st.next_tp_tag, B)) || (rc = dev_alloc(env, &st.tp_refill_list, B)) ||
+                (rc = dev_alloc(env, &env->tp_refill_slots, 2))) return fail(rc);
+            if (hipMemset(st.next_tp_tag, 0xFF, B * 4) || hipMemset(env->tp_refill_slots, 0, 8)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+            st.tp_refill_count = env->tp_refill_slots; st.tp_refill_zero = nullptr;
+        }
         if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_commit, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&env->ev_refill, hipEventDisableTiming) != hipSuccess) { env->err = "could not create the side stream"; return fail(SMR_E_HIP); }
         if (hipEventRecord(env->ev_refill, env->side) != hipSuccess) { env->err = "hipEventRecord failed"; return fail(SMR_E_HIP); }
+        if (env->tp_refill_slots &&
+            (hipStreamCreateWithFlags(&env->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess)) { env->err = "could not create the second side stream"; return fail(SMR_E_HIP); }
     }
     if (hipDeviceSynchronize() != hipSuccess) { env->err = "hipDeviceSynchronize failed"; return fail(SMR_E_HIP); }
     *out = env;
@@ -1333,8 +1379,13 @@ static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *co
 }
 
 static void launch_target(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {
-    if (scene_extra(env)) hipLaunchKernelGGL(target_kernel<true>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
-    else hipLaunchKernelGGL(target_kernel<false>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+    else hipLaunchKernelGGL((target_kernel<false, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+}
+// the staged next target of the listed envs (after their current one was installed), on stream s
+static void launch_target_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride) {
+    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr);
+    else hipLaunchKernelGGL((target_kernel<false, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr);
 }
 
 static int launch_reset_list(smr_env *env, float *obs_dev) {
@@ -1364,7 +1415,14 @@ static int staged_launch_refill(smr_env *env) {        // side stream: prepare n
     {
         LaunchTimer t(env, SMR_K_RESET, env->side);
         const int B = env->B;
+        if (env->tp_refill_slots) {                     // the next target of the envs whose staged one was installed: its own stream,
+            SMR_HIP(hipEventRecord(env->ev_fork, env->side));                      // beside the start states (both are latency chains)
+            SMR_HIP(hipStreamWaitEvent(env->side2, env->ev_fork, 0));
+            launch_target_staged(env, env->side2, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), env->st.tp_refill_list, env->st.tp_refill_count, 0, reset_group_stride(true));
+            SMR_HIP(hipEventRecord(env->ev_join, env->side2));
+        }
         launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), env->side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(true), (float *)nullptr);
+        if (env->tp_refill_slots) SMR_HIP(hipStreamWaitEvent(env->side, env->ev_join, 0));
     }
     SMR_HIP(hipGetLastError());
     SMR_HIP(hipEventRecord(env->ev_refill, env->side));
@@ -1396,6 +1454,7 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     if (env->staged) {
         // list counter: the slot the NEXT step does not use (that step's finish kernel clears it again, after this refill)
         env->st.refill_count = env->refill_slots + (1 - env->parity); env->st.refill_zero = nullptr;
+        if (env->tp_refill_slots) { env->st.tp_refill_count = env->tp_refill_slots + env->parity; env->st.tp_refill_zero = nullptr; }   // an empty slot: nothing to refill
         if (!mask_dev) {
             // every env: prepare for the current tags, commit, and refill all in the background
             if ((rc = staged_prepare_all(env))) return rc;
@@ -1410,6 +1469,8 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
             }
             if (env->hscene.use_target) {
                 launch_target(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, obs_dev);
+                SMR_HIP(hipGetLastError());
+                if (env->tp_refill_slots) launch_target_staged(env, env->stream, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1);   // and the ones behind them
                 SMR_HIP(hipGetLastError());
             }
             return staged_launch_refill(env);
@@ -1427,6 +1488,9 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
         }
         if (env->hscene.use_target) {
             launch_target(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, reset_group_stride(), obs_dev);
+            SMR_HIP(hipGetLastError());
+            if (env->tp_refill_slots)
+                launch_target_staged(env, env->stream, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, reset_group_stride());
             SMR_HIP(hipGetLastError());
         }
         return staged_launch_refill(env);
@@ -1478,8 +1542,9 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         if (rc) return rc;
         env->st.refill_count = env->refill_slots + env->parity;             // cleared by the previous step's finish kernel
         env->st.refill_zero = env->refill_slots + (1 - env->parity);
+        if (env->tp_refill_slots) { env->st.tp_refill_count = env->tp_refill_slots + env->parity; env->st.tp_refill_zero = env->tp_refill_slots + (1 - env->parity); }
         env->parity ^= 1;
-    } else env->st.refill_zero = nullptr;
+    } else { env->st.refill_zero = nullptr; env->st.tp_refill_zero = nullptr; }
     {
         LaunchTimer t(env, SMR_K_FINISH);
         hipLaunchKernelGGL(finish_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, obs_dev,
@@ -1553,6 +1618,12 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     SMR_HIP(hipDeviceSynchronize());
     if (env->staged && h->reset_count) {               // the staged start states belong to the old reset counters
         if ((rc = staged_prepare_all(env))) return rc;
+        SMR_HIP(hipStreamSynchronize(env->stream));
+    }
+    if (env->tp_refill_slots && h->target_count) {     // ... and the staged target points to the old target counters
+        if ((rc = staged_wait_refill(env))) return rc;
+        launch_target_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1);
+        SMR_HIP(hipGetLastError());
         SMR_HIP(hipStreamSynchronize(env->stream));
     }
     return SMR_OK;

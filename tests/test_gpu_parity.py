@@ -642,3 +642,48 @@ def test_planet_scene_variants_against_oracle(built, variant):
     assert mism <= 4, "%d unexplained mismatches" % mism
     assert n_done > (0 if variant == "no_termination" else 20)
     env.close()
+
+
+@pytest.mark.gpu
+def test_staged_target_points_equal_the_synchronous_path(built):
+    """reaching task with auto-reset: start states AND target points prepared ahead on the side stream (default) against
+    SMR_SYNC_RESET=1 (everything drawn inside step()): bit-identical observations, rewards, dones and target state over 60
+    steps, with targets reached and episodes restarting on the way."""
+    import torch
+    B, T = 2048, 60
+    rng = np.random.default_rng(2)
+    acts = rng.uniform(-1, 1, (T, B, 7)).astype(np.float32)
+    runs = []
+    for sync in ("0", "1"):
+        os.environ["SMR_SYNC_RESET"] = sync
+        try:
+            env = _reach_env(B, seed=13, auto_reset=True)
+        finally:
+            del os.environ["SMR_SYNC_RESET"]
+        rec = [env.reset().cpu().numpy().copy()]
+        st = env.get_state()
+        near = st["target"].copy()                            # put a third of the targets close by, so that they are reached
+        near[::3, :3] = np.array([0.0, 0.0, 0.0]) + st["target"][::3, :3] * 0 + _ee_of(env, st["q"][::3]) + np.array([0.0, 0.0, 0.07])
+        near[::3, 3] = near[::3, 4] = 0.07
+        env.set_state(target=near)
+        counts = 0
+        for t in range(T):
+            obs, rew, done, info = env.step(torch.from_numpy(acts[t]).cuda())
+            rec.append(np.concatenate([obs.cpu().numpy(), rew.cpu().numpy()[:, None], done.cpu().numpy()[:, None].astype(np.float32)], axis=1))
+        st = env.get_state()
+        rec.append(st["target"]); rec.append(st["target_count"].astype(np.float32)[:, None])
+        runs.append(rec)
+        env.close()
+    # the installed target's distances come from the end-of-step target link point finish has at hand, the synchronous kernel
+    # recomputes it from the stored joint positions: equal to rounding, so are the rewards that divide by them
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert a.shape == b.shape and np.abs(a - b).max() < (2e-4 if 0 < i <= T else 2e-6), (i, np.abs(a - b).max())
+        if 0 < i <= T:
+            assert np.array_equal(a[:, -1], b[:, -1]) and np.abs(a[:, :-2] - b[:, :-2]).max() < 2e-6      # dones exact, observations to rounding
+    assert (runs[0][-1] > 2).sum() > 50                                   # targets were reached and re-drawn (beyond the resets)
+
+
+def _ee_of(env, q):
+    from oracle.oracle import OracleEnv
+    ora = OracleEnv(env.scene, 1)
+    return np.array([ora.body_frames(x.astype(np.float64))[0][8] for x in q]) + np.array([0.0, 0.0, 0.1])
