@@ -146,6 +146,11 @@ struct DState {
     int *tp_refill_list;       // [B] envs whose staged point was consumed in this step
     int *tp_refill_count;      // this step's counter; two slots alternate like refill_count
     int *tp_refill_zero;
+    // staged balls (ball scenes with staged start states): the launch of every env's NEXT ball - a pure function of (seed, env,
+    // balls spawned so far) - is prepared on the side stream; spawn_kernel installs it (and picks the contact-free initial update)
+    float *next_ball;          // [10][B] p0, v0, e0, omega
+    int *next_ball_i;          // [2][B] kmax, khit
+    unsigned *next_ball_tag;   // [B] the spawn count the staged launch was drawn for
     // staged start states (scenes without a ball): the start state of every env's NEXT episode, prepared off the
     // critical path on a second stream and committed by the finish kernel when the env is done
     float *next_q, *next_v, *next_a;   // [7][B]

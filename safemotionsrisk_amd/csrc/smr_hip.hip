@@ -645,7 +645,9 @@ __device__ inline void store_ball(const DState &st, int B, int e, const BallSpaw
 // list entry e >= 0: the ball of env e was retired in flight; -(e + 1): env e was reset (staged robot state committed) and
 // gets the ball of its new episode, advanced to a random contact-free time step (ctlp.py:1052-1111).  all_reset: every
 // entry is a reset (explicit env.reset()).
-template <bool EXTRA>
+// STAGE: only the launch of the env's NEXT ball (tag = its spawn count) is computed, into next_ball*; nothing live is touched.
+// Otherwise the ball is installed - from the staged launch when one with the right tag is there, else drawn on the spot.
+template <bool EXTRA, bool STAGE>
 __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                    const int *__restrict__ count_ptr, int count_fixed, int all_reset, int group_stride,
                                                    float *__restrict__ obs) {
@@ -662,7 +664,29 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const unsigned spawns = (unsigned)st.ball_i[4 * B + e];
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
-    const BallSpawn b = spawn_ball_group<EXTRA>(S, rng, G);
+    if (STAGE) {
+        const BallSpawn b = spawn_ball_group<EXTRA>(S, rng, G);
+        if (g == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { st.next_ball[c * B + e] = b.p0[c]; st.next_ball[(3 + c) * B + e] = b.v0[c]; st.next_ball[(6 + c) * B + e] = b.e0[c]; }
+            st.next_ball[9 * B + e] = b.omega;
+            st.next_ball_i[e] = b.kmax; st.next_ball_i[B + e] = b.khit;
+            st.next_ball_tag[e] = spawns;
+        }
+        return;
+    }
+    BallSpawn b;
+    const bool have = st.next_ball != nullptr && st.next_ball_tag[e] == spawns;
+    if (have) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { b.p0[c] = st.next_ball[c * B + e]; b.v0[c] = st.next_ball[(3 + c) * B + e]; b.e0[c] = st.next_ball[(6 + c) * B + e]; }
+        b.omega = st.next_ball[9 * B + e];
+        b.kmax = st.next_ball_i[e]; b.khit = st.next_ball_i[B + e];
+    }
+    if (G.any(!have)) {                                  // nothing matching staged for this group: draw it now
+        const BallSpawn b2 = spawn_ball_group<EXTRA>(S, rng, G);
+        if (!have) b = b2;
+    }
     BallState bs;
     for (int c = 0; c < 3; ++c) { bs.p0[c] = b.p0[c]; bs.v0[c] = b.v0[c]; bs.e0[c] = b.e0[c]; }
     bs.omega = b.omega;
@@ -1026,6 +1050,8 @@ struct smr_env {
     DScene hscene;              // host copy (device pointers inside)
     int *refill_slots = nullptr; // two list counters: step s uses slot s & 1, its finish kernel clears the other
     int *tp_refill_slots = nullptr;   // the same for the staged target points (null: not staged)
+    int *spawn_lists = nullptr, *spawn_counts = nullptr;   // two spawn lists: the side stream re-stages from one while finish fills the other
+    bool stage_balls = false;
     int parity = 0;
     DScene *dscene = nullptr;
     DState st;
@@ -1256,9 +1282,10 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
         (rc = dev_alloc(env, &st.res, (size_t)env->N * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
-        (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &st.spawn_list, B)) || (rc = dev_alloc(env, &st.spawn_count, 1)))
+        (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 2 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 2)))
         return fail(rc);
-    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(st.spawn_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 8)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts;
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
@@ -1279,6 +1306,11 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
         if (hipMemset(st.staged_tag, 0xFF, B * 4) || hipMemset(env->refill_slots, 0, 8) || hipMemset(st.stale_commits, 0, 4) ||
             hipMemset(st.next_planet_idx, 0, 2 * B * 4) || hipMemset(st.next_hit, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         st.refill_count = env->refill_slots; st.refill_zero = nullptr;
+        if (scene->use_ball) {
+            if ((rc = dev_alloc(env, &st.next_ball, 10 * B)) || (rc = dev_alloc(env, &st.next_ball_i, 2 * B)) || (rc = dev_alloc(env, &st.next_ball_tag, B))) return fail(rc);
+            if (hipMemset(st.next_ball_tag, 0xFF, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+            env->stage_balls = true;
+        }
         if (scene->use_target_points) {
             if ((rc = dev_alloc(env, &st.next_tp, 3 * B)) || (rc = dev_alloc(env, &st.next_tp_tag, B)) || (rc = dev_alloc(env, &st.tp_refill_list, B)) ||
                 (rc = dev_alloc(env, &env->tp_refill_slots, 2))) return fail(rc);
@@ -1288,7 +1320,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
         if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_commit, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&env->ev_refill, hipEventDisableTiming) != hipSuccess) { env->err = "could not create the side stream"; return fail(SMR_E_HIP); }
         if (hipEventRecord(env->ev_refill, env->side) != hipSuccess) { env->err = "hipEventRecord failed"; return fail(SMR_E_HIP); }
-        if (env->tp_refill_slots &&
+        if ((env->tp_refill_slots || env->stage_balls) &&
             (hipStreamCreateWithFlags(&env->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess)) { env->err = "could not create the second side stream"; return fail(SMR_E_HIP); }
     }
@@ -1374,8 +1406,13 @@ static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int 
 }
 
 static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int all_reset, int stride, float *obs) {
-    if (scene_extra(env)) hipLaunchKernelGGL(spawn_kernel<true>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
-    else hipLaunchKernelGGL(spawn_kernel<false>, grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
+    else hipLaunchKernelGGL((spawn_kernel<false, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
+}
+// the staged launch of the NEXT ball of the listed envs (after their current one was installed), on stream s
+static void launch_spawn_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride) {
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr);
+    else hipLaunchKernelGGL((spawn_kernel<false, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr);
 }
 
 static void launch_target(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {
@@ -1415,14 +1452,16 @@ static int staged_launch_refill(smr_env *env) {        // side stream: prepare n
     {
         LaunchTimer t(env, SMR_K_RESET, env->side);
         const int B = env->B;
-        if (env->tp_refill_slots) {                     // the next target of the envs whose staged one was installed: its own stream,
-            SMR_HIP(hipEventRecord(env->ev_fork, env->side));                      // beside the start states (both are latency chains)
+        if (env->side2) {                               // the next target / ball of the envs whose staged one was installed: its own
+            SMR_HIP(hipEventRecord(env->ev_fork, env->side));                      // stream, beside the start states (all are latency chains)
             SMR_HIP(hipStreamWaitEvent(env->side2, env->ev_fork, 0));
-            launch_target_staged(env, env->side2, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), env->st.tp_refill_list, env->st.tp_refill_count, 0, reset_group_stride(true));
+            const dim3 grid(((size_t)B * 8 * reset_group_stride(true) + 63) / 64);
+            if (env->tp_refill_slots) launch_target_staged(env, env->side2, grid, env->st.tp_refill_list, env->st.tp_refill_count, 0, reset_group_stride(true));
+            if (env->stage_balls) launch_spawn_staged(env, env->side2, grid, env->st.spawn_list, env->st.spawn_count, 0, reset_group_stride(true));
             SMR_HIP(hipEventRecord(env->ev_join, env->side2));
         }
         launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), env->side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(true), (float *)nullptr);
-        if (env->tp_refill_slots) SMR_HIP(hipStreamWaitEvent(env->side, env->ev_join, 0));
+        if (env->side2) SMR_HIP(hipStreamWaitEvent(env->side, env->ev_join, 0));
     }
     SMR_HIP(hipGetLastError());
     SMR_HIP(hipEventRecord(env->ev_refill, env->side));
@@ -1455,6 +1494,10 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
         // list counter: the slot the NEXT step does not use (that step's finish kernel clears it again, after this refill)
         env->st.refill_count = env->refill_slots + (1 - env->parity); env->st.refill_zero = nullptr;
         if (env->tp_refill_slots) { env->st.tp_refill_count = env->tp_refill_slots + env->parity; env->st.tp_refill_zero = nullptr; }   // an empty slot: nothing to refill
+        if (env->stage_balls) {                            // likewise an empty spawn list for the side stream (the balls of the reset envs are staged below)
+            env->st.spawn_list = env->spawn_lists + (size_t)env->parity * B; env->st.spawn_count = env->spawn_counts + env->parity;
+            SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
+        }
         if (!mask_dev) {
             // every env: prepare for the current tags, commit, and refill all in the background
             if ((rc = staged_prepare_all(env))) return rc;
@@ -1465,6 +1508,8 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
             SMR_HIP(hipGetLastError());
             if (env->hscene.use_ball) {                 // the balls of the new episodes (after the robot states are committed)
                 launch_spawn(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, 1, obs_dev);
+                SMR_HIP(hipGetLastError());
+                if (env->stage_balls) launch_spawn_staged(env, env->stream, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1);   // and the ones behind them
                 SMR_HIP(hipGetLastError());
             }
             if (env->hscene.use_target) {
@@ -1484,6 +1529,9 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
         SMR_HIP(hipGetLastError());
         if (env->hscene.use_ball) {
             launch_spawn(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, 1, reset_group_stride(), obs_dev);
+            SMR_HIP(hipGetLastError());
+            if (env->stage_balls)
+                launch_spawn_staged(env, env->stream, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, reset_group_stride());
             SMR_HIP(hipGetLastError());
         }
         if (env->hscene.use_target) {
@@ -1518,7 +1566,11 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipSetDevice(env->device));
     const int B = env->B;
     if (env->auto_reset && !(env->staged && env->auto_reset)) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));   // staged: unused
-    if (env->hscene.use_ball) SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
+    if (env->hscene.use_ball) {
+        // this step's spawn list: the side stream may still be re-staging from the other one
+        env->st.spawn_list = env->spawn_lists + (size_t)env->parity * B; env->st.spawn_count = env->spawn_counts + env->parity;
+        SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
+    }
     if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
     {
         LaunchTimer t(env, SMR_K_PLAN);
@@ -1618,6 +1670,12 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     SMR_HIP(hipDeviceSynchronize());
     if (env->staged && h->reset_count) {               // the staged start states belong to the old reset counters
         if ((rc = staged_prepare_all(env))) return rc;
+        SMR_HIP(hipStreamSynchronize(env->stream));
+    }
+    if (env->stage_balls && h->ball_i) {               // ... the staged balls to the old spawn counters
+        if ((rc = staged_wait_refill(env))) return rc;
+        launch_spawn_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1);
+        SMR_HIP(hipGetLastError());
         SMR_HIP(hipStreamSynchronize(env->stream));
     }
     if (env->tp_refill_slots && h->target_count) {     // ... and the staged target points to the old target counters

@@ -687,3 +687,33 @@ def _ee_of(env, q):
     from oracle.oracle import OracleEnv
     ora = OracleEnv(env.scene, 1)
     return np.array([ora.body_frames(x.astype(np.float64))[0][8] for x in q]) + np.array([0.0, 0.0, 0.1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ball_machine", [False, True])
+def test_staged_balls_equal_the_synchronous_path(built, ball_machine):
+    """ball scene with auto-reset: the launch of every env's next ball prepared ahead on the side stream (default) against
+    SMR_SYNC_RESET=1 (drawn inside step()): identical observations, rewards, dones and ball state over 60 steps."""
+    import torch
+    from safemotionsrisk_amd import VecSafeMotionsEnv, BALL_ENV_CONFIG
+    B, T = 1024, 60
+    rng = np.random.default_rng(3)
+    acts = rng.uniform(-1, 1, (T, B, 7)).astype(np.float32)
+    runs = []
+    for sync in ("0", "1"):
+        os.environ["SMR_SYNC_RESET"] = sync
+        try:
+            env = VecSafeMotionsEnv(B, device=0, seed=17, auto_reset=True, **dict(BALL_ENV_CONFIG, ball_machine_mode=ball_machine))
+        finally:
+            del os.environ["SMR_SYNC_RESET"]
+        rec = [env.reset().cpu().numpy().copy()]
+        for t in range(T):
+            obs, rew, done, info = env.step(torch.from_numpy(acts[t]).cuda())
+            rec.append(np.concatenate([obs.cpu().numpy(), rew.cpu().numpy()[:, None], done.cpu().numpy()[:, None].astype(np.float32)], axis=1))
+        st = env.get_state()
+        rec.append(st["ball"]); rec.append(st["ball_i"].astype(np.float32))
+        runs.append(rec)
+        env.close()
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert np.array_equal(a, b), i
+    assert (runs[0][-1].reshape(B, -1)[:, 4] > 3).sum() > B // 4            # several balls per env were spawned
