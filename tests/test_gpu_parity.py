@@ -717,3 +717,46 @@ def test_staged_balls_equal_the_synchronous_path(built, ball_machine):
     for i, (a, b) in enumerate(zip(*runs)):
         assert np.array_equal(a, b), i
     assert (runs[0][-1].reshape(B, -1)[:, 4] > 3).sum() > B // 4            # several balls per env were spawned
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["space", "ball", "reach"])
+def test_staging_survives_manual_resets_and_state_injection(built, scene):
+    """auto-reset stepping mixed with env.reset(mask), env.reset() and set_state of the counters the staged entries are keyed by:
+    the staged pipeline (side streams, alternating lists) against SMR_SYNC_RESET=1."""
+    import torch
+    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG, BALL_ENV_CONFIG, REACH_ENV_CONFIG
+    cfg = {"space": SPACE_ENV_CONFIG, "ball": BALL_ENV_CONFIG, "reach": REACH_ENV_CONFIG}[scene]
+    B, T = 777, 45
+    rng = np.random.default_rng(6)
+    acts = rng.uniform(-1, 1, (T, B, 7)).astype(np.float32)
+    masks = rng.random((T, B)) < 0.2
+    runs = []
+    for sync in ("0", "1"):
+        os.environ["SMR_SYNC_RESET"] = sync
+        try:
+            env = VecSafeMotionsEnv(B, device=0, seed=23, auto_reset=True, **cfg)
+        finally:
+            del os.environ["SMR_SYNC_RESET"]
+        rec = [env.reset().cpu().numpy().copy()]
+        for t in range(T):
+            obs, rew, done, info = env.step(torch.from_numpy(acts[t]).cuda())
+            rec.append(np.concatenate([obs.cpu().numpy(), rew.cpu().numpy()[:, None], done.cpu().numpy()[:, None].astype(np.float32)], axis=1))
+            if t % 7 == 3:
+                rec.append(env.reset(mask=torch.from_numpy(masks[t])).cpu().numpy().copy())
+            if t == 20:
+                rec.append(env.reset().cpu().numpy().copy())
+            if t == 30:                                        # jump the counters: every staged entry is stale afterwards
+                st = env.get_state()
+                kw = dict(reset_count=st["reset_count"] + 5)
+                if scene == "ball":
+                    bi = st["ball_i"].copy(); bi[:, 4] += 3; kw["ball_i"] = bi
+                if scene == "reach":
+                    kw["target_count"] = st["target_count"] + 4
+                env.set_state(**kw)
+        env.synchronize()
+        runs.append(rec)
+        env.close()
+    tol = 2e-4 if scene == "reach" else 0.0
+    for i, (a, b) in enumerate(zip(*runs)):
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol, (i, np.abs(a - b).max())
