@@ -54,7 +54,7 @@ constexpr int kMaxPlanetPieces = 28;       // lane-autonomous planet queries: on
 constexpr int kMaxPlanetVerts = 512;       // ... and the LDS budget for the planets' vertices
 constexpr int kPlanetDescDwords = 8;
 constexpr float kKeyStep = 0.0025f;        // candidate key = floor(lower bound / kKeyStep), 255 = done / no candidate
-constexpr int kStartBins = 4;                                // cube-map resolution of the climb start table
+constexpr int kStartBins = 8;                                // cube-map resolution of the climb start table
 constexpr int kStartCells = 6 * kStartBins * kStartBins;     // entries per piece
 
 struct DPlanet {

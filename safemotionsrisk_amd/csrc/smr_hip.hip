@@ -96,7 +96,7 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             lds_v[4 * i] = f[0]; lds_v[4 * i + 1] = f[1]; lds_v[4 * i + 2] = f[2]; lds_v[4 * i + 3] = f[3];
         }
         for (int i = threadIdx.x; i < LP.ids_count; i += kBlock) lds_ids[i] = gi[i];
-        if (threadIdx.x < kStartCells / 4) lds_start[threadIdx.x] = gm[threadIdx.x];
+        for (int i = threadIdx.x; i < kStartCells / 4; i += kBlock) lds_start[i] = gm[i];
         if (AUTO && !pair_block) stage_planets(S, threadIdx.x, kBlock, lds_pv, lds_pd);
     }
     __syncthreads();
