@@ -760,3 +760,35 @@ def test_staging_survives_manual_resets_and_state_injection(built, scene):
     tol = 2e-4 if scene == "reach" else 0.0
     for i, (a, b) in enumerate(zip(*runs)):
         assert a.shape == b.shape and np.abs(a - b).max() <= tol, (i, np.abs(a - b).max())
+
+
+@pytest.mark.gpu
+def test_limits_hold_under_adversarial_actions_on_the_gpu(built):
+    """The invariants the reference asserts (obs.py:379-403: |pos|, |vel|, |acc| <= 1.001) over 8 s episodes of actions that
+    push every joint into a limit and hold it there (constant signs per env), flip (every 7 steps) and chatter (every step):
+    the range code runs on 1-ulp reciprocals / square roots on the GPU, the CPU tests of the same loops on exact ones."""
+    import torch
+    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
+    B, T = 8192, 80
+    cfg = dict(SPACE_ENV_CONFIG, trajectory_duration=8.0, terminate_on_collision_with_moving_obstacle=False,
+               terminate_on_collision_with_static_obstacle=False)
+    for jerk in (1.0, 0.15):
+        env = VecSafeMotionsEnv(B, device=0, seed=31, auto_reset=True, **dict(cfg, jerk_limit_factor=jerk))
+        env.reset()
+        s = env.scene.struct
+        lo, hi, V, A = (np.array(x) for x in (s.pos_lo, s.pos_hi, s.vel_max, s.acc_max))
+        gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+        base = torch.sign(torch.rand((B, 7), device="cuda", generator=gen) - 0.5)
+        worst = np.zeros(3)
+        for t in range(T):
+            mode = torch.arange(B, device="cuda") % 3
+            flip = -1.0 if (t // 7) % 2 else 1.0
+            chat = -1.0 if t % 2 else 1.0
+            act = base * torch.where(mode == 0, 1.0, torch.where(mode == 1, flip, chat)).unsqueeze(1)
+            obs, rew, done, info = env.step(act)
+            if t % 8 == 7:
+                st = env.get_state()
+                worst = np.maximum(worst, [np.abs(-1 + 2 * (st["q"] - lo) / (hi - lo)).max(), (np.abs(st["v"]) / V).max(), (np.abs(st["a"]) / A).max()])
+        assert (worst <= 1.001).all(), worst
+        assert worst[0] > 0.999 and worst[2] > 0.999                         # the limits were actually reached
+        env.close()
