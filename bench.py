@@ -147,6 +147,16 @@ def main():
                     traffic = pmc["kernels"]["smr::%s_kernel" % dominant]["hbm_bytes"]
                 except Exception:
                     traffic = None
+        # what actually bounds the dominant kernel: vector issue.  Wave-level VALU instructions per launch (SQ_INSTS_VALU of the same
+        # PMC passes) x 4 cycles on one of the chip's 1024 SIMDs at 2.4 GHz, against the kernel's measured time
+        issue = None
+        try:
+            if traffic is not None:
+                valu = pmc["kernels"]["smr::%s_kernel" % dominant]["SQ_INSTS_VALU"]
+                floor_ms = valu * 4.0 / (1024 * 2.4e9) * 1e3
+                issue = {"valu_insts_per_launch": valu, "issue_floor_ms": floor_ms, "kernel_ms": dom_ms, "frac_of_peak_issue": floor_ms / dom_ms}
+        except Exception:
+            issue = None
         out = {
             "metric": "env-steps/sec at batch 65 536, 7-DoF space scene",
             "value": total_env_steps / elapsed,
@@ -172,6 +182,8 @@ def main():
             "kernel_ms": kernels,
             "overlapped_kernels": overlapped,
         }
+        if issue is not None:
+            out["roofline"]["vector_issue"] = issue
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(SPACE_ENV_CONFIG)
         print(json.dumps(out))
