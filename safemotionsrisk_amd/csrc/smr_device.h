@@ -153,10 +153,13 @@ struct DState {
     unsigned *next_ball_tag;   // [B] the spawn count the staged launch was drawn for
     // staged start states (scenes without a ball): the start state of every env's NEXT episode, prepared off the
     // critical path on a second stream and committed by the finish kernel when the env is done
-    float *next_q, *next_v, *next_a;   // [7][B]
-    int *next_planet_idx;              // [2][B]
-    int *next_hit;                     // [B]
-    unsigned *staged_tag;              // [B]  reset_count value the staged state belongs to (~0u: none)
+    // TWO staged start states per env, slot = tag & 1 (tags reset_count and reset_count + 1): the refill of a consumed slot then has
+    // two step periods before the env can need it - it never sits on the critical path, whatever the main path shrinks to
+    float *next_q, *next_v, *next_a;   // [2][7][B]
+    int *next_planet_idx;              // [2][2][B]
+    int *next_hit;                     // [2][B]
+    unsigned *staged_tag;              // [2][B]  reset_count value the staged state belongs to (~0u: none)
+    unsigned *refill_tags;             // parallel to refill_list: the tag to prepare (the env may restart again before the refill runs)
     int *refill_list;                  // [B]  envs whose staged state was consumed
     int *refill_count;                 // the counter of THIS step's list: two slots alternate, finish clears the other one
     int *refill_zero;                  // ... (refill_zero, or null) so that no memset sits between the step's kernels

@@ -170,17 +170,18 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
 __device__ inline void commit_staged(const DScene &S, const DState &st, int e, float *row) {
     const int B = S.B;
     const unsigned tag = st.reset_count[e];
-    if (st.staged_tag[e] != tag) atomicAdd(st.stale_commits, 1);          // host checks: never expected
+    const size_t sl = (size_t)(tag & 1u);                                    // the slot of this tag
+    if (st.staged_tag[sl * B + e] != tag) atomicAdd(st.stale_commits, 1);    // host checks: never expected
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
 #pragma unroll
     for (int j = 0; j < SMR_NJ; ++j) {
-        q[j] = st.next_q[j * B + e]; v[j] = st.next_v[j * B + e]; a[j] = st.next_a[j * B + e];
+        q[j] = st.next_q[(sl * SMR_NJ + j) * B + e]; v[j] = st.next_v[(sl * SMR_NJ + j) * B + e]; a[j] = st.next_a[(sl * SMR_NJ + j) * B + e];
         st.q[j * B + e] = q[j]; st.v[j * B + e] = v[j]; st.a[j * B + e] = a[j];
     }
-    int idx[SMR_MAX_PLANETS] = {st.next_planet_idx[e], st.next_planet_idx[B + e]};
+    int idx[SMR_MAX_PLANETS] = {st.next_planet_idx[(sl * 2) * B + e], st.next_planet_idx[(sl * 2 + 1) * B + e]};
     st.planet_idx[e] = idx[0]; st.planet_idx[B + e] = idx[1];
     st.step_count[e] = 0;
-    st.moving_hit[e] = st.next_hit[e];
+    st.moving_hit[e] = st.next_hit[sl * B + e];
     st.reset_count[e] = tag + 1u;
     if (row) write_observation(S, q, v, a, idx, row);
 }
@@ -362,8 +363,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
 
     if (S.use_ball) { st.ball_i[e] = ball_k; st.ball_i[3 * B + e] = ball_active; }
     if (d && S.auto_reset && staged) {
+        const unsigned tag = st.reset_count[e];
         commit_staged(S, st, e, obs + (size_t)e * S.obs_size);   // next episode's start state was prepared in the background
-        st.refill_list[atomicAdd(st.refill_count, 1)] = e;       // hipcc folds this into one atomic per wave
+        const int ri = atomicAdd(st.refill_count, 1);            // hipcc folds this into one atomic per wave
+        st.refill_list[ri] = e; st.refill_tags[ri] = tag + 2u;   // tag + 1 sits in the other slot already
         if (S.use_ball) st.spawn_list[atomicAdd(st.spawn_count, 1)] = -(e + 1);   // its ball: spawn_kernel, as a reset
         if (S.use_target) {                                                       // its target point, seen from the new start pose
             float qn[SMR_NJ];
@@ -769,10 +772,11 @@ static int reset_group_stride(bool staged = false) {
 // not lane count, bounds this kernel, so only every group_stride-th group takes an entry.
 // STAGED: the result goes to the staging arrays (next_*, staged_tag) and nothing of the live env is touched -
 // the kernel then runs on the side stream while the main stream steps the envs (scenes without a ball).
+// tags / tag_offset (STAGED): the reset count the state is for - tags[i], or the env's current count + tag_offset
 template <bool STAGED, bool EXTRA>
 __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                    const int *__restrict__ count_ptr, int count_fixed, int group_stride,
-                                                   float *__restrict__ obs) {
+                                                   float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t >> 3, g = t & 7;
@@ -784,7 +788,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
     const int B = S.B;
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const int gbase = G.gbase;
-    const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, st.reset_count[e]};
+    const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, tags ? tags[i] : st.reset_count[e] + (unsigned)tag_offset};
     const int jj = g < SMR_NJ ? g : 0;
 
     // ---- start position: attempts in sequence, each tested link-parallel (stream S_POS, attempt n = draws 7n..7n+6)
@@ -885,8 +889,9 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
     }
 
     if (STAGED) {      // robot part only; the ball of a reset depends on the env's spawn history: spawn_kernel draws it at commit time
-        if (g < SMR_NJ) { st.next_q[g * B + e] = qj; st.next_v[g * B + e] = vj; st.next_a[g * B + e] = aj; }
-        else { st.next_planet_idx[e] = idx[0]; st.next_planet_idx[B + e] = idx[1]; st.next_hit[e] = hit; st.staged_tag[e] = rng.tag; }
+        const size_t sl = (size_t)(rng.tag & 1u);
+        if (g < SMR_NJ) { st.next_q[(sl * SMR_NJ + g) * B + e] = qj; st.next_v[(sl * SMR_NJ + g) * B + e] = vj; st.next_a[(sl * SMR_NJ + g) * B + e] = aj; }
+        else { st.next_planet_idx[(sl * 2) * B + e] = idx[0]; st.next_planet_idx[(sl * 2 + 1) * B + e] = idx[1]; st.next_hit[sl * B + e] = hit; st.staged_tag[sl * B + e] = rng.tag; }
         return;
     }
     // ---- ball: spawn + random initial time step, candidates in sequence (ctlp.py:1052-1111)
@@ -1046,6 +1051,13 @@ struct smr_env {
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;      // staged target points run beside the staged start states (forked from / joined into `side`)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // the refills of consecutive steps overlap (each has two step periods): a second set of streams / events, used by odd steps
+    hipStream_t side_b = nullptr, side2_b = nullptr;
+    hipEvent_t ev_commit_b = nullptr, ev_refill_b = nullptr, ev_fork_b = nullptr, ev_join_b = nullptr;
+    int rot = 0;                      // which of the three list slots this step uses (a list is re-used two steps after its refill was awaited)
+    int *refill_lists = nullptr;      // [3][B]
+    unsigned *refill_tag_lists = nullptr;   // [3][B]
+    int *tp_refill_lists = nullptr;   // [3][B]
     hipEvent_t ev_commit = nullptr, ev_refill = nullptr;
     DScene hscene;              // host copy (device pointers inside)
     int *refill_slots = nullptr; // two list counters: step s uses slot s & 1, its finish kernel clears the other
@@ -1247,6 +1259,9 @@ int smr_destroy(smr_env_t *env) {
     (void)hipStreamSynchronize(env->stream);
     if (env->side) { (void)hipStreamSynchronize(env->side); (void)hipStreamDestroy(env->side); }
     if (env->side2) { (void)hipStreamSynchronize(env->side2); (void)hipStreamDestroy(env->side2); }
+    if (env->side_b) { (void)hipStreamSynchronize(env->side_b); (void)hipStreamDestroy(env->side_b); }
+    if (env->side2_b) { (void)hipStreamSynchronize(env->side2_b); (void)hipStreamDestroy(env->side2_b); }
+    for (hipEvent_t ev : {env->ev_commit_b, env->ev_refill_b, env->ev_fork_b, env->ev_join_b}) if (ev) (void)hipEventDestroy(ev);
     if (env->ev_fork) (void)hipEventDestroy(env->ev_fork);
     if (env->ev_join) (void)hipEventDestroy(env->ev_join);
     if (env->ev_commit) (void)hipEventDestroy(env->ev_commit);
@@ -1282,9 +1297,9 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
         (rc = dev_alloc(env, &st.res, (size_t)env->N * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
-        (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 2 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 2)))
+        (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)))
         return fail(rc);
-    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 8)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts;
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
@@ -1299,27 +1314,33 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
         env->staged = !(off && off[0] == '1');
     }
     if (env->staged) {
-        if ((rc = dev_alloc(env, &st.next_q, 7 * B)) || (rc = dev_alloc(env, &st.next_v, 7 * B)) || (rc = dev_alloc(env, &st.next_a, 7 * B)) ||
-            (rc = dev_alloc(env, &st.next_planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.next_hit, B)) || (rc = dev_alloc(env, &st.staged_tag, B)) ||
-            (rc = dev_alloc(env, &st.refill_list, B)) || (rc = dev_alloc(env, &env->refill_slots, 2)) || (rc = dev_alloc(env, &st.stale_commits, 1)))
+        if ((rc = dev_alloc(env, &st.next_q, 14 * B)) || (rc = dev_alloc(env, &st.next_v, 14 * B)) || (rc = dev_alloc(env, &st.next_a, 14 * B)) ||
+            (rc = dev_alloc(env, &st.next_planet_idx, 4 * B)) || (rc = dev_alloc(env, &st.next_hit, 2 * B)) || (rc = dev_alloc(env, &st.staged_tag, 2 * B)) ||
+            (rc = dev_alloc(env, &env->refill_lists, 3 * B)) || (rc = dev_alloc(env, &env->refill_tag_lists, 3 * B)) ||
+            (rc = dev_alloc(env, &env->refill_slots, 3)) || (rc = dev_alloc(env, &st.stale_commits, 1)))
             return fail(rc);
-        if (hipMemset(st.staged_tag, 0xFF, B * 4) || hipMemset(env->refill_slots, 0, 8) || hipMemset(st.stale_commits, 0, 4) ||
-            hipMemset(st.next_planet_idx, 0, 2 * B * 4) || hipMemset(st.next_hit, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
-        st.refill_count = env->refill_slots; st.refill_zero = nullptr;
+        if (hipMemset(st.staged_tag, 0xFF, 2 * B * 4) || hipMemset(env->refill_slots, 0, 12) || hipMemset(st.stale_commits, 0, 4) ||
+            hipMemset(st.next_planet_idx, 0, 4 * B * 4) || hipMemset(st.next_hit, 0, 2 * B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+        st.refill_list = env->refill_lists; st.refill_tags = env->refill_tag_lists; st.refill_count = env->refill_slots; st.refill_zero = nullptr;
         if (scene->use_ball) {
             if ((rc = dev_alloc(env, &st.next_ball, 10 * B)) || (rc = dev_alloc(env, &st.next_ball_i, 2 * B)) || (rc = dev_alloc(env, &st.next_ball_tag, B))) return fail(rc);
             if (hipMemset(st.next_ball_tag, 0xFF, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
             env->stage_balls = true;
         }
         if (scene->use_target_points) {
-            if ((rc = dev_alloc(env, &st.next_tp, 3 * B)) || (rc = dev_alloc(env, &st.next_tp_tag, B)) || (rc = dev_alloc(env, &st.tp_refill_list, B)) ||
-                (rc = dev_alloc(env, &env->tp_refill_slots, 2))) return fail(rc);
-            if (hipMemset(st.next_tp_tag, 0xFF, B * 4) || hipMemset(env->tp_refill_slots, 0, 8)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
-            st.tp_refill_count = env->tp_refill_slots; st.tp_refill_zero = nullptr;
+            if ((rc = dev_alloc(env, &st.next_tp, 3 * B)) || (rc = dev_alloc(env, &st.next_tp_tag, B)) || (rc = dev_alloc(env, &env->tp_refill_lists, 3 * B)) ||
+                (rc = dev_alloc(env, &env->tp_refill_slots, 3))) return fail(rc);
+            if (hipMemset(st.next_tp_tag, 0xFF, B * 4) || hipMemset(env->tp_refill_slots, 0, 12)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+            st.tp_refill_list = env->tp_refill_lists; st.tp_refill_count = env->tp_refill_slots; st.tp_refill_zero = nullptr;
         }
         if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_commit, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&env->ev_refill, hipEventDisableTiming) != hipSuccess) { env->err = "could not create the side stream"; return fail(SMR_E_HIP); }
-        if (hipEventRecord(env->ev_refill, env->side) != hipSuccess) { env->err = "hipEventRecord failed"; return fail(SMR_E_HIP); }
+        if (hipStreamCreateWithFlags(&env->side_b, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_commit_b, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&env->ev_refill_b, hipEventDisableTiming) != hipSuccess) { env->err = "could not create the side stream"; return fail(SMR_E_HIP); }
+        if (hipEventRecord(env->ev_refill, env->side) != hipSuccess || hipEventRecord(env->ev_refill_b, env->side_b) != hipSuccess) { env->err = "hipEventRecord failed"; return fail(SMR_E_HIP); }
+        if ((env->tp_refill_slots || env->stage_balls) &&
+            (hipStreamCreateWithFlags(&env->side2_b, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_fork_b, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&env->ev_join_b, hipEventDisableTiming) != hipSuccess)) { env->err = "could not create the second side stream"; return fail(SMR_E_HIP); }
         if ((env->tp_refill_slots || env->stage_balls) &&
             (hipStreamCreateWithFlags(&env->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess)) { env->err = "could not create the second side stream"; return fail(SMR_E_HIP); }
@@ -1354,7 +1375,7 @@ struct LaunchTimer {
 
 static int resolve_profile(smr_env *env) {
     SMR_HIP(hipStreamSynchronize(env->stream));
-    if (env->side) SMR_HIP(hipStreamSynchronize(env->side));
+    if (env->side) { SMR_HIP(hipStreamSynchronize(env->side)); SMR_HIP(hipStreamSynchronize(env->side_b)); }
     for (auto &p : env->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { env->prof_ms[p.k] += ms; env->prof_n[p.k] += 1; }
@@ -1400,9 +1421,10 @@ struct TmpBuf {
 static bool scene_extra(const smr_env *env) { return env->hscene.n_bodies > SMR_NLINK || env->hscene.n_self_pairs > 0; }
 
 template <bool STAGED>
-static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {
-    if (scene_extra(env)) hipLaunchKernelGGL((reset_kernel<STAGED, true>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
-    else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs,
+                         const unsigned *tags = nullptr, int tag_offset = 0) {
+    if (scene_extra(env)) hipLaunchKernelGGL((reset_kernel<STAGED, true>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
+    else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
 }
 
 static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int all_reset, int stride, float *obs) {
@@ -1442,39 +1464,56 @@ static int launch_reset_list(smr_env *env, float *obs_dev) {
 // main stream:  ... finish/commit (consumes staged states, appends to refill_list) -> ev_commit
 // side stream:  wait ev_commit -> reset_kernel<true>(refill_list) -> ev_refill
 // main stream:  wait ev_refill before the next commit (and before refill_count is cleared for it)
-static int staged_wait_refill(smr_env *env) {          // main stream: the previous refill must have landed
+static int staged_wait_refill(smr_env *env) {          // main stream: every refill in flight must have landed (reset paths, state injection)
     SMR_HIP(hipStreamWaitEvent(env->stream, env->ev_refill, 0));
+    SMR_HIP(hipStreamWaitEvent(env->stream, env->ev_refill_b, 0));
     return SMR_OK;
 }
-static int staged_launch_refill(smr_env *env) {        // side stream: prepare new start states for the consumed ones
-    SMR_HIP(hipEventRecord(env->ev_commit, env->stream));
-    SMR_HIP(hipStreamWaitEvent(env->side, env->ev_commit, 0));
+static int staged_wait_lane(smr_env *env, int p) {     // main stream, step t: the refill launched at step t - 2 (same parity) must have landed
+    SMR_HIP(hipStreamWaitEvent(env->stream, p ? env->ev_refill_b : env->ev_refill, 0));
+    return SMR_OK;
+}
+// side streams of parity p: prepare the start states behind the consumed ones (and the next balls / target points).  The refill has
+// two step periods: the env's other slot covers a restart in the very next step.
+static int staged_launch_refill(smr_env *env, int p) {
+    hipStream_t side = p ? env->side_b : env->side, side2 = p ? env->side2_b : env->side2;
+    hipEvent_t ev_commit = p ? env->ev_commit_b : env->ev_commit, ev_refill = p ? env->ev_refill_b : env->ev_refill,
+               ev_fork = p ? env->ev_fork_b : env->ev_fork, ev_join = p ? env->ev_join_b : env->ev_join;
+    SMR_HIP(hipEventRecord(ev_commit, env->stream));
+    SMR_HIP(hipStreamWaitEvent(side, ev_commit, 0));
     {
-        LaunchTimer t(env, SMR_K_RESET, env->side);
+        LaunchTimer t(env, SMR_K_RESET, side);
         const int B = env->B;
-        if (env->side2) {                               // the next target / ball of the envs whose staged one was installed: its own
-            SMR_HIP(hipEventRecord(env->ev_fork, env->side));                      // stream, beside the start states (all are latency chains)
-            SMR_HIP(hipStreamWaitEvent(env->side2, env->ev_fork, 0));
+        if (side2) {                                    // the next target / ball of the envs whose staged one was installed: its own
+            SMR_HIP(hipEventRecord(ev_fork, side));                                // stream, beside the start states (all are latency chains)
+            SMR_HIP(hipStreamWaitEvent(side2, ev_fork, 0));
             const dim3 grid(((size_t)B * 8 * reset_group_stride(true) + 63) / 64);
-            if (env->tp_refill_slots) launch_target_staged(env, env->side2, grid, env->st.tp_refill_list, env->st.tp_refill_count, 0, reset_group_stride(true));
-            if (env->stage_balls) launch_spawn_staged(env, env->side2, grid, env->st.spawn_list, env->st.spawn_count, 0, reset_group_stride(true));
-            SMR_HIP(hipEventRecord(env->ev_join, env->side2));
+            if (env->tp_refill_slots) launch_target_staged(env, side2, grid, env->st.tp_refill_list, env->st.tp_refill_count, 0, reset_group_stride(true));
+            if (env->stage_balls) launch_spawn_staged(env, side2, grid, env->st.spawn_list, env->st.spawn_count, 0, reset_group_stride(true));
+            SMR_HIP(hipEventRecord(ev_join, side2));
         }
-        launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), env->side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(true), (float *)nullptr);
-        if (env->side2) SMR_HIP(hipStreamWaitEvent(env->side, env->ev_join, 0));
+        launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(true),
+                           (float *)nullptr, env->st.refill_tags, 0);
+        if (side2) SMR_HIP(hipStreamWaitEvent(side, ev_join, 0));
     }
     SMR_HIP(hipGetLastError());
-    SMR_HIP(hipEventRecord(env->ev_refill, env->side));
+    SMR_HIP(hipEventRecord(ev_refill, side));
     return SMR_OK;
 }
-// main stream, synchronous: (re)compute the staged state of every env for its current reset_count
-static int staged_prepare_all(smr_env *env) {
+// main stream, synchronous: (re)compute the staged state of every env for its reset_count + tag_offset
+static int staged_prepare_all(smr_env *env, int tag_offset = 0) {
     int rc;
     if ((rc = staged_wait_refill(env))) return rc;
     LaunchTimer t(env, SMR_K_RESET);
-    launch_reset<true>(env, dim3(((size_t)env->B * 8 + 63) / 64), env->stream, (const int *)nullptr, (const int *)nullptr, env->B, 1, (float *)nullptr);
+    launch_reset<true>(env, dim3(((size_t)env->B * 8 + 63) / 64), env->stream, (const int *)nullptr, (const int *)nullptr, env->B, 1, (float *)nullptr, nullptr, tag_offset);
     SMR_HIP(hipGetLastError());
     return SMR_OK;
+}
+// the list slots of this step (three rotate: a list is written again two steps after its refill was awaited)
+static void staged_select_lists(smr_env *env, int r) {
+    const size_t B = (size_t)env->B;
+    env->st.refill_list = env->refill_lists + r * B; env->st.refill_tags = env->refill_tag_lists + r * B; env->st.refill_count = env->refill_slots + r;
+    if (env->tp_refill_slots) { env->st.tp_refill_list = env->tp_refill_lists + r * B; env->st.tp_refill_count = env->tp_refill_slots + r; }
 }
 static int staged_check(smr_env *env) {                // after a synchronisation: no commit may have missed its staged state
     int stale = 0;
@@ -1491,57 +1530,46 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     const int B = env->B;
     int rc;
     if (env->staged) {
-        // list counter: the slot the NEXT step does not use (that step's finish kernel clears it again, after this refill)
-        env->st.refill_count = env->refill_slots + (1 - env->parity); env->st.refill_zero = nullptr;
-        if (env->tp_refill_slots) { env->st.tp_refill_count = env->tp_refill_slots + env->parity; env->st.tp_refill_zero = nullptr; }   // an empty slot: nothing to refill
-        if (env->stage_balls) {                            // likewise an empty spawn list for the side stream (the balls of the reset envs are staged below)
-            env->st.spawn_list = env->spawn_lists + (size_t)env->parity * B; env->st.spawn_count = env->spawn_counts + env->parity;
-            SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
-        }
-        if (!mask_dev) {
-            // every env: prepare for the current tags, commit, and refill all in the background
-            if ((rc = staged_prepare_all(env))) return rc;
-            hipLaunchKernelGGL(commit_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, (const int *)nullptr,
-                               (const int *)nullptr, B, obs_dev);
-            SMR_HIP(hipGetLastError());
-            hipLaunchKernelGGL(iota_list_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, B, env->st.refill_list, env->st.refill_count);
-            SMR_HIP(hipGetLastError());
-            if (env->hscene.use_ball) {                 // the balls of the new episodes (after the robot states are committed)
-                launch_spawn(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, 1, obs_dev);
-                SMR_HIP(hipGetLastError());
-                if (env->stage_balls) launch_spawn_staged(env, env->stream, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1);   // and the ones behind them
-                SMR_HIP(hipGetLastError());
-            }
-            if (env->hscene.use_target) {
-                launch_target(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, obs_dev);
-                SMR_HIP(hipGetLastError());
-                if (env->tp_refill_slots) launch_target_staged(env, env->stream, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1);   // and the ones behind them
-                SMR_HIP(hipGetLastError());
-            }
-            return staged_launch_refill(env);
-        }
+        // Explicit resets are worked synchronously on the caller's stream: every refill in flight is awaited first, the lists of the
+        // current slot are used and left empty again, and the states BEHIND the committed ones (tags + 1, + 2) are prepared here.
         if ((rc = staged_wait_refill(env))) return rc;
-        SMR_HIP(hipMemsetAsync(env->st.refill_count, 0, sizeof(int), env->stream));
-        hipLaunchKernelGGL(mask_to_list_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, mask_dev, B, env->st.refill_list, env->st.refill_count);
-        SMR_HIP(hipGetLastError());
-        hipLaunchKernelGGL(commit_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, (const int *)env->st.refill_list,
-                           (const int *)env->st.refill_count, 0, obs_dev);
-        SMR_HIP(hipGetLastError());
-        if (env->hscene.use_ball) {
-            launch_spawn(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, 1, reset_group_stride(), obs_dev);
+        staged_select_lists(env, env->rot);
+        env->st.refill_zero = nullptr; env->st.tp_refill_zero = nullptr;
+        if (env->stage_balls) { env->st.spawn_list = env->spawn_lists + (size_t)env->rot * B; env->st.spawn_count = env->spawn_counts + env->rot; }
+        const int stride = mask_dev ? reset_group_stride() : 1;
+        const dim3 ggrid(((size_t)B * 8 * stride + 63) / 64);
+        const int *list = nullptr, *count = nullptr;
+        int fixed = B;
+        if (mask_dev) {
+            SMR_HIP(hipMemsetAsync(env->st.refill_count, 0, sizeof(int), env->stream));
+            hipLaunchKernelGGL(mask_to_list_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, mask_dev, B, env->st.refill_list, env->st.refill_count);
             SMR_HIP(hipGetLastError());
-            if (env->stage_balls)
-                launch_spawn_staged(env, env->stream, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, reset_group_stride());
+            list = env->st.refill_list; count = env->st.refill_count; fixed = 0;
+        } else {
+            // every env: (re)compute the state for the current tag (a mask reset finds both of an env's slots staged already)
+            launch_reset<true>(env, ggrid, env->stream, nullptr, nullptr, B, 1, (float *)nullptr, nullptr, 0);
+            SMR_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(commit_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, list, count, fixed, obs_dev);
+        SMR_HIP(hipGetLastError());
+        // behind the committed tag r (reset_count is r + 1 now): r + 1 (already staged for a mask reset) and r + 2
+        if (!mask_dev) { launch_reset<true>(env, ggrid, env->stream, list, count, fixed, stride, (float *)nullptr, nullptr, 0); SMR_HIP(hipGetLastError()); }
+        launch_reset<true>(env, ggrid, env->stream, list, count, fixed, stride, (float *)nullptr, nullptr, 1);
+        SMR_HIP(hipGetLastError());
+        if (env->hscene.use_ball) {                     // the balls of the new episodes (after the robot states are committed), and the ones behind them
+            launch_spawn(env, ggrid, list, count, fixed, 1, stride, obs_dev);
+            SMR_HIP(hipGetLastError());
+            if (env->stage_balls) launch_spawn_staged(env, env->stream, ggrid, list, count, fixed, stride);
             SMR_HIP(hipGetLastError());
         }
         if (env->hscene.use_target) {
-            launch_target(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, reset_group_stride(), obs_dev);
+            launch_target(env, ggrid, list, count, fixed, stride, obs_dev);
             SMR_HIP(hipGetLastError());
-            if (env->tp_refill_slots)
-                launch_target_staged(env, env->stream, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.refill_list, env->st.refill_count, 0, reset_group_stride());
+            if (env->tp_refill_slots) launch_target_staged(env, env->stream, ggrid, list, count, fixed, stride);
             SMR_HIP(hipGetLastError());
         }
-        return staged_launch_refill(env);
+        if (mask_dev) SMR_HIP(hipMemsetAsync(env->st.refill_count, 0, sizeof(int), env->stream));     // the slot is the next step's: leave it empty
+        return SMR_OK;
     }
     if (!mask_dev) {
         LaunchTimer t(env, SMR_K_RESET);
@@ -1568,7 +1596,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (env->auto_reset && !(env->staged && env->auto_reset)) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));   // staged: unused
     if (env->hscene.use_ball) {
         // this step's spawn list: the side stream may still be re-staging from the other one
-        env->st.spawn_list = env->spawn_lists + (size_t)env->parity * B; env->st.spawn_count = env->spawn_counts + env->parity;
+        env->st.spawn_list = env->spawn_lists + (size_t)env->rot * B; env->st.spawn_count = env->spawn_counts + env->rot;
         SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
     }
     if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
@@ -1589,13 +1617,14 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     }
     SMR_HIP(hipGetLastError());
     const bool staged = env->staged && env->auto_reset;
+    const int lane = env->parity;
     if (staged) {
-        int rc = staged_wait_refill(env);
+        int rc = staged_wait_lane(env, lane);               // the refill of two steps ago: its slots are committed from / its lists re-used below
         if (rc) return rc;
-        env->st.refill_count = env->refill_slots + env->parity;             // cleared by the previous step's finish kernel
-        env->st.refill_zero = env->refill_slots + (1 - env->parity);
-        if (env->tp_refill_slots) { env->st.tp_refill_count = env->tp_refill_slots + env->parity; env->st.tp_refill_zero = env->tp_refill_slots + (1 - env->parity); }
-        env->parity ^= 1;
+        staged_select_lists(env, env->rot);                 // this slot's counters were cleared by the previous step's finish kernel
+        const int nxt = (env->rot + 1) % 3;                 // ... as this one clears the next (last used two steps ago, awaited just now)
+        env->st.refill_zero = env->refill_slots + nxt;
+        env->st.tp_refill_zero = env->tp_refill_slots ? env->tp_refill_slots + nxt : nullptr;
     } else { env->st.refill_zero = nullptr; env->st.tp_refill_zero = nullptr; }
     {
         LaunchTimer t(env, SMR_K_FINISH);
@@ -1613,7 +1642,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         launch_target(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.tp_list, env->st.tp_list_count, 0, reset_group_stride(), obs_dev);
         SMR_HIP(hipGetLastError());
     }
-    if (staged) return staged_launch_refill(env);
+    if (staged) {
+        const int rc = staged_launch_refill(env, lane);
+        env->parity ^= 1; env->rot = (env->rot + 1) % 3;
+        return rc;
+    }
+    if (env->hscene.use_ball) env->rot = (env->rot + 1) % 3;
     if (env->auto_reset) return launch_reset_list(env, obs_dev);
     return SMR_OK;
 }
@@ -1630,7 +1664,7 @@ int smr_synchronize(smr_env_t *env) {
     if (!env) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     SMR_HIP(hipStreamSynchronize(env->stream));
-    if (env->side) { SMR_HIP(hipStreamSynchronize(env->side)); return staged_check(env); }
+    if (env->side) { SMR_HIP(hipStreamSynchronize(env->side)); SMR_HIP(hipStreamSynchronize(env->side_b)); return staged_check(env); }
     return SMR_OK;
 }
 
@@ -1653,7 +1687,7 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     if (!env || !h) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     SMR_HIP(hipStreamSynchronize(env->stream));
-    if (env->side) SMR_HIP(hipStreamSynchronize(env->side));
+    if (env->side) { SMR_HIP(hipStreamSynchronize(env->side)); SMR_HIP(hipStreamSynchronize(env->side_b)); }
     if (h->planet_idx)
         for (size_t e = 0; e < (size_t)env->B; ++e)
             for (int p = 0; p < env->hscene.n_planets; ++p) {
@@ -1669,7 +1703,7 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
         return rc;
     SMR_HIP(hipDeviceSynchronize());
     if (env->staged && h->reset_count) {               // the staged start states belong to the old reset counters
-        if ((rc = staged_prepare_all(env))) return rc;
+        if ((rc = staged_prepare_all(env, 0)) || (rc = staged_prepare_all(env, 1))) return rc;
         SMR_HIP(hipStreamSynchronize(env->stream));
     }
     if (env->stage_balls && h->ball_i) {               // ... the staged balls to the old spawn counters
