@@ -141,16 +141,18 @@ struct DState {
     int *tp_list_count;        // [1]
     // staged target points (scenes with staged start states): the NEXT target of every env - a pure function of (seed, env,
     // targets drawn so far) - is prepared on the side stream; finish installs it when a target is reached / an env restarts
-    float *next_tp;            // [3][B]
-    unsigned *next_tp_tag;     // [B] the target count the staged point was drawn for
+    float *next_tp;            // [2][3][B]  two staged points per env (target counts c and c + 1, slot = count & 1), like the start states
+    unsigned *next_tp_tag;     // [2][B] the target count the staged point was drawn for
     int *tp_refill_list;       // [B] envs whose staged point was consumed in this step
+    unsigned *tp_refill_tags;  // parallel: the count to draw for
     int *tp_refill_count;      // this step's counter; two slots alternate like refill_count
     int *tp_refill_zero;
     // staged balls (ball scenes with staged start states): the launch of every env's NEXT ball - a pure function of (seed, env,
     // balls spawned so far) - is prepared on the side stream; spawn_kernel installs it (and picks the contact-free initial update)
-    float *next_ball;          // [10][B] p0, v0, e0, omega
-    int *next_ball_i;          // [2][B] kmax, khit
-    unsigned *next_ball_tag;   // [B] the spawn count the staged launch was drawn for
+    float *next_ball;          // [2][10][B] p0, v0, e0, omega; two staged launches per env (spawn counts c and c + 1, slot = count & 1)
+    int *next_ball_i;          // [2][2][B] kmax, khit
+    unsigned *next_ball_tag;   // [2][B] the spawn count the staged launch was drawn for
+    unsigned *spawn_tags;      // parallel to spawn_list: the count to draw for when the entry is re-staged
     // staged start states (scenes without a ball): the start state of every env's NEXT episode, prepared off the
     // critical path on a second stream and committed by the finish kernel when the env is done
     // TWO staged start states per env, slot = tag & 1 (tags reset_count and reset_count + 1): the refill of a consumed slot then has

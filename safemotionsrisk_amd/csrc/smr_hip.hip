@@ -201,18 +201,20 @@ __global__ void commit_kernel(const DScene *__restrict__ Sp, DState st, const in
 __device__ inline void install_target(const DScene &S, const DState &st, int e, F3 ee, float *row, bool staged) {
     const int B = S.B;
     const unsigned count = st.tp_count[e];
-    if (!staged || st.next_tp_tag[e] != count) {
+    const size_t sl = (size_t)(count & 1u);
+    if (!staged || st.next_tp_tag[sl * B + e] != count) {
         st.tp_list[atomicAdd(st.tp_list_count, 1)] = e;
-        if (staged) st.tp_refill_list[atomicAdd(st.tp_refill_count, 1)] = e;   // nothing matching staged: drawn now, staged again behind it
+        if (staged) { const int ri = atomicAdd(st.tp_refill_count, 1); st.tp_refill_list[ri] = e; st.tp_refill_tags[ri] = count + 2u; }   // drawn now, staged again behind it
         return;
     }
-    const float tp[3] = {st.next_tp[e], st.next_tp[B + e], st.next_tp[2 * B + e]};
+    const float tp[3] = {st.next_tp[(sl * 3) * B + e], st.next_tp[(sl * 3 + 1) * B + e], st.next_tp[(sl * 3 + 2) * B + e]};
     const F3 d = F3{tp[0], tp[1], tp[2]} - ee;
     const float dist = sqrtf(dot(d, d));
     st.tp[e] = tp[0]; st.tp[B + e] = tp[1]; st.tp[2 * B + e] = tp[2]; st.tp[3 * B + e] = dist; st.tp[4 * B + e] = dist;
     st.tp_count[e] = count + 1u;
     write_target_observation(S, tp, ee, row);
-    st.tp_refill_list[atomicAdd(st.tp_refill_count, 1)] = e;
+    const int ri = atomicAdd(st.tp_refill_count, 1);
+    st.tp_refill_list[ri] = e; st.tp_refill_tags[ri] = count + 2u;            // count + 1 sits in the other slot
 }
 
 __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions,
@@ -367,7 +369,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         commit_staged(S, st, e, obs + (size_t)e * S.obs_size);   // next episode's start state was prepared in the background
         const int ri = atomicAdd(st.refill_count, 1);            // hipcc folds this into one atomic per wave
         st.refill_list[ri] = e; st.refill_tags[ri] = tag + 2u;   // tag + 1 sits in the other slot already
-        if (S.use_ball) st.spawn_list[atomicAdd(st.spawn_count, 1)] = -(e + 1);   // its ball: spawn_kernel, as a reset
+        if (S.use_ball) {                                                         // its ball: spawn_kernel, as a reset
+            const int si = atomicAdd(st.spawn_count, 1);
+            st.spawn_list[si] = -(e + 1); st.spawn_tags[si] = (unsigned)st.ball_i[4 * B + e] + 2u;
+        }
         if (S.use_target) {                                                       // its target point, seen from the new start pose
             float qn[SMR_NJ];
 #pragma unroll
@@ -385,7 +390,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
             else write_target_observation(S, tp, ee_end, row);
         }
         if (S.use_ball) {
-            if (ball_respawn) st.spawn_list[atomicAdd(st.spawn_count, 1)] = e;    // ball columns written by spawn_kernel
+            if (ball_respawn) {                                                   // ball columns written by spawn_kernel
+                const int si = atomicAdd(st.spawn_count, 1);
+                st.spawn_list[si] = e; st.spawn_tags[si] = (unsigned)st.ball_i[4 * B + e] + 2u;
+            }
             else write_ball_observation(S, ball, ball_k, row + 3 * SMR_NJ + S.obs_target_size);
         }
     }
@@ -650,10 +658,11 @@ __device__ inline void store_ball(const DState &st, int B, int e, const BallSpaw
 // entry is a reset (explicit env.reset()).
 // STAGE: only the launch of the env's NEXT ball (tag = its spawn count) is computed, into next_ball*; nothing live is touched.
 // Otherwise the ball is installed - from the staged launch when one with the right tag is there, else drawn on the spot.
+// tags / tag_offset (STAGE): the spawn count the launch is for - tags[i], or the env's current count + tag_offset
 template <bool EXTRA, bool STAGE>
 __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                    const int *__restrict__ count_ptr, int count_fixed, int all_reset, int group_stride,
-                                                   float *__restrict__ obs) {
+                                                   float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t >> 3, g = t & 7;
@@ -665,26 +674,27 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
     const int e = entry < 0 ? -(entry + 1) : entry;
     const int B = S.B;
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
-    const unsigned spawns = (unsigned)st.ball_i[4 * B + e];
+    const unsigned spawns = STAGE ? (tags ? tags[i] : (unsigned)st.ball_i[4 * B + e] + (unsigned)tag_offset) : (unsigned)st.ball_i[4 * B + e];
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
+    const size_t sl = (size_t)(spawns & 1u);
     if (STAGE) {
         const BallSpawn b = spawn_ball_group<EXTRA>(S, rng, G);
         if (g == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { st.next_ball[c * B + e] = b.p0[c]; st.next_ball[(3 + c) * B + e] = b.v0[c]; st.next_ball[(6 + c) * B + e] = b.e0[c]; }
-            st.next_ball[9 * B + e] = b.omega;
-            st.next_ball_i[e] = b.kmax; st.next_ball_i[B + e] = b.khit;
-            st.next_ball_tag[e] = spawns;
+            for (int c = 0; c < 3; ++c) { st.next_ball[(sl * 10 + c) * B + e] = b.p0[c]; st.next_ball[(sl * 10 + 3 + c) * B + e] = b.v0[c]; st.next_ball[(sl * 10 + 6 + c) * B + e] = b.e0[c]; }
+            st.next_ball[(sl * 10 + 9) * B + e] = b.omega;
+            st.next_ball_i[(sl * 2) * B + e] = b.kmax; st.next_ball_i[(sl * 2 + 1) * B + e] = b.khit;
+            st.next_ball_tag[sl * B + e] = spawns;
         }
         return;
     }
     BallSpawn b;
-    const bool have = st.next_ball != nullptr && st.next_ball_tag[e] == spawns;
+    const bool have = st.next_ball != nullptr && st.next_ball_tag[sl * B + e] == spawns;
     if (have) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { b.p0[c] = st.next_ball[c * B + e]; b.v0[c] = st.next_ball[(3 + c) * B + e]; b.e0[c] = st.next_ball[(6 + c) * B + e]; }
-        b.omega = st.next_ball[9 * B + e];
-        b.kmax = st.next_ball_i[e]; b.khit = st.next_ball_i[B + e];
+        for (int c = 0; c < 3; ++c) { b.p0[c] = st.next_ball[(sl * 10 + c) * B + e]; b.v0[c] = st.next_ball[(sl * 10 + 3 + c) * B + e]; b.e0[c] = st.next_ball[(sl * 10 + 6 + c) * B + e]; }
+        b.omega = st.next_ball[(sl * 10 + 9) * B + e];
+        b.kmax = st.next_ball_i[(sl * 2) * B + e]; b.khit = st.next_ball_i[(sl * 2 + 1) * B + e];
     }
     if (G.any(!have)) {                                  // nothing matching staged for this group: draw it now
         const BallSpawn b2 = spawn_ball_group<EXTRA>(S, rng, G);
@@ -716,10 +726,11 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
 // the target link point of a random valid configuration inside the target box (attempt m = draws 7m..7m+6 of stream
 // S_TARGET, tag = target points sampled so far), with the distances the next observation records (ctlp.py:2229-2243).
 // STAGED: the point for the env's CURRENT target count goes to next_tp / next_tp_tag and nothing of the live env is touched
+// tags / tag_offset (STAGED): the target count the point is for - tags[i], or the env's current count + tag_offset
 template <bool EXTRA, bool STAGED>
 __global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                     const int *__restrict__ count_ptr, int count_fixed, int group_stride,
-                                                    float *__restrict__ obs) {
+                                                    float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t >> 3, g = t & 7;
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ S
     const int B = S.B;
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const int jj = g < SMR_NJ ? g : 0;
-    const unsigned count = st.tp_count[e];
+    const unsigned count = STAGED ? (tags ? tags[i] : st.tp_count[e] + (unsigned)tag_offset) : st.tp_count[e];
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, count};
     float q[SMR_NJ];
     for (unsigned m = 0; m < 100000u; ++m) {
@@ -739,8 +750,9 @@ __global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ S
     }
     if (g == 0 && STAGED) {
         const F3 target = ee_point(S, q);
-        st.next_tp[e] = target.x; st.next_tp[B + e] = target.y; st.next_tp[2 * B + e] = target.z;
-        st.next_tp_tag[e] = count;
+        const size_t sl = (size_t)(count & 1u);
+        st.next_tp[(sl * 3) * B + e] = target.x; st.next_tp[(sl * 3 + 1) * B + e] = target.y; st.next_tp[(sl * 3 + 2) * B + e] = target.z;
+        st.next_tp_tag[sl * B + e] = count;
     }
     if (g == 0 && !STAGED) {
         const F3 target = ee_point(S, q);
@@ -1058,6 +1070,7 @@ struct smr_env {
     int *refill_lists = nullptr;      // [3][B]
     unsigned *refill_tag_lists = nullptr;   // [3][B]
     int *tp_refill_lists = nullptr;   // [3][B]
+    unsigned *tp_refill_tag_lists = nullptr, *spawn_tag_lists = nullptr;   // [3][B] each
     hipEvent_t ev_commit = nullptr, ev_refill = nullptr;
     DScene hscene;              // host copy (device pointers inside)
     int *refill_slots = nullptr; // two list counters: step s uses slot s & 1, its finish kernel clears the other
@@ -1297,10 +1310,10 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
         (rc = dev_alloc(env, &st.res, (size_t)env->N * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
-        (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)))
+        (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)) || (rc = dev_alloc(env, &env->spawn_tag_lists, 3 * B)))
         return fail(rc);
     if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
-    st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts;
+    st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts; st.spawn_tags = env->spawn_tag_lists;
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
@@ -1323,15 +1336,15 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
             hipMemset(st.next_planet_idx, 0, 4 * B * 4) || hipMemset(st.next_hit, 0, 2 * B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         st.refill_list = env->refill_lists; st.refill_tags = env->refill_tag_lists; st.refill_count = env->refill_slots; st.refill_zero = nullptr;
         if (scene->use_ball) {
-            if ((rc = dev_alloc(env, &st.next_ball, 10 * B)) || (rc = dev_alloc(env, &st.next_ball_i, 2 * B)) || (rc = dev_alloc(env, &st.next_ball_tag, B))) return fail(rc);
-            if (hipMemset(st.next_ball_tag, 0xFF, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+            if ((rc = dev_alloc(env, &st.next_ball, 20 * B)) || (rc = dev_alloc(env, &st.next_ball_i, 4 * B)) || (rc = dev_alloc(env, &st.next_ball_tag, 2 * B))) return fail(rc);
+            if (hipMemset(st.next_ball_tag, 0xFF, 2 * B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
             env->stage_balls = true;
         }
         if (scene->use_target_points) {
-            if ((rc = dev_alloc(env, &st.next_tp, 3 * B)) || (rc = dev_alloc(env, &st.next_tp_tag, B)) || (rc = dev_alloc(env, &env->tp_refill_lists, 3 * B)) ||
-                (rc = dev_alloc(env, &env->tp_refill_slots, 3))) return fail(rc);
-            if (hipMemset(st.next_tp_tag, 0xFF, B * 4) || hipMemset(env->tp_refill_slots, 0, 12)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
-            st.tp_refill_list = env->tp_refill_lists; st.tp_refill_count = env->tp_refill_slots; st.tp_refill_zero = nullptr;
+            if ((rc = dev_alloc(env, &st.next_tp, 6 * B)) || (rc = dev_alloc(env, &st.next_tp_tag, 2 * B)) || (rc = dev_alloc(env, &env->tp_refill_lists, 3 * B)) ||
+                (rc = dev_alloc(env, &env->tp_refill_tag_lists, 3 * B)) || (rc = dev_alloc(env, &env->tp_refill_slots, 3))) return fail(rc);
+            if (hipMemset(st.next_tp_tag, 0xFF, 2 * B * 4) || hipMemset(env->tp_refill_slots, 0, 12)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+            st.tp_refill_list = env->tp_refill_lists; st.tp_refill_tags = env->tp_refill_tag_lists; st.tp_refill_count = env->tp_refill_slots; st.tp_refill_zero = nullptr;
         }
         if (hipStreamCreateWithFlags(&env->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_commit, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&env->ev_refill, hipEventDisableTiming) != hipSuccess) { env->err = "could not create the side stream"; return fail(SMR_E_HIP); }
@@ -1428,23 +1441,25 @@ static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int 
 }
 
 static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int all_reset, int stride, float *obs) {
-    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
-    else hipLaunchKernelGGL((spawn_kernel<false, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs);
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
+    else hipLaunchKernelGGL((spawn_kernel<false, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
 }
 // the staged launch of the NEXT ball of the listed envs (after their current one was installed), on stream s
-static void launch_spawn_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride) {
-    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr);
-    else hipLaunchKernelGGL((spawn_kernel<false, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr);
+static void launch_spawn_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride,
+                                const unsigned *tags = nullptr, int tag_offset = 0) {
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
+    else hipLaunchKernelGGL((spawn_kernel<false, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
 }
 
 static void launch_target(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {
-    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
-    else hipLaunchKernelGGL((target_kernel<false, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs);
+    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, (const unsigned *)nullptr, 0);
+    else hipLaunchKernelGGL((target_kernel<false, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, (const unsigned *)nullptr, 0);
 }
 // the staged next target of the listed envs (after their current one was installed), on stream s
-static void launch_target_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride) {
-    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr);
-    else hipLaunchKernelGGL((target_kernel<false, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr);
+static void launch_target_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride,
+                                 const unsigned *tags = nullptr, int tag_offset = 0) {
+    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
+    else hipLaunchKernelGGL((target_kernel<false, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
 }
 
 static int launch_reset_list(smr_env *env, float *obs_dev) {
@@ -1488,8 +1503,8 @@ static int staged_launch_refill(smr_env *env, int p) {
             SMR_HIP(hipEventRecord(ev_fork, side));                                // stream, beside the start states (all are latency chains)
             SMR_HIP(hipStreamWaitEvent(side2, ev_fork, 0));
             const dim3 grid(((size_t)B * 8 * reset_group_stride(true) + 63) / 64);
-            if (env->tp_refill_slots) launch_target_staged(env, side2, grid, env->st.tp_refill_list, env->st.tp_refill_count, 0, reset_group_stride(true));
-            if (env->stage_balls) launch_spawn_staged(env, side2, grid, env->st.spawn_list, env->st.spawn_count, 0, reset_group_stride(true));
+            if (env->tp_refill_slots) launch_target_staged(env, side2, grid, env->st.tp_refill_list, env->st.tp_refill_count, 0, reset_group_stride(true), env->st.tp_refill_tags, 0);
+            if (env->stage_balls) launch_spawn_staged(env, side2, grid, env->st.spawn_list, env->st.spawn_count, 0, reset_group_stride(true), env->st.spawn_tags, 0);
             SMR_HIP(hipEventRecord(ev_join, side2));
         }
         launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(true),
@@ -1513,7 +1528,7 @@ static int staged_prepare_all(smr_env *env, int tag_offset = 0) {
 static void staged_select_lists(smr_env *env, int r) {
     const size_t B = (size_t)env->B;
     env->st.refill_list = env->refill_lists + r * B; env->st.refill_tags = env->refill_tag_lists + r * B; env->st.refill_count = env->refill_slots + r;
-    if (env->tp_refill_slots) { env->st.tp_refill_list = env->tp_refill_lists + r * B; env->st.tp_refill_count = env->tp_refill_slots + r; }
+    if (env->tp_refill_slots) { env->st.tp_refill_list = env->tp_refill_lists + r * B; env->st.tp_refill_tags = env->tp_refill_tag_lists + r * B; env->st.tp_refill_count = env->tp_refill_slots + r; }
 }
 static int staged_check(smr_env *env) {                // after a synchronisation: no commit may have missed its staged state
     int stale = 0;
@@ -1535,7 +1550,7 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
         if ((rc = staged_wait_refill(env))) return rc;
         staged_select_lists(env, env->rot);
         env->st.refill_zero = nullptr; env->st.tp_refill_zero = nullptr;
-        if (env->stage_balls) { env->st.spawn_list = env->spawn_lists + (size_t)env->rot * B; env->st.spawn_count = env->spawn_counts + env->rot; }
+        if (env->stage_balls) { env->st.spawn_list = env->spawn_lists + (size_t)env->rot * B; env->st.spawn_tags = env->spawn_tag_lists + (size_t)env->rot * B; env->st.spawn_count = env->spawn_counts + env->rot; }
         const int stride = mask_dev ? reset_group_stride() : 1;
         const dim3 ggrid(((size_t)B * 8 * stride + 63) / 64);
         const int *list = nullptr, *count = nullptr;
@@ -1559,13 +1574,13 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
         if (env->hscene.use_ball) {                     // the balls of the new episodes (after the robot states are committed), and the ones behind them
             launch_spawn(env, ggrid, list, count, fixed, 1, stride, obs_dev);
             SMR_HIP(hipGetLastError());
-            if (env->stage_balls) launch_spawn_staged(env, env->stream, ggrid, list, count, fixed, stride);
+            if (env->stage_balls) { launch_spawn_staged(env, env->stream, ggrid, list, count, fixed, stride, nullptr, 0); launch_spawn_staged(env, env->stream, ggrid, list, count, fixed, stride, nullptr, 1); }
             SMR_HIP(hipGetLastError());
         }
         if (env->hscene.use_target) {
             launch_target(env, ggrid, list, count, fixed, stride, obs_dev);
             SMR_HIP(hipGetLastError());
-            if (env->tp_refill_slots) launch_target_staged(env, env->stream, ggrid, list, count, fixed, stride);
+            if (env->tp_refill_slots) { launch_target_staged(env, env->stream, ggrid, list, count, fixed, stride, nullptr, 0); launch_target_staged(env, env->stream, ggrid, list, count, fixed, stride, nullptr, 1); }
             SMR_HIP(hipGetLastError());
         }
         if (mask_dev) SMR_HIP(hipMemsetAsync(env->st.refill_count, 0, sizeof(int), env->stream));     // the slot is the next step's: leave it empty
@@ -1596,7 +1611,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (env->auto_reset && !(env->staged && env->auto_reset)) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));   // staged: unused
     if (env->hscene.use_ball) {
         // this step's spawn list: the side stream may still be re-staging from the other one
-        env->st.spawn_list = env->spawn_lists + (size_t)env->rot * B; env->st.spawn_count = env->spawn_counts + env->rot;
+        env->st.spawn_list = env->spawn_lists + (size_t)env->rot * B; env->st.spawn_tags = env->spawn_tag_lists + (size_t)env->rot * B; env->st.spawn_count = env->spawn_counts + env->rot;
         SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
     }
     if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
@@ -1708,13 +1723,15 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     }
     if (env->stage_balls && h->ball_i) {               // ... the staged balls to the old spawn counters
         if ((rc = staged_wait_refill(env))) return rc;
-        launch_spawn_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1);
+        launch_spawn_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1, nullptr, 0);
+        launch_spawn_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1, nullptr, 1);
         SMR_HIP(hipGetLastError());
         SMR_HIP(hipStreamSynchronize(env->stream));
     }
     if (env->tp_refill_slots && h->target_count) {     // ... and the staged target points to the old target counters
         if ((rc = staged_wait_refill(env))) return rc;
-        launch_target_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1);
+        launch_target_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1, nullptr, 0);
+        launch_target_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1, nullptr, 1);
         SMR_HIP(hipGetLastError());
         SMR_HIP(hipStreamSynchronize(env->stream));
     }
