@@ -111,9 +111,18 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], S.dt, S.dt);
         const int a = S.self_pair[pair][0], partner = S.self_pair[pair][1];
-        const Xf Ta = body_frame(S, qs, a);
+        // one pass down the chain gives both frames: the partner link's is a prefix of the body's
+        const int link_a = a < SMR_NLINK ? a : SMR_NLINK - 1;
+        Xf Ta = fk_base(S), Tp = Ta;
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) {
+            if (j == partner) Tp = Ta;
+            if (j < link_a) fk_advance(S, j, qs[j], Ta);
+        }
+        if (partner >= link_a) Tp = body_frame(S, qs, partner);                // not the case for the ball machine (partners are links 0..5)
+        if (a >= SMR_NLINK) Ta = mounted_frame(S, a, Ta);
         float d;
-        if (partner >= 0) d = piece_distance<false>(S, S.link_piece[a], Ta, LP, hull, body_frame(S, qs, partner), S.static_max, S.collision_dist);
+        if (partner >= 0) d = piece_distance<false>(S, S.link_piece[a], Ta, LP, hull, Tp, S.static_max, S.collision_dist);
         else d = self_pair_distance(S, pair, qs, LP, hull, Ta, S.static_max, S.collision_dist);
         st.dist[(size_t)(2 * NB + pair) * B + e] = d <= S.static_max ? d : S.static_max;
         return;
