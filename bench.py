@@ -1,54 +1,138 @@
 #!/usr/bin/env python3
 """Benchmark of the SafeMotions hot path on MI355X (contract: see the task statement / DESIGN.md).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config NAME]
 
-A "step" is one env.step() of every environment of the batch (plan + collide + finish + reset kernels,
-with auto-reset, so finished episodes are re-sampled inside the timed region).  Workload = BASELINE.json
-configs[2]: 65 536 envs per GPU, 7-DoF space/planet scene, collision_check_time=0.033 (3 contact samples
-per step).  N > 1: weak scaling, every rank steps its own 65 536 envs and the (obs, reward, done) shards
-are all-gathered over RCCL once per step (configs[4] at N = 8).  Actions are resident on the GPU before
-the timed region; rank 0 prints ONE JSON line.
+A "step" is one env.step() of every environment of the batch (plan + contact sweep + collide + finish kernels and the
+refill of finished episodes, with auto-reset, so finished episodes are re-sampled inside the timed region; the info
+matrix RLlib's callbacks read is written every step).  Default workload = BASELINE.json configs[2]: 65 536 envs per GPU,
+7-DoF space/planet scene of the README command, contact checks at the reference's cadence (24 per step, one after every
+1/240 s obstacle update, ctlp.py:2631-2637).  Other BASELINE configurations and variants: --config (see CONFIGS).
+N > 1: weak scaling, every rank steps its own 65 536 envs and the (obs, reward, done) shards are all-gathered over RCCL
+once per step (configs[4] at N = 8).  Without WORLD_SIZE in the environment `--gpus N` starts its N rank processes
+itself (fresh children, before this process touches the GPU); under torchrun it uses the ranks it is given.
+Actions are resident on the GPU before the timed region; rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_ENV_STEP = 342      # SURVEY section 8d, space scene (DESIGN.md "algorithmic bytes")
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec
-FP32_VALU_PEAK_TFLOPS = 157.3
+VALU_CYCLES_PER_WAVE_INST = 2.0    # MI355X_MICROARCH.md constants table: "v_fma_f32 (wave64): 2 cyc (SIMD-32); one wave alone: 4"
+N_SIMD, CLOCK_HZ = 1024, 2.4e9     # 256 CUs x 4 SIMD-32
+
+#: name -> (env_config name, overrides, constructor keywords, algorithmic HBM bytes per env-step, what it is)
+CONFIGS = {
+    "space": ("SPACE", {}, {}, 342, "BASELINE configs[2]: space/planet scene (robot_scene=0, obstacle_scene=5, planet_mode), README command; "
+                                    "24 contact samples per step = the reference's cadence"),
+    "space_n3": ("SPACE", {}, dict(collision_checks_per_step=3), 342, "space scene with 3 contact samples per step (round-1 headline configuration)"),
+    "space_n1": ("SPACE", {}, dict(collision_checks_per_step=1), 342, "space scene, contact tested at the end of the step only"),
+    "space4096": ("SPACE", {}, {}, 342, "BASELINE configs[1]: 4096 envs on one GPU, space/planet scene"),
+    "ball": ("BALL", {}, {}, 422, "BASELINE configs[3]: ball scene (ballistic moving obstacle), self + static + moving distance rewards"),
+    "space_bm": ("SPACE", dict(ball_machine_mode=True), {}, 342, "space scene on robot_ball_machine.urdf = trained_networks/backup_networks/space/params.json"),
+    "ball_bm": ("BALL", dict(ball_machine_mode=True), {}, 422, "ball scene on robot_ball_machine.urdf = trained_networks/backup_networks/ball/params.json"),
+    "reach": ("REACH", {}, {}, 390, "target-point reaching task (SafeMotionsEnv, TargetPointReachingReward), ball machine mounted, 8 s episodes"),
+}
 
 
-def cpu_baseline(scene_config, seconds_target=12.0):
-    """The float64 CPU restatement (oracle/, kind "port") on the host cores, bounded sample."""
+def _env_config(name):
+    import safemotionsrisk_amd as smr
+    base, over, kw, algo, what = CONFIGS[name]
+    cfg = dict(getattr(smr, base + "_ENV_CONFIG"), **over)
+    return cfg, kw, algo, what
+
+
+def cpu_baseline(config_name, seconds_target=8.0):
+    """The float64 CPU restatement (oracle/, kind "port") on the host cores, bounded samples: all cores over 4096 envs, one
+    thread over 256 envs, and BASELINE configs[0] - ONE env, 1000 steps of uniform(-1,1,7) actions (PCG64 seed 0), auto-reset,
+    the loop shape of evaluate.py:198-303 with --random_agent (base.py:1047-1048)."""
     import numpy as np
     from safemotionsrisk_amd.scene import build_scene
     from oracle.oracle import OracleEnv
+    cfg, kw, _, _ = _env_config(config_name)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
-    B = 4096
-    scene = build_scene(scene_config, auto_reset=True)
-    env = OracleEnv(scene, B, seed=0, num_threads=cores)
+    scene = build_scene(cfg, auto_reset=True, **kw)
+
+    def run(B, threads, budget, max_steps):
+        env = OracleEnv(scene, B, seed=0, num_threads=threads)
+        env.reset()
+        rng = np.random.default_rng(0)
+        actions = [rng.uniform(-1, 1, (B, 7)) for _ in range(4)]
+        env.step(actions[0])
+        steps, t0 = 0, time.perf_counter()
+        while True:
+            env.step(actions[steps % 4])
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget or steps >= max_steps:
+                break
+        env.close()
+        return B * steps / el, steps
+
+    all_cores, steps_all = run(4096, cores, seconds_target, 400)
+    one_thread, steps_one = run(256, 1, seconds_target, 400)
+    # configs[0]: 1 env, 1000 random-action steps, auto-reset
+    env = OracleEnv(scene, 1, seed=0, num_threads=1)
     env.reset()
     rng = np.random.default_rng(0)
-    actions = [rng.uniform(-1, 1, (B, 7)) for _ in range(4)]
-    env.step(actions[0])
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        env.step(actions[steps % 4])
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_target or steps >= 400:
-            break
+    t0, episodes = time.perf_counter(), 0
+    for _ in range(1000):
+        _, _, done, _, _ = env.step(rng.uniform(-1, 1, (1, 7)))
+        episodes += int(done[0])
+    single = 1000 / (time.perf_counter() - t0)
     env.close()
-    return dict(value=B * steps / el, unit="env-steps/s", cores=cores, kind="port",
-                sample="%d envs x %d steps of the same space scene (auto-reset, uniform actions, OpenMP over envs, "
-                       "float64 oracle; kinematic step only, no Bullet physics sub-steps)" % (B, steps))
+    return dict(value=all_cores, unit="env-steps/s", cores=cores, kind="port",
+                sample="%d envs x %d steps of the same scene (auto-reset, uniform actions, OpenMP over envs, float64 oracle; kinematic step "
+                       "only - the reference additionally runs 24 Bullet physics sub-steps per step)" % (4096, steps_all),
+                one_thread={"value": one_thread, "cores": 1, "sample": "256 envs x %d steps" % steps_one},
+                config1_single_env={"value": single, "cores": 1, "episodes": episodes,
+                                    "sample": "BASELINE configs[0] shape: 1 env, 1000 uniform(-1,1,7) steps (PCG64 seed 0), auto-reset"})
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N fresh rank processes (this process has not touched the GPU and does not)."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (args.gpus, codes))
+
+
+def load_pmc(config_name, B, n_checks):
+    """profiles/round2_pmc_<config>.json (scripts/make_pmc_json.py from separate rocprofv3 --pmc passes of this command)"""
+    path = os.path.join(ROOT, "profiles", "round2_pmc_%s.json" % config_name)
+    if not os.path.exists(path):
+        return None, "no %s" % os.path.relpath(path, ROOT)
+    pmc = json.load(open(path))
+    meta = pmc.get("run", {})
+    if meta.get("envs_per_gpu") != B or meta.get("collision_checks_per_step") != n_checks:
+        return None, "%s was collected at %s envs / %s checks, this run has %d / %d" % (os.path.relpath(path, ROOT), meta.get("envs_per_gpu"),
+                                                                                     meta.get("collision_checks_per_step"), B, n_checks)
+    return pmc, os.path.relpath(path, ROOT)
 
 
 def main():
@@ -56,22 +140,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs-per-gpu", type=int, default=65536)
-    ap.add_argument("--checks", type=int, default=None, help="contact samples per step (default: from collision_check_time = 3)")
+    ap.add_argument("--config", default="space", choices=sorted(CONFIGS))
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--checks", type=int, default=None, help="contact samples per step (default 24 = the reference's cadence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step all-gather")
+    ap.add_argument("--no-info", action="store_true", help="do not write the per-step info matrix")
     args = ap.parse_args()
 
-    import torch
-    import __graft_entry__ as entry
-    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
-    from safemotionsrisk_amd.dist import ShardedRollout
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)                       # before anything in this process touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start one rank per GPU (python -m torch.distributed.run --nproc-per-node %d ... "
+                         "bench.py --gpus %d), or run without a launcher" % (args.gpus, world, args.gpus, args.gpus))
+
+    import torch
+    import __graft_entry__ as entry
+    from safemotionsrisk_amd import VecSafeMotionsEnv
+    from safemotionsrisk_amd.dist import ShardedRollout
+
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        raise SystemExit("rank %d: local GPU %d does not exist (%d visible): --gpus %d needs %d GPUs" % (rank, local_rank, n_dev, args.gpus, args.gpus))
     distributed = world > 1
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "safemotionsrisk_amd", "libsmr_hip.so")):
         entry.build()
@@ -82,9 +177,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist.barrier()
 
-    B = args.envs_per_gpu
-    env = VecSafeMotionsEnv(B, device=local_rank, seed=0, auto_reset=True, collision_checks_per_step=args.checks,
-                            return_info=False, env_index_offset=rank, **SPACE_ENV_CONFIG)
+    cfg, kw, algo_bytes, what = _env_config(args.config)
+    B = args.envs_per_gpu or (4096 if args.config == "space4096" else 65536)
+    if args.checks is not None:
+        kw = dict(kw, collision_checks_per_step=args.checks)
+    env = VecSafeMotionsEnv(B, device=local_rank, seed=0, auto_reset=True, return_info=not args.no_info, env_index_offset=rank, **kw, **cfg)
     rollout = ShardedRollout(env) if (distributed and not args.no_gather) else None
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
@@ -111,6 +208,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    env.synchronize()                                   # raises if a device-side error condition was latched during the run
     prof = env.get_profile()
     env.set_profiling(False)
     if distributed:
@@ -119,44 +217,37 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        n_checks = int(env.scene.struct.collision_checks_per_step)
+        s = env.scene.struct
+        n_checks = int(s.collision_checks_per_step)
         total_env_steps = B * world * args.steps
         kernels = {k: (v["ms"] / max(v["launches"], 1)) for k, v in prof.items()}
-        dominant = max(kernels, key=kernels.get)
-        dom_ms = kernels[dominant]
-        achieved = ALGO_BYTES_PER_ENV_STEP * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel: measured in separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE;
-        # FETCH_SIZE doubled on gfx950) of this command at the default configuration, committed under profiles/
-        traffic, pmc_note = None, ""
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_final_pmc.json")))
-            if B == 65536 and n_checks == 3 and world == 1:
-                traffic = pmc["kernels"]["smr::%s_kernel" % dominant]["hbm_bytes"]
-                pmc_note = "; traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from profiles/round1_final_pmc.json"
-        except Exception:
-            pass
-        # kernels on the critical path: the reset kernel of a scene without a ball runs on the side stream, overlapped
-        overlapped = ["reset"] if not env.scene.struct.use_ball and not os.environ.get("SMR_SYNC_RESET") == "1" else []
+        # kernels on the critical path: the staged refill (reset, and in ball / reaching scenes the staged launches / targets) runs on
+        # side streams, overlapped with the step kernels
+        overlapped = ["reset"] if os.environ.get("SMR_SYNC_RESET") != "1" else []
         critical = {k: v for k, v in kernels.items() if k not in overlapped}
-        if critical:
-            dominant = max(critical, key=critical.get)
-            dom_ms = critical[dominant]
-            achieved = ALGO_BYTES_PER_ENV_STEP * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            if traffic is not None:
-                try:
-                    traffic = pmc["kernels"]["smr::%s_kernel" % dominant]["hbm_bytes"]
-                except Exception:
-                    traffic = None
-        # what actually bounds the dominant kernel: vector issue.  Wave-level VALU instructions per launch (SQ_INSTS_VALU of the same
-        # PMC passes) x 4 cycles on one of the chip's 1024 SIMDs at 2.4 GHz, against the kernel's measured time
-        issue = None
-        try:
-            if traffic is not None:
-                valu = pmc["kernels"]["smr::%s_kernel" % dominant]["SQ_INSTS_VALU"]
-                floor_ms = valu * 4.0 / (1024 * 2.4e9) * 1e3
-                issue = {"valu_insts_per_launch": valu, "issue_floor_ms": floor_ms, "kernel_ms": dom_ms, "frac_of_peak_issue": floor_ms / dom_ms}
-        except Exception:
-            issue = None
+        dominant = max(critical, key=critical.get)
+        dom_ms = critical[dominant]
+        achieved = algo_bytes * B / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # measured counters of the same command (separate rocprofv3 --pmc passes, committed under profiles/)
+        pmc, pmc_note = load_pmc(args.config, B, n_checks) if world == 1 else (None, "PMC profiles are collected at N = 1")
+        traffic = traffic_step = issue = None
+        if pmc is not None:
+            kname = {"collide": "smr::collide_kernel<fin>", "sweep": "smr::collide_kernel<sweep>"}.get(dominant, "smr::%s_kernel" % dominant)
+            kk = pmc["kernels"].get(kname, {})
+            traffic = kk.get("hbm_bytes")
+            step_kernels = [k for k in pmc["kernels"] if not any(x in k for x in ("reset", "spawn<staged>", "target<staged>"))]
+            traffic_step = {"hbm_bytes": sum(pmc["kernels"][k].get("hbm_bytes", 0.0) * pmc["kernels"][k].get("launches_per_step", 1.0) for k in step_kernels),
+                            "algorithmic_bytes": algo_bytes * B, "kernels": step_kernels}
+            traffic_step["ratio"] = traffic_step["hbm_bytes"] / traffic_step["algorithmic_bytes"]
+            if "SQ_INSTS_VALU" in kk:
+                valu = kk["SQ_INSTS_VALU"]
+                floor_ms = valu * VALU_CYCLES_PER_WAVE_INST / (N_SIMD * CLOCK_HZ) * 1e3
+                issue = {"valu_insts_per_launch": valu, "cycles_per_wave_inst": VALU_CYCLES_PER_WAVE_INST, "issue_floor_ms": floor_ms,
+                         "kernel_ms": dom_ms, "frac_of_peak_issue": floor_ms / dom_ms,
+                         "lane_utilisation": kk.get("lane_utilisation"),
+                         "note": "wave-level VALU instructions x 2 cycles (wave64 on a SIMD-32, >= 2 waves per SIMD) / 1024 SIMDs / 2.4 GHz against "
+                                 "the kernel's measured time; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): the share of "
+                                 "the issued lanes that are switched on"}
         out = {
             "metric": "env-steps/sec at batch 65 536, 7-DoF space scene",
             "value": total_env_steps / elapsed,
@@ -170,23 +261,23 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d envs/GPU, space/planet scene (robot_scene=0, obstacle_scene=5, "
-                                   "planet_mode), dt=0.1, T=2.0, %d contact samples/step, auto-reset, uniform(-1,1) actions"
-                                   % (B, n_checks),
-                       "envs_per_gpu": B, "global_batch": B * world, "collision_checks_per_step": n_checks,
+            "config": {"workload": "%s; %d envs/GPU, dt=%.3g, T=%.3g, %d contact samples/step, auto-reset, uniform(-1,1) actions, info matrix %s"
+                                   % (what, B, s.dt, s.dt * s.episode_steps, n_checks, "off" if args.no_info else "on"),
+                       "name": args.config, "envs_per_gpu": B, "global_batch": B * world, "collision_checks_per_step": n_checks,
                        "all_gather": bool(rollout is not None), "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "note": "path is FP32-VALU/LDS-latency bound, not HBM bound (SURVEY section 0.5): %d algorithmic B per "
-                                 "env-step x %d envs per launch / mean %s-kernel time%s" % (ALGO_BYTES_PER_ENV_STEP, B, dominant, pmc_note)},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_step": traffic_step,
+                         "binding_resource": "fp32 vector issue + LDS latency (not HBM, SURVEY section 0.5): see vector_issue",
+                         "vector_issue": issue, "pmc": pmc_note,
+                         "note": "achieved = %d algorithmic B per env-step x %d envs per launch / mean %s-kernel time (HIP events on the "
+                                 "handle's stream); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch" % (algo_bytes, B, dominant)},
             "kernel_ms": kernels,
             "overlapped_kernels": overlapped,
         }
-        if issue is not None:
-            out["roofline"]["vector_issue"] = issue
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(SPACE_ENV_CONFIG)
+            out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out))
+        sys.stdout.flush()
     env.close()
     if distributed:
         dist.barrier()

@@ -32,12 +32,15 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 3
+#define SMR_ABI_VERSION 4
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
 #define SMR_E_HIP (-2)          /* a HIP runtime call failed                   */
 #define SMR_E_NO_DEVICE (-3)    /* no usable GPU (the library has no CPU path) */
+#define SMR_E_SAMPLING (-4)     /* a rejection-sampling loop of reset / ball launch / target point ran out of attempts (the
+                                   reference raises ValueError there, ctlp.py:2127-2136); detected on the device, reported by the
+                                   next synchronising call (smr_synchronize, smr_get_state, smr_set_state, smr_get_profile) */
 
 /* columns of the optional per-step info matrix (float32 [B][SMR_INFO_N]); the Python shim turns
  * them into the reference's info dict (base.py:1350-1386, rewards.py:490-498) */
@@ -53,11 +56,12 @@ extern "C" {
 
 /* kernels timed by smr_get_profile */
 #define SMR_K_PLAN 0      /* A2/A4: safe acceleration range + action mapping            */
-#define SMR_K_COLLIDE 1   /* A3/A6/A7/A8/A11: cubic sample, FK, GJK distances, contacts  */
+#define SMR_K_COLLIDE 1   /* A3/A6/A7/A8/A11: end-of-step sample: FK, GJK distances, contact   */
 #define SMR_K_FINISH 2    /* A1/A12/A13/A15/A16: state update, reward, termination, obs  */
 #define SMR_K_RESET 3     /* A17/A9: start-state and planet-phase sampling               */
 #define SMR_K_SPAWN 4     /* A10: a new ball for the envs whose ball was retired         */
-#define SMR_K_COUNT 5
+#define SMR_K_SWEEP 5     /* A11: contact sweep over the intermediate samples 1 .. N-1    */
+#define SMR_K_COUNT 6
 
 typedef struct smr_env smr_env_t;   /* opaque */
 

@@ -6,5 +6,5 @@ Host mirror of the reference's env surface over a C-ABI library of HIP kernels (
 interface (metrics.py).
 """
 from .scene import SPACE_ENV_CONFIG, BALL_ENV_CONFIG, REACH_ENV_CONFIG, build_scene  # noqa: F401
-from .env import VecSafeMotionsEnv, SafeMotionsEnvCollisionAvoidance  # noqa: F401
+from .env import VecSafeMotionsEnv, SafeMotionsEnvCollisionAvoidance, SafeMotionsEnv  # noqa: F401
 from .metrics import EpisodeMetrics, RllibVectorEnv  # noqa: F401

@@ -92,6 +92,12 @@ struct DScene {
     // in LDS for the lane-autonomous planet queries (planets_auto = 0: does not fit, wave-lockstep queries)
     int planets_auto, planet_p0, planet_pn, planet_vn;   // planet_vn: vertex slots of auto_verts (4 floats each)
     int body_order[SMR_MAX_BODIES];   // dispatch order of the bodies in the collide grid (longest-running first)
+    // conservative advancement over the intermediate contact samples (contact sweep, below): no point of body b moves faster than
+    // sum_j |qdot_j| sweep_R[b][j]; no point of planet p moves farther than planet_step[p] per orbit index; the ball stays inside
+    // the sphere of radius ball_bound_radius (margin included) about its frame origin
+    float sweep_R[SMR_MAX_BODIES][SMR_NJ];
+    float planet_step[SMR_MAX_PLANETS];
+    float ball_bound_radius;
     const float *auto_verts;   // the planet pieces' vertices, every piece padded to a multiple of 4 with its last vertex
     const float *auto_desc;    // kPlanetDescDwords per piece: first slot, padded count, margin, planet (0 / 1), centre xyz
     float planet_obs_min[3], planet_obs_max[3];
@@ -127,7 +133,8 @@ struct DState {
     int *moving_hit;           // [B]
     unsigned *reset_count;     // [B]  number of resets of the env = Philox tag of its next reset
     float *a1;                 // [7][B]   plan -> collide/finish
-    float *res;                // [N][8][B] collide -> finish: contact flag of (sample k, link l)
+    float *res;                // [2][n_bodies][B] collide -> finish: contact flag of body l at the end-of-step sample [0] and at any
+                               // of the intermediate samples 1 .. N-1 [1] (N > 1)
     float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
     int *done_list;            // [B]
     int *done_count;           // [1]
@@ -166,7 +173,15 @@ struct DState {
     int *refill_count;                 // the counter of THIS step's list: two slots alternate, finish clears the other one
     int *refill_zero;                  // ... (refill_zero, or null) so that no memset sits between the step's kernels
     int *stale_commits;                // [1]  commits that found no matching staged state (must stay 0)
+    int *error_flags;                  // [1]  kSampling* bits: a bounded rejection-sampling loop ran out of attempts (the reference raises
+                                       //      ValueError there, ctlp.py:2127-2136); reported by the next synchronising call
 };
+
+enum { kSamplingStart = 1, kSamplingPlanetPhase = 2, kSamplingBallLaunch = 4, kSamplingBallTarget = 8, kSamplingTargetPoint = 16,
+       kSamplingBallInitialStep = 32, kSamplingKinematicState = 64 };
+#ifndef SMR_HOST_EMUL
+__device__ __forceinline__ void sampling_exhausted(const DState &st, int bit) { atomicOr(st.error_flags, bit); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // small vector algebra
@@ -1310,6 +1325,165 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A11, the intermediate contact samples k = 1 .. N-1 of a step (the reference tests contact after every one of its 24 obstacle
+// updates per step, ctlp.py:2631-2637,2849-2861): conservative advancement instead of N full evaluations.  At a sample the lane
+// computes a rigorous LOWER bound of the distance between its body and every moving piece (bounding spheres, then capsules).
+// Between two samples no point of the body moves farther than (dt / N) sum_j max|qdot_j| sweep_R[b][j] and no point of a moving
+// obstacle farther than its per-update bound, so the samples k + 1 .. k + m are contact free while m x that motion stays below
+// bound - contact_dist: the lane jumps over them.  Only a sample whose bound does not clear the contact distance gets the real
+// query.  The flags are those of testing all N samples (which is what the float64 oracle does); nearly every (env, body) lane
+// is through after one or two bound evaluations, so N = 24 costs about what N = 1 does.
+// ---------------------------------------------------------------------------------------------
+// largest |velocity| of a constant-jerk segment (v0, a0 -> a1 over dt), rounded up
+__device__ __forceinline__ float cubic_speed_bound(float v0, float a0, float a1, float dt) {
+    const float v1 = v0 + 0.5f * (a0 + a1) * dt;
+    float m = fmaxf(fabsf(v0), fabsf(v1));
+    if (a0 * a1 < 0.f) m = fmaxf(m, fabsf(v0 + 0.5f * a0 * (a0 * dt / (a0 - a1))));   // the acceleration changes sign inside the step
+    return m * 1.00001f + 1e-7f;
+}
+
+// number of samples after the current one that a lower bound lb (> contact_dist) rules out, motion per sample `step` (> 0)
+__device__ __forceinline__ int sweep_skip(float lb, float contact_dist, float step) {
+    const float x = (lb - contact_dist - 1e-6f) / (step * 1.0001f + 1e-7f);      // i <= x  =>  i step < lb - contact_dist
+    return x > 0.f ? (int)fminf(x, 1.0e6f) : 0;
+}
+
+// Lower bound of the distance (margins subtracted) between the body (piece LP under T) and every piece of the planets at orbit
+// indices idx.  A bound above `enough` is returned as soon as it is known (whole-planet spheres, then piece spheres); only pieces
+// that stay below it get the capsule-capsule bound.  Piece loads are wave uniform (scalar).
+__device__ inline float planets_lower_bound(const DScene &S, const DPiece &LP, const Xf &T, const int idx[SMR_MAX_PLANETS], float enough) {
+    const F3 lc = apply(T, F3{LP.cx, LP.cy, LP.cz});
+    const F3 l0 = apply(T, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), l1 = apply(T, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
+    float lb = 3.0e38f;
+    for (int p = 0; p < S.n_planets; ++p) {
+        const Xf X = planet_pose(S, p, idx[p]);
+        const F3 e = apply(X, F3{S.planet[p].bx, S.planet[p].by, S.planet[p].bz}) - lc;
+        const float lbw = sqrtf(dot(e, e)) * 0.99999f - 1e-6f - S.planet[p].bradius - LP.radius - LP.margin;
+        float lbp = lbw;
+        if (__any(lbw <= enough)) {                           // some lane of the wavefront is near this planet: its pieces
+            float m = 3.0e38f;
+            const int pb = S.planet[p].piece_begin, pc = S.planet[p].piece_count;
+            for (int c = 0; c < pc; ++c) {
+                const DPiece PP = load_piece(S.pieces, pb + c);
+                const float margins = PP.margin + LP.margin;
+                const F3 dc = apply(X, F3{PP.cx, PP.cy, PP.cz}) - lc;
+                float b = sqrtf(dot(dc, dc)) * 0.99999f - 1e-6f - PP.radius - LP.radius - margins;
+                if (b <= enough && lbw <= enough) {
+                    const F3 a0 = apply(X, F3{PP.cap_a[0], PP.cap_a[1], PP.cap_a[2]}), a1 = apply(X, F3{PP.cap_b[0], PP.cap_b[1], PP.cap_b[2]});
+                    b = fmaxf(b, sqrtf(seg_seg_dist2(a0, a1, l0, l1)) * 0.99999f - 1e-6f - PP.cap_r - LP.cap_r - margins);
+                }
+                m = fminf(m, b);
+            }
+            if (lbw <= enough) lbp = fmaxf(lbw, m);
+        }
+        lb = fminf(lb, lbp);
+    }
+    return lb;
+}
+
+// ... and against the ball at pose XB: the ball piece lies inside the sphere of radius ball_bound_radius about its frame origin
+__device__ inline float ball_lower_bound(const DScene &S, const DPiece &LP, const Xf &T, const Xf &XB) {
+    const F3 lc = apply(T, F3{LP.cx, LP.cy, LP.cz});
+    const F3 l0 = apply(T, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), l1 = apply(T, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
+    const F3 e = XB.t - lc;
+    const float lb_s = sqrtf(dot(e, e)) * 0.99999f - 1e-6f - LP.radius;
+    const float lb_c = sqrtf(seg_seg_dist2(XB.t, XB.t, l0, l1)) * 0.99999f - 1e-6f - LP.cap_r;
+    return fmaxf(lb_s, lb_c) - S.ball_bound_radius - LP.margin;
+}
+
+// One lane of the collide kernel: body l of one env, either its end-of-step sample (fin: table / planet / ball distances of the
+// reward and the contact test at t = dt) or its contact sweep over the samples 1 .. N-1.  The state is read through strided
+// pointers (the kernel: [component][B] arrays; the host emulation: plain arrays).
+struct LaneInput {
+    const float *q, *v, *a, *a1; int stride;           // joint j at [j * stride]
+    int planet_idx[SMR_MAX_PLANETS], moving_hit;
+    BallState ball; int ball_k0, ball_kmax, ball_khit, ball_active;
+};
+struct LaneResult { bool contact; float d_static, d_moving; int evals, queries; };
+
+template <bool SELF, bool AUTO, bool fin, class HB>
+__device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &LP, const HB &hull, const LaneInput &in,
+                                          const float *lds_pv, const float *lds_pd, uint32_t *keys, int kstride) {
+    LaneResult out = {false, S.static_max, S.moving_max + 0.002f, 0, 0};
+    const int N = S.checks_per_step, upd = S.updates_per_step / N;
+    const bool con_link = (S.contact_mask >> l) & 1u;
+    bool want_contact, moving_alive = true;
+    int k_last = N - 1;                                 // sweep: last sample to test
+    if (S.use_ball) {
+        // the ball is tested at a sample only while it is in flight (ctlp.py:2836-2861): not yet retired by the
+        // update counters, and inside the 1.25 m cylinder around the robot
+        const int u_end = ball_retire_update(S, in.ball_k0, in.ball_kmax, in.ball_khit);
+        moving_alive = in.ball_active && (N * upd < u_end);       // at the end-of-step sample
+        want_contact = (fin ? moving_alive : in.ball_active != 0) && con_link;
+        const int kl = (u_end - 1) / upd;                          // samples with k upd < u_end
+        k_last = kl < k_last ? kl : k_last;
+    } else {
+        want_contact = S.term_moving && S.n_planets > 0 && in.moving_hit == 0 && con_link;
+    }
+    const bool want_static = fin && ((S.static_mask >> l) & 1u);
+    const bool want_moving = fin && moving_alive && ((S.moving_mask >> l) & 1u);
+    int k = fin ? N : 1;
+    bool alive = fin ? (want_static || want_moving || want_contact) : (want_contact && k <= k_last);
+    if (!alive) return out;
+    const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
+    float step = 0.f;                                   // sweep: no point of the body or of a moving piece moves farther between two samples
+    if (!fin) {
+        for (int j = 0; j < chain; ++j) step += cubic_speed_bound(in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], S.dt) * S.sweep_R[l][j];
+        step *= S.dt / (float)N;
+        if (S.use_ball) {
+            const float udt = S.dt / (float)S.updates_per_step, t0 = (float)in.ball_k0 * udt, t1 = t0 + S.dt;
+            const float vz = fmaxf(fabsf(in.ball.v0[2] - 9.81f * t0), fabsf(in.ball.v0[2] - 9.81f * t1));
+            step += sqrtf(in.ball.v0[0] * in.ball.v0[0] + in.ball.v0[1] * in.ball.v0[1] + vz * vz) * 1.0001f * udt * (float)upd;
+        } else {
+            float ps = 0.f;
+            for (int p = 0; p < S.n_planets; ++p) ps = fmaxf(ps, S.planet_step[p]);
+            step += ps * (float)upd;
+        }
+    }
+    for (int round = 0; round < (fin ? 1 : N); ++round) {
+        Xf T = fk_base(S), XB = T;
+        int idx[SMR_MAX_PLANETS] = {0, 0};
+        bool pending = false;
+        while (alive && !pending) {                     // sweep: bound evaluations until a sample needs the real query (fin: once)
+            const float t = fin ? S.dt : S.dt * (float)k / (float)N;
+            T = fk_base(S);
+            for (int j = 0; j < chain; ++j)             // FK up to this body's link; joint values straight from the cubic
+                fk_advance(S, j, interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt), T);
+            if (SELF && l >= SMR_NLINK) T = mounted_frame(S, l, T);
+            if (S.use_ball) XB = ball_pose(S, in.ball, in.ball_k0 + k * upd, nullptr);
+            else {
+#pragma unroll
+                for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+                    if (p < S.n_planets) idx[p] = (in.planet_idx[p] + k * upd) % S.planet[p].n_orbit;
+            }
+            if (fin) { pending = true; break; }
+            ++out.evals;
+            const float lb = S.use_ball ? ball_lower_bound(S, LP, T, XB)
+                                        : planets_lower_bound(S, LP, T, idx, S.contact_dist + step * (float)(k_last - k + 1));
+            if (lb > S.contact_dist) { k += 1 + sweep_skip(lb, S.contact_dist, step); alive = k <= k_last; }
+            else pending = true;
+        }
+        if (!__any(pending)) break;
+        const bool con = fin ? want_contact : pending;
+        if (pending) ++out.queries;
+        Sample r;
+        if (S.use_ball) {
+            const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
+            r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, con && near);
+        } else {
+            r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, con, nullptr, AUTO);
+            if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, con, r);
+        }
+        if (fin) { out.contact = r.contact; out.d_static = r.d_static; out.d_moving = r.d_moving; return out; }
+        if (pending) {
+            if (r.contact) { out.contact = true; alive = false; }
+            else { k += 1; alive = k <= k_last; }
+        }
+    }
+    return out;
 }
 
 // A15: planet part of the observation (obs.py:262-292)

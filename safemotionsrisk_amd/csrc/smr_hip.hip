@@ -2,13 +2,13 @@
 //
 // step() = three launches on the handle's stream (+ one for the envs that finished):
 //   plan    (B x 7 lanes)  A2/A4  safe acceleration range of the current state, action -> end acceleration
-//   collide (B x N x 8 lanes)  A3/A6/A7/A8/A11  (sample k of the cubic, link l): FK + GJK contact test; the last
-//                          sample also yields the table / planet minimum distances of the reward
+//   collide (B x 2 x 8 lanes)  A3/A6/A7/A8/A11  (end-of-step sample | contact sweep, link l): FK + GJK distances of the reward and
+//                          the contact test at the end of the step; the N-1 intermediate contact samples of a link by
+//                          conservative advancement in one lane
 //   finish  (B lanes)      A1/A12/A13/A15/A16  latch, state update, reward, termination, observation,
 //                          wave-aggregated append of finished envs to the reset list
 //   reset   (B lanes, only list entries work)  A17/A9  start state + planet phase by rejection sampling
-// The B x N x 8 grid of `collide` puts every (sample, link) on its own lane: 24x (N=3) the wavefronts of a
-// one-lane-per-env launch.  The GJK loops are divergent and wait on scalar loads; only many resident
+// The B x 2 x 8 grid of `collide` puts every link on its own lane: 8-16x the wavefronts of a one-lane-per-env launch.  The GJK loops are divergent and wait on scalar loads; only many resident
 // wavefronts per SIMD keep the 1024 SIMDs of the chip busy at B = 65 536.
 #include <hip/hip_runtime.h>
 
@@ -43,38 +43,36 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
 }
 
-// one lane per (env, sample k, body l); grid = (B/64, N, n_bodies)
+// one lane per (env, body l); grid = (B / block, self pairs + n_bodies).  FIN: the end-of-step sample k = N (distances of the reward
+// + its contact test); !FIN: the intermediate contact samples 1 .. N-1 of a body, by conservative advancement in one lane
+// (smr_device.h, "contact sweep") - its own kernel so that its loop state does not cost the end-of-step path registers
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
 // SELF: the scene has self-collision pairs (ball machine); the plain robot runs the instantiation without that code
 // AUTO: lane-autonomous planet queries (planet_queries_auto); four wavefronts then share the LDS copies
-template <bool SELF, bool AUTO>
+template <bool SELF, bool AUTO, bool FIN>
 __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = AUTO ? 256 : 64;
-    // grid (env block, body, sample), the sample slowest: ALL end-of-step blocks - the long ones - are dispatched before the
-    // contact-only samples, which then fill the machine while the last heavy wavefronts finish.
     // grid y: first the self-collision pairs (SELF; they only work at the end-of-step sample), then the bodies, outer ones
     // (most planet work) first
-    const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
-    const bool pair_block = SELF && (int)blockIdx.y < n_pair_blocks;
+    const int n_pair_blocks = (SELF && FIN) ? S.n_self_pairs : 0;
+    const bool pair_block = SELF && FIN && (int)blockIdx.y < n_pair_blocks;
     const int pair = pair_block ? (int)blockIdx.y : 0;
-    if (pair_block && blockIdx.z != 0) return;
     // the body whose hull this block climbs over: its own body, or for a pair block the partner link (the ball machine
     // piece is then the scanned A side; with the base adapter as partner the piece itself is staged)
     const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0])
                              : S.body_order[(int)blockIdx.y - n_pair_blocks];
-    if (!pair_block) {                                   // nothing to do for this (sample, body): leave before anything is staged
-        const bool fin = (int)blockIdx.z == 0;
+    if (!pair_block) {                                   // nothing to do for this (block kind, body): leave before anything is staged
+        constexpr bool fin = FIN;
         const bool any = (fin && (((S.static_mask | S.moving_mask) >> l) & 1u)) || ((S.contact_mask >> l) & 1u) || (fin && SELF);
         if (!any) {
-            if (fin) {                                   // finish reads these
-                const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
-                if (e0 < S.B) { st.dist[(size_t)l * S.B + e0] = S.static_max; st.dist[(size_t)(S.n_bodies + l) * S.B + e0] = S.moving_max + 0.002f; }
-            }
             const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
-            if (e0 < S.B) st.res[((size_t)(S.checks_per_step - (int)blockIdx.z - 1) * S.n_bodies + l) * S.B + e0] = 0.f;
+            if (e0 < S.B) {
+                if (fin) { st.dist[(size_t)l * S.B + e0] = S.static_max; st.dist[(size_t)(S.n_bodies + l) * S.B + e0] = S.moving_max + 0.002f; }   // finish reads these
+                st.res[((size_t)(FIN ? 0 : 1) * S.n_bodies + l) * S.B + e0] = 0.f;
+            }
             return;
         }
     }
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     if (e >= S.B) return;
     const int B = S.B, N = S.checks_per_step;
     const int NB = S.n_bodies;
-    if (SELF && pair_block) {
+    if (SELF && FIN && pair_block) {
         // A7 self, pair (a, partner) at the end of the step (ctlp.py:3345-3372): distance in dist[2 NB + pair]
         float qs[SMR_NJ];
 #pragma unroll
@@ -127,52 +125,19 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
         st.dist[(size_t)(2 * NB + pair) * B + e] = d <= S.static_max ? d : S.static_max;
         return;
     }
-    const int k = N - (int)blockIdx.z;                 // sample k of N, t_k = k dt / N; the end-of-step sample (distances) first
-    const bool final_sample = (k == N);
-    const int upd = S.updates_per_step / N;
-    float *res = st.res + ((size_t)(k - 1) * NB + l) * B;
-    const bool con_link = (S.contact_mask >> l) & 1u;
-    bool want_contact, moving_alive = true;
-    BallState ball;
-    int ball_k = 0;
+    float *res = st.res + ((size_t)(FIN ? 0 : 1) * NB + l) * B;
+    LaneInput in;
+    in.q = st.q + e; in.v = st.v + e; in.a = st.a + e; in.a1 = st.a1 + e; in.stride = B;
+    in.planet_idx[0] = st.planet_idx[e]; in.planet_idx[1] = st.planet_idx[B + e];
+    in.moving_hit = st.moving_hit[e];
+    in.ball_k0 = 0; in.ball_kmax = 0; in.ball_khit = 0; in.ball_active = 0;
     if (S.use_ball) {
-        // the ball is tested at this sample only while it is in flight (ctlp.py:2836-2861): not yet retired by the
-        // update counters, and inside the 1.25 m cylinder around the robot
-        const int k0 = st.ball_i[e], active = st.ball_i[3 * B + e];
-        const int u_end = ball_retire_update(S, k0, st.ball_i[B + e], st.ball_i[2 * B + e]);
-        moving_alive = active && (k * upd < u_end);
-        ball = load_ball(st, B, e);
-        ball_k = k0 + k * upd;
-        want_contact = moving_alive && con_link;
-    } else {
-        want_contact = S.term_moving && S.n_planets > 0 && st.moving_hit[e] == 0 && con_link;
+        in.ball = load_ball(st, B, e);
+        in.ball_k0 = st.ball_i[e]; in.ball_kmax = st.ball_i[B + e]; in.ball_khit = st.ball_i[2 * B + e]; in.ball_active = st.ball_i[3 * B + e];
     }
-    const bool want_static = final_sample && ((S.static_mask >> l) & 1u);
-    const bool want_moving = final_sample && moving_alive && ((S.moving_mask >> l) & 1u);
-    if (final_sample) { st.dist[(size_t)l * B + e] = S.static_max; st.dist[(size_t)(NB + l) * B + e] = S.moving_max + 0.002f; }
-    res[e] = 0.f;
-    if (!want_static && !want_moving && !want_contact) return;
-    const float t = final_sample ? S.dt : S.dt * (float)k / (float)N;
-    const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
-    Xf T = fk_base(S);
-    for (int j = 0; j < chain; ++j)                    // FK up to this body's link; joint values straight from the cubic
-        fk_advance(S, j, interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt), T);
-    if (SELF && l >= SMR_NLINK) T = mounted_frame(S, l, T);
-    Sample r;
-    if (S.use_ball) {
-        Xf XB = ball_pose(S, ball, ball_k, nullptr);
-        const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near);
-    } else {
-        int idx[SMR_MAX_PLANETS] = {0, 0};
-#pragma unroll
-        for (int p = 0; p < SMR_MAX_PLANETS; ++p)
-            if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
-        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, nullptr, AUTO);
-        if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock, LP, hull, T, idx, want_moving, want_contact, r);
-    }
+    const LaneResult r = collide_lane<SELF, AUTO, FIN>(S, l, LP, hull, in, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock);
     res[e] = r.contact ? 1.f : 0.f;
-    if (final_sample) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving; }
+    if (FIN) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving; }
 }
 
 // env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
@@ -239,7 +204,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     int hit = st.moving_hit[e];
     int contact = 0;
     const int NB = S.n_bodies;
-    for (int k = 0; k < N * NB; ++k) contact |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;
+    for (int k = 0; k < (N > 1 ? 2 : 1) * NB; ++k) contact |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;   // end-of-step sample | samples 1 .. N-1
     if (S.term_moving && S.n_planets > 0) hit |= contact;                     // ctlp.py:2631-2637
     float d_static = S.static_max, d_self = S.static_max, d_moving = S.moving_max + 0.002f;
     for (int l = 0; l < NB; ++l) {                                            // minimum over bodies, ctlp.py:3263-3278,3294-3372
@@ -554,23 +519,26 @@ struct BallSpawn { float p0[3], v0[3], e0[3], omega; int kmax, khit; };
 // _add_moving_object, ctlp.py:1723-1931, by a group of 8 lanes: candidate target poses one after the other, each
 // tested link-parallel; the scalar launch arithmetic is computed redundantly by all lanes, in float64.
 template <bool EXTRA>
-__device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, const Group &G) {
+__device__ inline BallSpawn spawn_ball_group(const DScene &S, const DState &st, const Rng &rng, const Group &G) {
     const int jj = G.g < SMR_NJ ? G.g : 0;
     const double udt = S.dt64 / S.updates_per_step, v = S.ball_speed, grav = 9.81;
     double rel[3] = {0, 0, 0}, vel[3] = {0, 0, 1};
     unsigned pose_attempt = 0;
+    bool launched = false;
     for (unsigned n = 0; n < 25000u; ++n) {
         const double h = rng.uniformd(S_BALL_RELEASE, 3u * n, S.ball_height[0], S.ball_height[1]);       // ctlp.py:1943-1952
         const double r = sqrt(S.ball_sphere_radius * S.ball_sphere_radius - h * h);
         const double ang = rng.uniformd(S_BALL_RELEASE, 3u * n + 1u, S.ball_angle[0], S.ball_angle[1]);
         rel[0] = S.ball_center[0] + r * cos(ang); rel[1] = S.ball_center[1] + r * sin(ang); rel[2] = S.ball_center[2] + h;
         double target[3] = {0, 0, 0};
+        bool have_target = false;
         for (int tries = 0; tries < 25000; ++tries) {                                                       // ctlp.py:1782-1790
             float q[SMR_NJ];
             G.gather(rng.uniform(S_BALL_POSE, 7u * pose_attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
             ++pose_attempt;
-            if (group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); break; }
+            if (group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); have_target = true; break; }
         }
+        if (!have_target) { if (G.g == 0) sampling_exhausted(st, kSamplingBallTarget); break; }            // ctlp.py:2127-2136 raises
         const double dx = target[0] - rel[0], dy = target[1] - rel[1], dh = target[2] - rel[2];
         const double dxy = sqrt(dx * dx + dy * dy);
         const double sq = v * v * v * v - grav * (grav * dxy * dxy + 2 * dh * v * v);                      // ctlp.py:1797
@@ -591,8 +559,9 @@ __device__ inline BallSpawn spawn_ball_group(const DScene &S, const Rng &rng, co
                 if (in_top || in_bot) valid = false;
             }
         }
-        if (valid) break;
+        if (valid) { launched = true; break; }
     }
+    if (!launched && G.g == 0) sampling_exhausted(st, kSamplingBallLaunch);
     BallSpawn out;
     for (int c = 0; c < 3; ++c) { out.p0[c] = (float)rel[c]; out.v0[c] = (float)vel[c]; }
     out.omega = (float)rng.uniformd(S_BALL_MISC, 0u, 0.0, 2.0 * 3.14159265358979323846);                   // ctlp.py:4056-4057
@@ -687,7 +656,7 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
     const size_t sl = (size_t)(spawns & 1u);
     if (STAGE) {
-        const BallSpawn b = spawn_ball_group<EXTRA>(S, rng, G);
+        const BallSpawn b = spawn_ball_group<EXTRA>(S, st, rng, G);
         if (g == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) { st.next_ball[(sl * 10 + c) * B + e] = b.p0[c]; st.next_ball[(sl * 10 + 3 + c) * B + e] = b.v0[c]; st.next_ball[(sl * 10 + 6 + c) * B + e] = b.e0[c]; }
@@ -706,7 +675,7 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
         b.kmax = st.next_ball_i[(sl * 2) * B + e]; b.khit = st.next_ball_i[(sl * 2 + 1) * B + e];
     }
     if (G.any(!have)) {                                  // nothing matching staged for this group: draw it now
-        const BallSpawn b2 = spawn_ball_group<EXTRA>(S, rng, G);
+        const BallSpawn b2 = spawn_ball_group<EXTRA>(S, st, rng, G);
         if (!have) b = b2;
     }
     BallState bs;
@@ -720,10 +689,12 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
         int kcap = b.kmax < b.khit ? b.kmax : b.khit;
         int max_ts = kcap / S.updates_per_step;
         if (max_ts < 0) max_ts = 0;
-        for (unsigned n = 0; n < 100000u; ++n) {
+        bool free_step = false;
+        for (unsigned n = 0; n < 100000u && !free_step; ++n) {
             k0 = rng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
-            if (!group_ball_contact<EXTRA>(S, G, q, ball_pose(S, bs, k0, nullptr))) break;
+            free_step = !group_ball_contact<EXTRA>(S, G, q, ball_pose(S, bs, k0, nullptr));
         }
+        if (!free_step && g == 0) sampling_exhausted(st, kSamplingBallInitialStep);
     }
     if (g == 0) {
         store_ball(st, B, e, b, k0, spawns + 1u);
@@ -753,10 +724,12 @@ __global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ S
     const unsigned count = STAGED ? (tags ? tags[i] : st.tp_count[e] + (unsigned)tag_offset) : st.tp_count[e];
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, count};
     float q[SMR_NJ];
-    for (unsigned m = 0; m < 100000u; ++m) {
+    bool found = false;
+    for (unsigned m = 0; m < 100000u && !found; ++m) {
         G.gather(rng.uniform(S_TARGET, 7u * m + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
-        if (group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.target_min_static, S.target_min_self)) break;
+        found = group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.target_min_static, S.target_min_self);
     }
+    if (!found && g == 0) sampling_exhausted(st, kSamplingTargetPoint);                                   // ctlp.py:2127-2136 raises
     if (g == 0 && STAGED) {
         const F3 target = ee_point(S, q);
         const size_t sl = (size_t)(count & 1u);
@@ -821,6 +794,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
             ++attempt;
             if (group_pose_valid<EXTRA>(S, G, q, S.start_box, S.start_min_static, S.start_min_self)) return;
         }
+        if (g == 0) sampling_exhausted(st, kSamplingStart);                                               // ctlp.py:2127-2136 raises
     };
     next_position();
 
@@ -831,6 +805,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         qj = q[jj];
     } else if (S.kin_mode && rng.uniform01(S_MODE, 0) < S.kin_prob) {                   // ctlp.py:1494-1556
         for (unsigned round = 0;; ++round) {
+            if (round >= 4096u) { if (g == 0) sampling_exhausted(st, kSamplingKinematicState); break; }    // the reference loops on (ctlp.py:1499-1556)
             bool found = (g >= SMR_NJ);
             const float qme = q[jj];
             // the group walks the 5 x 10 (velocity, acceleration) tries in lockstep; a lane that has its pair tags along
@@ -890,7 +865,8 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         int n_indep = 0;
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p) n_indep += (p < S.n_planets && !S.planet[p].coupled) ? 1 : 0;
-        for (unsigned n = 0; n < 100000u; ++n) {
+        bool free_phase = false;
+        for (unsigned n = 0; n < 100000u && !free_phase; ++n) {
             int k = 0;
 #pragma unroll
             for (int p = 0; p < SMR_MAX_PLANETS; ++p) {
@@ -899,8 +875,9 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
                 if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % no + no) % no;
                 else idx[p] = rng.randint(S_PLANET, n * (unsigned)n_indep + (unsigned)(k++), no);
             }
-            if (!group_planet_contact<EXTRA>(S, G, q, idx)) break;
+            free_phase = !group_planet_contact<EXTRA>(S, G, q, idx);
         }
+        if (!free_phase && g == 0) sampling_exhausted(st, kSamplingPlanetPhase);                          // the reference loops on (ctlp.py:4477-4490)
         // obstacle_wrapper.update(update_after_reset=True): one planet update + contact check,
         // base.py:980-985, ctlp.py:2626-2637
 #pragma unroll
@@ -922,7 +899,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
     if (S.use_ball) {
         ball_spawns = (unsigned)st.ball_i[4 * B + e];
         const Rng brng = {S.seed_lo, S.seed_hi, (unsigned)e, ball_spawns};
-        bsp = spawn_ball_group<EXTRA>(S, brng, G);
+        bsp = spawn_ball_group<EXTRA>(S, st, brng, G);
         if (S.ball_random_initial) {
             BallState bs;
             for (int c = 0; c < 3; ++c) { bs.p0[c] = bsp.p0[c]; bs.v0[c] = bsp.v0[c]; bs.e0[c] = bsp.e0[c]; }
@@ -930,10 +907,12 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
             int kcap = bsp.kmax < bsp.khit ? bsp.kmax : bsp.khit;
             int max_ts = kcap / S.updates_per_step;
             if (max_ts < 0) max_ts = 0;
-            for (unsigned n = 0; n < 100000u; ++n) {
+            bool free_step = false;
+            for (unsigned n = 0; n < 100000u && !free_step; ++n) {
                 ball_k0 = brng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
-                if (!group_ball_contact<EXTRA>(S, G, q, ball_pose(S, bs, ball_k0, nullptr))) break;
+                free_step = !group_ball_contact<EXTRA>(S, G, q, ball_pose(S, bs, ball_k0, nullptr));
             }
+            if (!free_step && g == 0) sampling_exhausted(st, kSamplingBallInitialStep);
         }
     }
 
@@ -1087,6 +1066,7 @@ struct smr_env {
     int *spawn_lists = nullptr, *spawn_counts = nullptr;   // two spawn lists: the side stream re-stages from one while finish fills the other
     bool stage_balls = false;
     int parity = 0;
+    bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
     DState st;
     std::vector<void *> allocs;
@@ -1184,7 +1164,9 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
         q.coupled = pl.coupled; q.radius_x = (float)pl.radius_xy[0]; q.radius_y = (float)pl.radius_xy[1];
         q.orbit_pose = dpose; q.orbit_local = dlocal;
         planet_bounds(pieces, q);
+        d.planet_step[p] = planet_step_bound(G, q, pose.data());
     }
+    sweep_tables(s, G, d);
     copy3(d.planet_obs_min, s.planet_obs_pos_min); copy3(d.planet_obs_max, s.planet_obs_pos_max);
     d.use_ball = s.use_ball; d.dt64 = s.dt;
     planet_tables(G, d);
@@ -1317,7 +1299,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)env->N * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)2 * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)) || (rc = dev_alloc(env, &env->spawn_tag_lists, 3 * B)))
         return fail(rc);
@@ -1328,8 +1310,8 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     if ((rc = dev_alloc(env, &st.tp, 5 * B)) || (rc = dev_alloc(env, &st.tp_count, B)) || (rc = dev_alloc(env, &st.tp_list, B)) ||
-        (rc = dev_alloc(env, &st.tp_list_count, 1))) return fail(rc);
-    if (hipMemset(st.tp, 0, 5 * B * 4) || hipMemset(st.tp_count, 0, B * 4) || hipMemset(st.tp_list_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+        (rc = dev_alloc(env, &st.tp_list_count, 1)) || (rc = dev_alloc(env, &st.error_flags, 1))) return fail(rc);
+    if (hipMemset(st.tp, 0, 5 * B * 4) || hipMemset(st.tp_count, 0, B * 4) || hipMemset(st.tp_list_count, 0, 4) || hipMemset(st.error_flags, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     // staged start states (robot part; in ball scenes spawn_kernel draws the ball at commit time)
     {
         const char *off = std::getenv("SMR_SYNC_RESET");          // debugging / A-B measurement: reset on the critical path
@@ -1539,7 +1521,19 @@ static void staged_select_lists(smr_env *env, int r) {
     env->st.refill_list = env->refill_lists + r * B; env->st.refill_tags = env->refill_tag_lists + r * B; env->st.refill_count = env->refill_slots + r;
     if (env->tp_refill_slots) { env->st.tp_refill_list = env->tp_refill_lists + r * B; env->st.tp_refill_tags = env->tp_refill_tag_lists + r * B; env->st.tp_refill_count = env->tp_refill_slots + r; }
 }
-static int staged_check(smr_env *env) {                // after a synchronisation: no commit may have missed its staged state
+static int staged_check(smr_env *env) {                // after a synchronisation: device-side error conditions of the steps since the last one
+    int flags = 0;
+    SMR_HIP(hipMemcpy(&flags, env->st.error_flags, sizeof(int), hipMemcpyDeviceToHost));
+    if (flags) {
+        SMR_HIP(hipMemset(env->st.error_flags, 0, sizeof(int)));
+        env->err = std::string("Could not find a valid sample within the attempt limit (the reference raises ValueError, ctlp.py:2127-2136):") +
+                   ((flags & kSamplingStart) ? " collision-free robot start position;" : "") + ((flags & kSamplingPlanetPhase) ? " contact-free planet phase;" : "") +
+                   ((flags & kSamplingBallLaunch) ? " ball launch;" : "") + ((flags & kSamplingBallTarget) ? " ball target pose;" : "") +
+                   ((flags & kSamplingTargetPoint) ? " target point;" : "") + ((flags & kSamplingBallInitialStep) ? " contact-free initial ball time step;" : "") +
+                   ((flags & kSamplingKinematicState) ? " kinematically feasible start velocity / acceleration;" : "");
+        return SMR_E_SAMPLING;
+    }
+    if (!env->st.stale_commits) return SMR_OK;
     int stale = 0;
     SMR_HIP(hipMemcpy(&stale, env->st.stale_commits, sizeof(int), hipMemcpyDeviceToHost));
     if (stale) { env->err = "internal error: a reset was committed without a matching staged start state"; return SMR_E_INVALID; }
@@ -1553,6 +1547,10 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     SMR_HIP(hipSetDevice(env->device));
     const int B = env->B;
     int rc;
+    if (env->staged && mask_dev && !env->primed) {     // a partial reset as the very first call: nothing is staged yet
+        if ((rc = staged_prepare_all(env, 0)) || (rc = staged_prepare_all(env, 1))) return rc;
+    }
+    env->primed = true;
     if (env->staged) {
         // Explicit resets are worked synchronously on the caller's stream: every refill in flight is awaited first, the lists of the
         // current slot are used and left empty again, and the states BEHIND the committed ones (tags + 1, + 2) are prepared here.
@@ -1615,6 +1613,10 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
              float *info_dev) {
     if (!env) return SMR_E_INVALID;
     if (!actions_dev || !obs_dev || !reward_dev || !done_dev || !reason_dev) { env->err = "smr_step: NULL buffer"; return SMR_E_INVALID; }
+    if (env->staged && env->auto_reset && !env->primed) {
+        env->err = "smr_step before the first smr_reset: with auto_reset a finished env restarts from a start state that reset() prepares";
+        return SMR_E_INVALID;
+    }
     SMR_HIP(hipSetDevice(env->device));
     const int B = env->B;
     if (env->auto_reset && !(env->staged && env->auto_reset)) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));   // staged: unused
@@ -1630,14 +1632,22 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     }
     SMR_HIP(hipGetLastError());
     {
-        LaunchTimer t(env, SMR_K_COLLIDE);
         const bool self = env->hscene.n_self_pairs > 0, autop = env->hscene.planets_auto != 0;
         const int block = autop ? 256 : 64;
-        const dim3 grid((B + block - 1) / block, env->hscene.n_bodies + env->hscene.n_self_pairs, env->N);
-        if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        // first the contact sweeps over the samples 1 .. N-1 (short, uniform lanes), then the end-of-step sample
+        const dim3 sweep((B + block - 1) / block, env->hscene.n_bodies), grid((B + block - 1) / block, env->hscene.n_bodies + env->hscene.n_self_pairs);
+        if (env->N > 1) {
+            LaunchTimer t(env, SMR_K_SWEEP);
+            if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true, false>), sweep, dim3(block), 0, env->stream, env->dscene, env->st);
+            else if (self) hipLaunchKernelGGL((collide_kernel<true, false, false>), sweep, dim3(block), 0, env->stream, env->dscene, env->st);
+            else if (autop) hipLaunchKernelGGL((collide_kernel<false, true, false>), sweep, dim3(block), 0, env->stream, env->dscene, env->st);
+            else hipLaunchKernelGGL((collide_kernel<false, false, false>), sweep, dim3(block), 0, env->stream, env->dscene, env->st);
+        }
+        LaunchTimer t(env, SMR_K_COLLIDE);
+        if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else if (self) hipLaunchKernelGGL((collide_kernel<true, false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((collide_kernel<false, false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
     }
     SMR_HIP(hipGetLastError());
     const bool staged = env->staged && env->auto_reset;
@@ -1688,8 +1698,8 @@ int smr_synchronize(smr_env_t *env) {
     if (!env) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     SMR_HIP(hipStreamSynchronize(env->stream));
-    if (env->side) { SMR_HIP(hipStreamSynchronize(env->side)); SMR_HIP(hipStreamSynchronize(env->side_b)); return staged_check(env); }
-    return SMR_OK;
+    if (env->side) { SMR_HIP(hipStreamSynchronize(env->side)); SMR_HIP(hipStreamSynchronize(env->side_b)); }
+    return staged_check(env);
 }
 
 int smr_get_state(smr_env_t *env, const smr_host_state_t *h) {
@@ -1697,7 +1707,7 @@ int smr_get_state(smr_env_t *env, const smr_host_state_t *h) {
     SMR_HIP(hipSetDevice(env->device));
     SMR_HIP(hipStreamSynchronize(env->stream));
     int rc;
-    if (env->side && (rc = staged_check(env))) return rc;
+    if ((rc = staged_check(env))) return rc;
     if ((rc = state_get(env, h->q, env->st.q, 7)) || (rc = state_get(env, h->v, env->st.v, 7)) || (rc = state_get(env, h->a, env->st.a, 7)) ||
         (rc = state_get(env, h->planet_idx, env->st.planet_idx, 2)) || (rc = state_get(env, h->step_count, env->st.step_count, 1)) ||
         (rc = state_get(env, h->moving_hit, env->st.moving_hit, 1)) || (rc = state_get(env, h->reset_count, env->st.reset_count, 1)) ||
@@ -1744,7 +1754,8 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
         SMR_HIP(hipGetLastError());
         SMR_HIP(hipStreamSynchronize(env->stream));
     }
-    return SMR_OK;
+    if (h->reset_count) env->primed = true;            // every staged slot was just prepared for the injected counters
+    return staged_check(env);
 }
 
 int smr_set_profiling(smr_env_t *env, int32_t enable) {
@@ -1765,7 +1776,7 @@ int smr_get_profile(smr_env_t *env, double ms_out[SMR_K_COUNT], int64_t launches
         if (launches_out) launches_out[k] = env->prof_n[k];
         env->prof_ms[k] = 0; env->prof_n[k] = 0;
     }
-    return SMR_OK;
+    return staged_check(env);
 }
 
 int smr_test_fk(smr_env_t *env, const float *q_host, int32_t n, float *pos_out, float *rot_out) {

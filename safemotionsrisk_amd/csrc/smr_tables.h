@@ -358,6 +358,72 @@ inline void planet_tables(HostGeometry &G, DScene &d) {
     d.planets_auto = 1; d.planet_p0 = p0; d.planet_pn = p1 - p0; d.planet_vn = (int)G.auto_verts.size();
 }
 
+// Contact sweep constants (smr_device.h, "contact sweep").  sweep_R[b][j]: no point of body b (margin included) is farther from the
+// axis of joint j than the link lengths between them plus the body's extent about its link frame, so it moves no faster than
+// sum_j |qdot_j| sweep_R[b][j] (joint j turns about an axis through the origin of link j + 1, fk_advance).
+inline void sweep_tables(const smr_scene_t &s, const HostGeometry &G, DScene &d) {
+    for (int b = 0; b < s.n_bodies; ++b) {
+        const DPiece &P = G.pieces[s.link_piece[b]];
+        double rho = 0;
+        for (int k = 0; k < P.count; ++k) {
+            const float4 &v = G.verts[(size_t)P.begin + k];
+            double x[3] = {v.x, v.y, v.z};
+            if (b >= SMR_NLINK) {
+                double y[3];
+                for (int r = 0; r < 3; ++r) y[r] = s.body_xyz[b][r] + s.body_rot[b][3 * r] * x[0] + s.body_rot[b][3 * r + 1] * x[1] + s.body_rot[b][3 * r + 2] * x[2];
+                for (int r = 0; r < 3; ++r) x[r] = y[r];
+            }
+            rho = std::max(rho, std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]));
+        }
+        rho += P.margin;
+        const int chain = b < SMR_NLINK ? b : SMR_NLINK - 1;
+        for (int j = 0; j < SMR_NJ; ++j) {
+            double R = rho;
+            for (int i = j + 1; i < chain; ++i) R += std::sqrt(s.joint_xyz[i][0] * s.joint_xyz[i][0] + s.joint_xyz[i][1] * s.joint_xyz[i][1] + s.joint_xyz[i][2] * s.joint_xyz[i][2]);
+            d.sweep_R[b][j] = j < chain ? (float)(R * 1.00001 + 1e-6) : 0.f;
+        }
+    }
+    d.ball_bound_radius = 0.f;
+    if (s.use_ball && s.ball_piece >= 0 && s.ball_piece < s.n_pieces) {
+        const DPiece &P = G.pieces[s.ball_piece];
+        double r = 0;
+        for (int k = 0; k < P.count; ++k) { const float4 &v = G.verts[(size_t)P.begin + k]; r = std::max(r, std::sqrt((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z)); }
+        d.ball_bound_radius = (float)((r + P.margin) * 1.00001 + 1e-6);
+    }
+}
+
+// planet_step: the farthest any vertex of the planet's pieces moves from one orbit index to the next (float32 pose table
+// [n_orbit][8] as the kernels read it, same quaternion -> matrix formula as quat_pose), rounded up; the margin moves with it
+inline float planet_step_bound(const HostGeometry &G, const DPlanet &q, const float *pose) {
+    auto xf = [&](int i, double R[9], double t[3]) {
+        const float *row = pose + 8 * (size_t)i;
+        const double x = row[3], y = row[4], z = row[5], w = row[6], n = x * x + y * y + z * z + w * w, sc = n > 0 ? 2.0 / n : 0.0;
+        R[0] = 1 - sc * (y * y + z * z); R[1] = sc * (x * y - z * w); R[2] = sc * (x * z + y * w);
+        R[3] = sc * (x * y + z * w); R[4] = 1 - sc * (x * x + z * z); R[5] = sc * (y * z - x * w);
+        R[6] = sc * (x * z - y * w); R[7] = sc * (y * z + x * w); R[8] = 1 - sc * (x * x + y * y);
+        t[0] = row[0]; t[1] = row[1]; t[2] = row[2];
+    };
+    double worst = 0;
+    for (int i = 0; i < q.n_orbit; ++i) {
+        double Ra[9], ta[3], Rb[9], tb[3];
+        xf(i, Ra, ta); xf((i + 1) % q.n_orbit, Rb, tb);
+        for (int c = 0; c < q.piece_count; ++c) {
+            const DPiece &P = G.pieces[q.piece_begin + c];
+            for (int k = 0; k < P.count; ++k) {
+                const float4 &v = G.verts[(size_t)P.begin + k];
+                double dd = 0;
+                for (int r = 0; r < 3; ++r) {
+                    const double a = Ra[3 * r] * v.x + Ra[3 * r + 1] * v.y + Ra[3 * r + 2] * v.z + ta[r];
+                    const double b = Rb[3 * r] * v.x + Rb[3 * r + 1] * v.y + Rb[3 * r + 2] * v.z + tb[r];
+                    dd += (a - b) * (a - b);
+                }
+                worst = std::max(worst, std::sqrt(dd));
+            }
+        }
+    }
+    return (float)(worst * 1.0001 + 2e-6);
+}
+
 // bounding sphere of a whole planet: centre = mean of the piece centres, radius covers every piece sphere + margin
 inline void planet_bounds(const std::vector<DPiece> &pieces, DPlanet &q) {
     double cx = 0, cy = 0, cz = 0;

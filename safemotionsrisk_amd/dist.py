@@ -44,7 +44,10 @@ class ShardedRollout:
     (VecSafeMotionsEnv on a GPU).  `group` is a torch.distributed process group (None: default group).
     """
 
-    def __init__(self, env, group=None, equal_shards=True):
+    def __init__(self, env, group=None, equal_shards=True, host_gather=False):
+        """host_gather: the consumer of the rollout lives on the host (a learner that wants numpy batches, or a process group
+        without a device backend such as gloo): the packed shard is copied to pinned host memory once per step and the
+        all-gather runs on host buffers; the gathered views are then CPU tensors."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.env, self.group = torch, dist, env, group
@@ -55,10 +58,21 @@ class ShardedRollout:
         env.obs, env.reward, env.done = self.local.obs, self.local.reward, self.local.done
         if not equal_shards:
             raise NotImplementedError("all_gather_into_tensor needs equal shards; pad num_envs to a multiple of world")
-        self.gathered = torch.zeros(self.world * self.local.nbytes, dtype=torch.uint8, device=env.obs.device)
+        self.host_gather = bool(host_gather)
+        out_device = "cpu" if self.host_gather else env.obs.device
+        self.gathered = torch.zeros(self.world * self.local.nbytes, dtype=torch.uint8, device=out_device)
+        self._host = None
+        if self.host_gather:
+            self._host = torch.zeros(self.local.nbytes, dtype=torch.uint8)
+            if env.obs.device.type == "cuda":
+                self._host = self._host.pin_memory()
 
     def _gather(self):
-        self.dist.all_gather_into_tensor(self.gathered, self.local.flat, group=self.group)
+        if self.host_gather:
+            self._host.copy_(self.local.flat)                       # device -> pinned host (synchronises with the env's stream)
+            self.dist.all_gather_into_tensor(self.gathered, self._host, group=self.group)
+        else:
+            self.dist.all_gather_into_tensor(self.gathered, self.local.flat, group=self.group)
         n = self.local.nbytes
         return [self.local.views(self.gathered[r * n:(r + 1) * n]) for r in range(self.world)]
 

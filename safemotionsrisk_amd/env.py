@@ -1,7 +1,8 @@
 """Batched drop-in for the reference's gym surface.
 
-``VecSafeMotionsEnv(num_envs=B, **env_config)`` mirrors ``SafeMotionsEnvCollisionAvoidance(**env_config)``
-(safemotions/envs/safe_motions_env.py:38, constructed at train.py:620): same ``env_config`` keys, same
+``VecSafeMotionsEnv(num_envs=B, **env_config)`` mirrors ``SafeMotionsEnvCollisionAvoidance(**env_config)`` and
+``SafeMotionsEnv(**env_config)`` (safemotions/envs/safe_motions_env.py:38,19, constructed at train.py:620; which of the two reward
+classes runs follows from ``collision_avoidance_mode``, as train.py:614-619 picks the class): same ``env_config`` keys, same
 ``TERMINATION_*`` constants, ``action_space`` / ``observation_space`` shapes, ``reset()`` -> obs and
 ``step(action)`` -> (obs, reward, done, info) - batched over B environments that live on one GPU, one
 environment per wavefront lane.  All arithmetic runs in libsmr_hip.so; torch only provides device
@@ -63,14 +64,9 @@ class VecSafeMotionsEnv:
         self.episode_counter = 0
         self._return_info = bool(return_info)
         self._seed = 0 if seed is None else int(seed)                           # base.py:1704-1710
-        with torch.cuda.device(self.device):
-            self._stream = torch.cuda.current_stream(self.device)
-            handle = C.c_void_p()
-            rc = self._L.smr_create(C.cast(self.scene.pointer(), C.c_void_p), self.num_envs, int(device),
-                                    C.c_uint64(self._seed + (int(env_index_offset) << 32)),
-                                    C.c_void_p(self._stream.cuda_stream), C.byref(handle))
-            _lib.check(self._L, None, rc, "smr_create")
-        self._h = handle
+        self._device_index, self._env_index_offset = int(device), int(env_index_offset)
+        self._h = None
+        self._create()
         B, O = self.num_envs, self.observation_size
         self.obs = torch.zeros((B, O), dtype=torch.float32, device=self.device)
         self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
@@ -78,9 +74,26 @@ class VecSafeMotionsEnv:
         self.termination_reason = torch.full((B,), -1, dtype=torch.int8, device=self.device)
         self.info = torch.zeros((B, _lib.INFO_N), dtype=torch.float32, device=self.device) if return_info else None
 
+    def _create(self):
+        torch = self._torch
+        with torch.cuda.device(self.device):
+            self._stream = torch.cuda.current_stream(self.device)
+            handle = C.c_void_p()
+            rc = self._L.smr_create(C.cast(self.scene.pointer(), C.c_void_p), self.num_envs, self._device_index,
+                                    C.c_uint64(self._seed + (self._env_index_offset << 32)),
+                                    C.c_void_p(self._stream.cuda_stream), C.byref(handle))
+            _lib.check(self._L, None, rc, "smr_create")
+        self._h = handle
+
     # ---- gym surface ----
     def set_seed(self, seed=None):
-        raise NotImplementedError("pass seed= to the constructor: the per-env Philox streams are keyed at creation")
+        """base.py:1704-1710 seeds the global numpy / random generators.  Here the per-env Philox streams are keyed by
+        (seed, env index, reset count): re-keying means a fresh handle - every env restarts from reset count 0 and must be
+        reset() before the next step(), as after construction."""
+        self._seed = 0 if seed is None else int(seed)
+        self.close()
+        self._create()
+        self.episode_counter = 0
 
     def reset(self, mask=None):
         """obs = env.reset() for all envs (or those selected by a bool/uint8 mask tensor)."""
@@ -213,5 +226,6 @@ class VecSafeMotionsEnv:
         return out
 
 
-#: name parity with the reference class (safe_motions_env.py:38)
+#: name parity with the reference classes (safe_motions_env.py:38,19)
 SafeMotionsEnvCollisionAvoidance = VecSafeMotionsEnv
+SafeMotionsEnv = VecSafeMotionsEnv

@@ -16,10 +16,10 @@ LIB_PATH = os.path.join(_PKG, "libsmr_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 INFO_N = 8
-K_COUNT = 5
-KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn")
+K_COUNT = 6
+KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn", "sweep")
 
 #: every symbol include/safemotions_hip.h declares
 EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "smr_last_error", "smr_num_envs",
@@ -101,7 +101,14 @@ class SmrError(RuntimeError):
     pass
 
 
+class SamplingError(SmrError, ValueError):
+    """SMR_E_SAMPLING: a rejection-sampling loop ran out of attempts; the reference raises ValueError there (ctlp.py:2127-2136)."""
+
+
+E_SAMPLING = -4
+
+
 def check(L, handle, rc, what):
     if rc != 0:
         msg = L.smr_last_error(handle)
-        raise SmrError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+        raise (SamplingError if rc == E_SAMPLING else SmrError)("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

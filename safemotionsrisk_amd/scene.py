@@ -426,10 +426,13 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
                 auto_reset=True, assets_path=_DATA):
     """Build the scene description for ``Env(**env_config)`` of the reference (train.py:620).
 
-    collision_checks_per_step: N samples of the moving-obstacle contact latch per step.  Default:
-    ``round(max(1, dt / collision_check_time))`` (ctlp.py:99-103; 3 for the README configs), or 1 when
-    ``collision_check_time`` is absent.  N=24 reproduces the reference's 1/240 s contact cadence
-    (ctlp.py:2632-2637).
+    collision_checks_per_step: N samples of the moving-obstacle contact latch per step.  Default: the reference's
+    cadence - one contact check after every 1/240 s obstacle update, i.e. ``updates_per_step`` = 24 per step
+    (ctlp.py:2631-2637 ``planet_updates_per_check = 1``, ctlp.py:2825-2858 for the ball).  A smaller N (a divisor
+    of 24; 1 = end of step only) is an explicit opt-in that trades fidelity for nothing much: the kernels skip
+    intermediate samples by a conservative sweep bound, so N = 24 costs about what N = 1 does.
+    ``collision_check_time`` does NOT drive N: in the reference it only sets the sampling of the braking-trajectory
+    checker (ctlp.py:99-103,3167-3185), which is where this library uses it too (``check_braking_trajectory_collisions``).
     """
     config = dict(env_config)
     validate_env_config(config)
@@ -444,8 +447,7 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     s.episode_steps = int(round(float(_cfg(config, "trajectory_duration")) / dt))      # tm.py:87,189
     s.updates_per_step = int(round(dt / SIM_TIME_STEP))                                 # base.py:755
     if collision_checks_per_step is None:
-        cct = _cfg(config, "collision_check_time")
-        collision_checks_per_step = 1 if cct is None else int(round(max(1, dt / cct)))  # ctlp.py:99-103
+        collision_checks_per_step = s.updates_per_step                                  # ctlp.py:2631-2637,2825-2858
     if collision_checks_per_step < 1 or s.updates_per_step % collision_checks_per_step:
         raise ValueError("collision_checks_per_step=%d must divide the %d obstacle updates per step"
                          % (collision_checks_per_step, s.updates_per_step))

@@ -98,8 +98,10 @@ extern "C" void *emul_scene_create(const smr_scene_t *sp) {
         q.piece_begin = pl.piece_begin; q.piece_count = pl.piece_count; q.n_orbit = pl.n_orbit; q.index_shift = pl.index_shift; q.coupled = pl.coupled;
         q.orbit_pose = H->pose[p].data(); q.orbit_local = H->local[p].data();
         planet_bounds(H->G.pieces, q);
+        d.planet_step[p] = planet_step_bound(H->G, q, H->pose[p].data());
     }
-    d.use_ball = s.use_ball; d.ball_piece = s.ball_piece; d.ball_radius = (float)s.ball_radius;
+    sweep_tables(s, H->G, d);
+    d.use_ball = s.use_ball; d.ball_piece = s.ball_piece; d.ball_radius = (float)s.ball_radius; d.ball_active_xy_radius = (float)s.ball_active_xy_radius;
     planet_tables(H->G, d);
     d.auto_verts = (const float *)H->G.auto_verts.data(); d.auto_desc = H->G.auto_desc.data();
     d.term_moving = s.terminate_on_moving_collision; d.collision_dist = (float)s.collision_distance;
@@ -183,3 +185,57 @@ extern "C" float emul_pos_margin(double plo, double phi, double V, double A, dou
     L.V_res = (float)(V - (double)L.V);
     return pos_margin(gap, v, a, a1, 1e-5f * L.V, L);
 }
+
+// one lane of the collide kernel (collide_lane): body l, end-of-step sample (fin) or the contact sweep over samples 1 .. N-1 of the
+// cubic (q, v, a -> a1); out = contact, d_static, d_moving, bound evaluations, real queries.  literal != 0: every sample
+// 1 .. N-1 is tested instead (what the sweep must reproduce).  ball: NULL or the 10 floats of smr_host_state_t.ball + counters
+extern "C" void emul_collide_lane(void *h, int l, const float *q, const float *v, const float *a, const float *a1, const int *idx0, int N, int fin,
+                                  int literal, const float *ball, const int *ball_i, float *out) {
+    HostScene *H = (HostScene *)h;
+    DScene &S = H->d;
+    S.checks_per_step = N;
+    const DPiece LP = load_piece(S.pieces, S.link_piece[l]);
+    const GlobalHull hull = global_hull(S, S.link_piece[l], LP);
+    static std::vector<float> pv, pd;
+    pv.assign(4 * kMaxPlanetVerts, 0.f); pd.assign(kPlanetDescDwords * kMaxPlanetPieces, 0.f);
+    if (S.planets_auto) stage_planets(S, 0, 1, pv.data(), pd.data());
+    uint32_t keys[7];
+    LaneInput in;
+    in.q = q; in.v = v; in.a = a; in.a1 = a1; in.stride = 1;
+    in.planet_idx[0] = idx0[0]; in.planet_idx[1] = idx0[1]; in.moving_hit = 0;
+    in.ball_k0 = in.ball_kmax = in.ball_khit = in.ball_active = 0;
+    if (ball) {
+        for (int c = 0; c < 3; ++c) { in.ball.p0[c] = ball[c]; in.ball.v0[c] = ball[3 + c]; in.ball.e0[c] = ball[6 + c]; }
+        in.ball.omega = ball[9];
+        in.ball_k0 = ball_i[0]; in.ball_kmax = ball_i[1]; in.ball_khit = ball_i[2]; in.ball_active = ball_i[3];
+    }
+    if (!literal) {
+        const LaneResult r = S.planets_auto ? (fin ? collide_lane<true, true, true>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1)
+                                                   : collide_lane<true, true, false>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1))
+                                            : (fin ? collide_lane<true, false, true>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1)
+                                                   : collide_lane<true, false, false>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1));
+        out[0] = r.contact ? 1.f : 0.f; out[1] = r.d_static; out[2] = r.d_moving; out[3] = (float)r.evals; out[4] = (float)r.queries;
+        return;
+    }
+    const int upd = S.updates_per_step / N;
+    const bool con_link = (S.contact_mask >> l) & 1u;
+    bool contact = false;
+    const int u_end = ball ? ball_retire_update(S, in.ball_k0, in.ball_kmax, in.ball_khit) : 0;
+    for (int k = 1; k < N && !contact && con_link; ++k) {
+        if (ball && !(in.ball_active && k * upd < u_end)) continue;
+        float qk[SMR_NJ];
+        for (int j = 0; j < SMR_NJ; ++j) qk[j] = interp_pos(q[j], v[j], a[j], a1[j], S.dt * (float)k / (float)N, S.dt);
+        const Xf T = body_frame(S, qk, l);
+        if (ball) {
+            const Xf XB = ball_pose(S, in.ball, in.ball_k0 + k * upd, nullptr);
+            const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
+            contact = collide_link(S, l, LP, hull, T, nullptr, &XB, false, false, near).contact;
+        } else {
+            int idx[2] = {(idx0[0] + k * upd) % S.planet[0].n_orbit, S.n_planets > 1 ? (idx0[1] + k * upd) % S.planet[1].n_orbit : 0};
+            contact = collide_link(S, l, LP, hull, T, idx, nullptr, false, false, true).contact;
+        }
+    }
+    out[0] = contact ? 1.f : 0.f; out[1] = out[2] = out[3] = out[4] = 0.f;
+}
+extern "C" float emul_sweep_R(void *h, int b, int j) { return ((HostScene *)h)->d.sweep_R[b][j]; }
+extern "C" float emul_planet_step(void *h, int p) { return ((HostScene *)h)->d.planet_step[p]; }

@@ -1,0 +1,57 @@
+"""Shared helpers of the parity tests: which done / reason mismatches between the float32 kernels and the float64 oracle are
+explained by a distance sitting on a decision threshold.
+
+Decisions of a step: d_static / d_self / d_moving < 0.001 m at the end of the step (rewards.py:115-121,153-155) and the contact
+latch `distance <= contact_distance` (0.02 m) at each of the N contact samples of the step (ctlp.py:2631-2637,2849-2861).  An env
+is a TIE when the oracle's float64 distance of one of these decisions lies within TIE of its threshold: float32 may then fall on
+the other side.  Anything else that differs is a finding, not a budget: the tests assert zero unexplained mismatches.
+"""
+import numpy as np
+
+TIE = 2e-5
+
+
+def cubic(q0, v0, a0, a1, t, dt):
+    q0, v0, a0, a1 = (np.asarray(x, dtype=np.float64) for x in (q0, v0, a0, a1))
+    return q0 + v0 * t + 0.5 * a0 * t * t + (a1 - a0) / dt * t ** 3 / 6
+
+
+def ball_retire_update(k, kmax, khit, updates_per_step=24):
+    """first update u in 1..24 at which the ball is retired (ctlp.py:2836-2848), 25 if it survives the step"""
+    u = max(1, min(kmax - k + 1, khit - k))
+    return updates_per_step + 1 if u > updates_per_step else u
+
+
+def explain_mismatches(ora, scene, st0, st1, bad, tie=TIE):
+    """For the envs flagged in `bad` (done / reason / counters differ): True where a threshold tie explains it.
+    st0 / st1: the product's get_state() before / after the step (st1["a"] is the end acceleration of the step's cubic).
+    Uses the oracle's float64 distances at the end of the step and at every intermediate contact sample."""
+    s = scene.struct
+    N, dt, upd = int(s.collision_checks_per_step), float(s.dt), int(s.updates_per_step) // int(s.collision_checks_per_step)
+    idx_bad = np.nonzero(bad)[0]
+    out = np.zeros(len(idx_bad), dtype=bool)
+    for n, e in enumerate(idx_bad):
+        q0, v0, a0, a1 = st0["q"][e], st0["v"][e], st0["a"][e], st1["a"][e]
+        samples = range(1, N + 1)
+        for k in samples:
+            qk = cubic(q0, v0, a0, a1, dt * k / N, dt)
+            if s.use_ball:
+                k0, kmax, khit, active = (int(x) for x in st0["ball_i"][e][:4])
+                if not active:
+                    break
+                if k * upd >= ball_retire_update(k0, kmax, khit):
+                    break
+                d = ora.ball_distances(qk, st0["ball"][e].astype(np.float64), k0 + k * upd)
+            else:
+                n_orbit = [int(s.planet[p].n_orbit) if p < s.n_planets else 1 for p in range(2)]
+                idx = np.array([(int(st0["planet_idx"][e][p]) + k * upd) % n_orbit[p] for p in range(2)], dtype=np.int32)
+                d = ora.distances(qk, idx)
+            if abs(d[2] - float(s.contact_distance)) < tie:
+                out[n] = True
+            if k == N and (np.abs(np.asarray(d[:3]) - float(s.collision_distance)) < tie).any():
+                out[n] = True
+        if not out[n]:                                  # static / self distances do not depend on the moving obstacle (a retired ball skips the loop end)
+            qn = cubic(q0, v0, a0, a1, dt, dt)
+            d = ora.ball_distances(qn, st0["ball"][e].astype(np.float64), 0) if s.use_ball else ora.distances(qn, np.zeros(2, np.int32))
+            out[n] = bool((np.abs(np.asarray(d[:2]) - float(s.collision_distance)) < tie).any())
+    return out

@@ -11,13 +11,17 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "space
 import pytest
 
 
-@pytest.mark.parametrize("name", ["space_step.npz", "space_bm_step.npz", "reach_step.npz"])
+@pytest.mark.parametrize("name", ["space_step.npz", "space_step_n3.npz", "space_step_n1.npz", "space_bm_step.npz", "reach_step.npz"])
 def test_oracle_reproduces_golden_step_vectors(built, space_scene, bm_scene, name):
-    from safemotionsrisk_amd.scene import REACH_ENV_CONFIG, build_scene
+    """space_step.npz: 24 contact samples per step (the reference's cadence, the default); _n3 / _n1: the opt-in variants"""
+    from safemotionsrisk_amd.scene import REACH_ENV_CONFIG, SPACE_ENV_CONFIG, build_scene
     g = np.load(os.path.join(os.path.dirname(GOLD), name))
     B, T = int(g["B"]), int(g["T"])
     reach = "reach" in name
     scene = build_scene(REACH_ENV_CONFIG, auto_reset=False) if reach else bm_scene if "bm" in name else space_scene
+    if "_n" in name:
+        scene = build_scene(SPACE_ENV_CONFIG, auto_reset=False, collision_checks_per_step=int(g["checks"]))
+    assert int(g["checks"]) == scene.struct.collision_checks_per_step == (int(name.split("_n")[1].split(".")[0]) if "_n" in name else 24)
     env = OracleEnv(scene, B, seed=int(g["seed"]), num_threads=4)
     env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], planet_idx=g["planet_idx0"], step_count=g["step_count0"],
                   moving_hit=g["moving_hit0"], **(dict(target=g["target0"], target_count=g["target_count0"]) if reach else {}))

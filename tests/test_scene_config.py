@@ -27,7 +27,7 @@ def test_masks_thresholds_and_sizes(space_scene):
     assert s.static_link_mask == 0b11111100        # iiwa_link_2..7: table observed AND closest_point_active
     assert s.moving_link_mask == 0b11111000        # iiwa_link_3..7 (scene.py:288-290)
     assert s.static_max_distance == pytest.approx(0.102) and s.moving_max_distance == pytest.approx(0.6)
-    assert s.collision_checks_per_step == 3 and s.updates_per_step == 24 and s.episode_steps == 20
+    assert s.collision_checks_per_step == 24 and s.updates_per_step == 24 and s.episode_steps == 20
     assert s.obs_size == 23 and s.obs_num_planets == 1 and s.obs_planet_size_per_planet == 2
     assert s.n_pieces == 8 + 1 + 24 + 1 and s.n_static == 1
     assert [s.start_box[c][0] for c in range(3)] == [-1.1, -1.1, -0.1]
@@ -36,8 +36,12 @@ def test_masks_thresholds_and_sizes(space_scene):
 
 
 def test_collision_checks_option():
-    assert build_scene(SPACE_ENV_CONFIG, collision_checks_per_step=24).struct.collision_checks_per_step == 24
-    assert build_scene(dict(SPACE_ENV_CONFIG, collision_check_time=None)).struct.collision_checks_per_step == 1
+    # default = the reference's contact cadence, one check per 1/240 s obstacle update (ctlp.py:2631-2637); collision_check_time
+    # has no say in it (it only samples the braking-trajectory checker, ctlp.py:99-103,3167-3185)
+    assert build_scene(SPACE_ENV_CONFIG).struct.collision_checks_per_step == 24
+    assert build_scene(dict(SPACE_ENV_CONFIG, collision_check_time=None)).struct.collision_checks_per_step == 24
+    assert build_scene(SPACE_ENV_CONFIG, collision_checks_per_step=3).struct.collision_checks_per_step == 3
+    assert build_scene(SPACE_ENV_CONFIG, collision_checks_per_step=1).struct.collision_checks_per_step == 1
     with pytest.raises(ValueError):
         build_scene(SPACE_ENV_CONFIG, collision_checks_per_step=5)     # must divide 24
 
