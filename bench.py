@@ -114,12 +114,20 @@ def launch_ranks(args):
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+    # a rank that fails leaves the others waiting in the rendezvous: stop them (our own children, by pid) instead of hanging
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    out = procs[0].stdout.read() if procs[0].stdout else b""
+    codes = [p.wait() for p in procs]
     if any(codes):
         raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (args.gpus, codes))
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
 
 
 def load_pmc(config_name, B, n_checks):
@@ -165,8 +173,9 @@ def main():
     from safemotionsrisk_amd.dist import ShardedRollout
 
     n_dev = torch.cuda.device_count()
-    if local_rank >= n_dev:
-        raise SystemExit("rank %d: local GPU %d does not exist (%d visible): --gpus %d needs %d GPUs" % (rank, local_rank, n_dev, args.gpus, args.gpus))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if local_rank >= n_dev or local_world > n_dev:       # every rank sees this, so none is left waiting in the rendezvous
+        raise SystemExit("rank %d: --gpus %d needs %d GPUs on this node, %d visible" % (rank, args.gpus, local_world, n_dev))
     distributed = world > 1
     if rank == 0 and not os.path.exists(os.path.join(ROOT, "safemotionsrisk_amd", "libsmr_hip.so")):
         entry.build()
@@ -232,7 +241,7 @@ def main():
         pmc, pmc_note = load_pmc(args.config, B, n_checks) if world == 1 else (None, "PMC profiles are collected at N = 1")
         traffic = traffic_step = issue = None
         if pmc is not None:
-            kname = {"collide": "smr::collide_kernel<fin>", "sweep": "smr::collide_kernel<sweep>"}.get(dominant, "smr::%s_kernel" % dominant)
+            kname = "smr::%s_kernel" % dominant
             kk = pmc["kernels"].get(kname, {})
             traffic = kk.get("hbm_bytes")
             step_kernels = [k for k in pmc["kernels"] if not any(x in k for x in ("reset", "spawn<staged>", "target<staged>"))]

@@ -56,12 +56,11 @@ extern "C" {
 
 /* kernels timed by smr_get_profile */
 #define SMR_K_PLAN 0      /* A2/A4: safe acceleration range + action mapping            */
-#define SMR_K_COLLIDE 1   /* A3/A6/A7/A8/A11: end-of-step sample: FK, GJK distances, contact   */
+#define SMR_K_COLLIDE 1   /* A3/A6/A7/A8/A11: cubic samples, FK, GJK distances, contacts     */
 #define SMR_K_FINISH 2    /* A1/A12/A13/A15/A16: state update, reward, termination, obs  */
 #define SMR_K_RESET 3     /* A17/A9: start-state and planet-phase sampling               */
 #define SMR_K_SPAWN 4     /* A10: a new ball for the envs whose ball was retired         */
-#define SMR_K_SWEEP 5     /* A11: contact sweep over the intermediate samples 1 .. N-1    */
-#define SMR_K_COUNT 6
+#define SMR_K_COUNT 5
 
 typedef struct smr_env smr_env_t;   /* opaque */
 

@@ -133,9 +133,10 @@ struct DState {
     int *moving_hit;           // [B]
     unsigned *reset_count;     // [B]  number of resets of the env = Philox tag of its next reset
     float *a1;                 // [7][B]   plan -> collide/finish
-    float *res;                // [2][n_bodies][B] collide -> finish: contact flag of body l at the end-of-step sample [0] and at any
-                               // of the intermediate samples 1 .. N-1 [1] (N > 1)
+    float *res;                // [n_bodies][B] collide -> finish: contact of body l at any of the N contact samples of the step
     float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
+    float *lb_moving;          // [n_bodies][B] lower bound of the body's distance to every moving piece at the end of the last step
+                               // (< 0: none - new episode, injected state); the next step's lanes rule out their first samples with it
     int *done_list;            // [B]
     int *done_count;           // [1]
     float *ball;               // [10][B] launch point p0, launch velocity v0, initial euler angles e0, spin rate
@@ -1112,11 +1113,13 @@ __device__ __forceinline__ int ball_retire_update(const DScene &S, int k, int km
 template <class HB>
 __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, const HB &hull, const Xf &T,
                                       const int idx[SMR_MAX_PLANETS], const Xf *XB, bool want_static, bool want_moving,
-                                      bool want_contact, const float *q_self = nullptr, bool skip_planets = false) {
+                                      bool want_contact, const float *q_self = nullptr, bool skip_planets = false, float moving_cut = -1.f) {
+    // moving_cut: moving distances above it are "no closest point" (default: the scene's moving_max; the contact sweep asks for less)
+    const float moving_max = moving_cut >= 0.f ? moving_cut : S.moving_max;
     Sample out;
     out.d_static = S.static_max;
     out.d_self = S.static_max;
-    out.d_moving = S.moving_max + 0.002f;
+    out.d_moving = moving_max + 0.002f;
     out.contact = false;
     if (want_static && ((S.static_mask >> l) & 1u)) {
         for (int s = 0; s < S.n_static; ++s) {
@@ -1131,15 +1134,17 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
             if (d <= S.static_max && d < out.d_self) out.d_self = d;
         }
     if (skip_planets) return out;                       // the caller runs planet_queries_auto instead
-    const bool mov = want_moving && ((S.moving_mask >> l) & 1u);
+    // an explicit moving_cut (contact sweep) asks for the distance whatever the reward's link set says
+    const bool mov = want_moving && (((S.moving_mask >> l) & 1u) || moving_cut >= 0.f);
     const bool con_link = (S.contact_mask >> l) & 1u;
     if (!(mov || (want_contact && con_link))) return out;
     const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
     if (S.use_ball) {                                   // one moving piece: the ball, pose XB
         const bool con = want_contact && con_link;
-        float cutoff = mov ? S.moving_max : S.contact_dist;
+        float cutoff = mov ? moving_max : S.contact_dist;
+        if (con) cutoff = fmaxf(cutoff, S.contact_dist);
         float d = piece_distance<false>(S, S.ball_piece, *XB, LP, hull, T, cutoff, stop_moving);
-        if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
+        if (mov && d <= moving_max && d < out.d_moving) out.d_moving = d;
         if (con && d <= S.contact_dist) out.contact = true;
         return out;
     }
@@ -1147,7 +1152,7 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
     // Upper bound on the minimum distance from interior points (3 of the link x 1 per piece): pairs that cannot
     // beat it are culled by their bounding spheres or leave GJK after one or two iterations.  The pair that
     // attains the minimum is never cut: its distance is <= the bound.
-    float cut_moving = S.moving_max;
+    float cut_moving = moving_max;
     if (mov) {
         const F3 l0 = apply(T, F3{LP.in[0][0], LP.in[0][1], LP.in[0][2]}), l1 = apply(T, F3{LP.in[1][0], LP.in[1][1], LP.in[1][2]}),
                  l2 = apply(T, F3{LP.in[2][0], LP.in[2][1], LP.in[2][2]});
@@ -1180,7 +1185,7 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
             if (plb > cutoff) continue;
             SMR_CNT_SLOT(pb + c);
             float d = piece_distance<false>(S, pb + c, XP, LP, hull, T, cutoff, stop_moving);
-            if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
+            if (mov && d <= moving_max && d < out.d_moving) out.d_moving = d;
             if (con && d <= S.contact_dist) out.contact = true;
         }
     }
@@ -1202,29 +1207,30 @@ __device__ inline void stage_planets(const DScene &S, int tid, int nthreads, flo
     for (int i = tid; i < kPlanetDescDwords * S.planet_pn; i += nthreads) pd[i] = gd[i];
 }
 
-template <class HB>
-__device__ inline void planet_queries_auto(const DScene &S, const float *pv, const float *pd, uint32_t *keys, int kstride,
-                                           const DPiece &LP, const HB &hull, const Xf &T, const int idx[SMR_MAX_PLANETS], bool mov,
-                                           bool want_contact, Sample &out) {
-    const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
+// pass 1 (lockstep, scalar piece loads): the key of every piece for the lanes with `live` set; pieces whose lower bound exceeds
+// cutoff_max get key 255.  Whole-planet and piece bounding spheres first; a wavefront none of whose lanes passes them skips the
+// capsule arithmetic.  The lane's 28 key bytes live in LDS (keys[w * kstride], w < 7): registers are what limits the collide kernel.
+// Returns a lower bound of the distance (margins subtracted) between the body and all planet pieces - the smallest of the bounds
+// the keys come from, beyond cutoff_max too (the contact sweep jumps by it).
+__device__ inline float planet_keys(const DScene &S, uint32_t *keys, int kstride, const DPiece &LP, const Xf &T, const int idx[SMR_MAX_PLANETS],
+                                    bool live, float cutoff_max) {
     const F3 lc = apply(T, F3{LP.cx, LP.cy, LP.cz});
-    bool finished = !(mov || want_contact);
-    // pass 1 (lockstep, scalar piece loads): the key of every piece.  Whole-planet and piece bounding spheres first; a
-    // wavefront none of whose lanes passes them skips the capsule arithmetic (nearly always at the contact-only samples).
-    // The lane's 28 key bytes live in LDS (keys[w * kstride], w < 7): registers are what limits this kernel.
+    float lb_min = 3.0e38f;
 #pragma unroll
     for (int w = 0; w < 7; ++w) keys[w * kstride] = 0xFFFFFFFFu;
-    if (__any(!finished)) {
-        float cutoff_max = mov ? S.moving_max : S.contact_dist;
-        if (want_contact) cutoff_max = fmaxf(cutoff_max, S.contact_dist);
+    if (__any(live)) {
         const F3 l0 = apply(T, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), l1 = apply(T, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
         const int second_planet = S.n_planets > 1 ? 1 : 0;
         const Xf X0 = planet_pose(S, 0, idx[0]);
         const Xf X1 = planet_pose(S, second_planet, idx[second_planet]);
         const F3 e0 = apply(X0, F3{S.planet[0].bx, S.planet[0].by, S.planet[0].bz}) - lc,
                  e1 = apply(X1, F3{S.planet[second_planet].bx, S.planet[second_planet].by, S.planet[second_planet].bz}) - lc;
-        const bool near0 = !finished && __builtin_amdgcn_sqrtf(dot(e0, e0)) - S.planet[0].bradius - LP.radius - LP.margin <= cutoff_max;
-        const bool near1 = !finished && __builtin_amdgcn_sqrtf(dot(e1, e1)) - S.planet[second_planet].bradius - LP.radius - LP.margin <= cutoff_max;
+        const float lbw0 = __builtin_amdgcn_sqrtf(dot(e0, e0)) * 0.99999f - 1e-6f - S.planet[0].bradius - LP.radius - LP.margin;
+        const float lbw1 = __builtin_amdgcn_sqrtf(dot(e1, e1)) * 0.99999f - 1e-6f - S.planet[second_planet].bradius - LP.radius - LP.margin;
+        const bool near0 = live && lbw0 <= cutoff_max;
+        const bool near1 = live && lbw1 <= cutoff_max;
+        if (!near0) lb_min = fminf(lb_min, lbw0);
+        if (S.n_planets > 1 && !near1) lb_min = fminf(lb_min, lbw1);
 #pragma unroll 1
         for (int w = 0; w < 7; ++w) {
             uint32_t word = 0xFFFFFFFFu;
@@ -1239,14 +1245,16 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
                         const float margins = PP.margin + LP.margin;
                         const F3 cen = {PP.cx, PP.cy, PP.cz};
                         const F3 dc = (second ? apply(X1, cen) : apply(X0, cen)) - lc;
-                        const float lb_s = __builtin_amdgcn_sqrtf(dot(dc, dc)) - PP.radius - LP.radius - margins;
+                        const float lb_s = __builtin_amdgcn_sqrtf(dot(dc, dc)) * 0.99999f - 1e-6f - PP.radius - LP.radius - margins;
+                        float lb = lb_s;
                         if (lb_s <= cutoff_max) {
                             const F3 ca = {PP.cap_a[0], PP.cap_a[1], PP.cap_a[2]}, cb = {PP.cap_b[0], PP.cap_b[1], PP.cap_b[2]};
                             const F3 a0 = second ? apply(X1, ca) : apply(X0, ca), a1 = second ? apply(X1, cb) : apply(X0, cb);
                             const float lb_c = __builtin_amdgcn_sqrtf(seg_seg_dist2(a0, a1, l0, l1)) * 0.99999f - 1e-6f - PP.cap_r - LP.cap_r - margins;
-                            const float lb = fmaxf(lb_s, lb_c);
+                            lb = fmaxf(lb_s, lb_c);
                             if (lb <= cutoff_max) key = (uint32_t)fminf(fmaxf(lb * (1.0f / kKeyStep), 0.f), 254.f);
                         }
+                        lb_min = fminf(lb_min, lb);
                     }
                 }
                 word = (word >> 8) | (key << 24);
@@ -1254,6 +1262,17 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
             keys[w * kstride] = word;
         }
     }
+    return live ? lb_min : 3.0e38f;
+}
+
+// pass 2: lane-autonomous GJK over the lane's candidate keys, best first (see above).  mov: the minimum distance up to moving_cut
+// goes to out.d_moving; want_contact: out.contact.
+template <class HB>
+__device__ inline void planet_gjk(const DScene &S, const float *pv, const float *pd, uint32_t *keys, int kstride,
+                                  const DPiece &LP, const HB &hull, const Xf &T, const int idx[SMR_MAX_PLANETS], bool mov,
+                                  bool want_contact, float moving_max, Sample &out) {
+    const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
+    bool finished = !(mov || want_contact);
     // pass 2: lane-autonomous GJK, best candidate first
     GjkRun g;
     g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);     // defined state for the lanes that never activate
@@ -1287,7 +1306,7 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
     for (int trip = 0; trip < 33 * kMaxPlanetPieces; ++trip) {
         if (!active && !finished) {
             con_cur = want_contact && !out.contact;
-            float cutoff = mov ? fminf(out.d_moving, S.moving_max) : S.contact_dist;
+            float cutoff = mov ? fminf(out.d_moving, moving_max) : S.contact_dist;
             if (con_cur) cutoff = fmaxf(cutoff, S.contact_dist);
             uint32_t best = 0xFFFFFFFFu, kw[7];
 #pragma unroll
@@ -1319,7 +1338,7 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
             float dist;
             if (gjk_iterate(g, sa, sb, dist)) {
                 const float d = dist - margins;
-                if (mov && d <= S.moving_max && d < out.d_moving) out.d_moving = d;
+                if (mov && d <= moving_max && d < out.d_moving) out.d_moving = d;
                 if (con_cur && d <= S.contact_dist) out.contact = true;
                 active = false;
             }
@@ -1327,15 +1346,27 @@ __device__ inline void planet_queries_auto(const DScene &S, const float *pv, con
     }
 }
 
+
+template <class HB>
+__device__ inline void planet_queries_auto(const DScene &S, const float *pv, const float *pd, uint32_t *keys, int kstride,
+                                           const DPiece &LP, const HB &hull, const Xf &T, const int idx[SMR_MAX_PLANETS], bool mov,
+                                           bool want_contact, Sample &out) {
+    float cutoff_max = mov ? S.moving_max : S.contact_dist;
+    if (want_contact) cutoff_max = fmaxf(cutoff_max, S.contact_dist);
+    planet_keys(S, keys, kstride, LP, T, idx, mov || want_contact, cutoff_max);
+    planet_gjk(S, pv, pd, keys, kstride, LP, hull, T, idx, mov, want_contact, S.moving_max, out);
+}
+
 // ---------------------------------------------------------------------------------------------
 // A11, the intermediate contact samples k = 1 .. N-1 of a step (the reference tests contact after every one of its 24 obstacle
-// updates per step, ctlp.py:2631-2637,2849-2861): conservative advancement instead of N full evaluations.  At a sample the lane
-// computes a rigorous LOWER bound of the distance between its body and every moving piece (bounding spheres, then capsules).
-// Between two samples no point of the body moves farther than (dt / N) sum_j max|qdot_j| sweep_R[b][j] and no point of a moving
-// obstacle farther than its per-update bound, so the samples k + 1 .. k + m are contact free while m x that motion stays below
-// bound - contact_dist: the lane jumps over them.  Only a sample whose bound does not clear the contact distance gets the real
-// query.  The flags are those of testing all N samples (which is what the float64 oracle does); nearly every (env, body) lane
-// is through after one or two bound evaluations, so N = 24 costs about what N = 1 does.
+// updates per step, ctlp.py:2631-2637,2849-2861).  The end-of-step lane of a body has, as a by-product of its distance queries, a
+// rigorous LOWER bound of the distance between the body and every moving piece at t = dt.  Between two samples no point of the
+// body moves farther than (dt / N) sum_j max|qdot_j| sweep_R[b][j] and no point of a moving obstacle farther than its per-update
+// bound, so the samples N-1, N-2, .. N-m are contact free while m x that motion stays below bound - contact_dist; the bound the
+// previous step left behind covers the first samples 1 .. m' the same way.  Only the samples in between become work items
+// (lane, sample) in an LDS queue of the wavefront, which its lanes then work off together, 64 at a time - dense rounds however
+// unevenly the items are spread over the lanes.  The flags are those of testing all N samples (which is what the float64 oracle
+// does); most (env, body) lanes need no item at all, so N = 24 costs little more than N = 1.
 // ---------------------------------------------------------------------------------------------
 // largest |velocity| of a constant-jerk segment (v0, a0 -> a1 over dt), rounded up
 __device__ __forceinline__ float cubic_speed_bound(float v0, float a0, float a1, float dt) {
@@ -1394,43 +1425,82 @@ __device__ inline float ball_lower_bound(const DScene &S, const DPiece &LP, cons
     return fmaxf(lb_s, lb_c) - S.ball_bound_radius - LP.margin;
 }
 
-// One lane of the collide kernel: body l of one env, either its end-of-step sample (fin: table / planet / ball distances of the
-// reward and the contact test at t = dt) or its contact sweep over the samples 1 .. N-1.  The state is read through strided
-// pointers (the kernel: [component][B] arrays; the host emulation: plain arrays).
+// One lane of the collide kernel: body l of one env at the end-of-step sample (table / planet / ball distances of the reward and
+// the contact test at t = dt), and how many of the intermediate contact samples 1 .. N-1 still need a test (k_need, see above).
+// The state is read through strided pointers (the kernel: [component][B] arrays; the host emulation: plain arrays).
 struct LaneInput {
     const float *q, *v, *a, *a1; int stride;           // joint j at [j * stride]
     int planet_idx[SMR_MAX_PLANETS], moving_hit;
     BallState ball; int ball_k0, ball_kmax, ball_khit, ball_active;
+    float lb_start;                                     // lower bound of the moving-piece distance at t = 0 (the previous step's lb_end; < 0: none)
 };
-struct LaneResult { bool contact; float d_static, d_moving; int evals, queries; };
+// k_first .. k_need: the intermediate samples that still need a test (empty when k_first > k_need); lb_end: the bound at t = dt
+struct LaneResult { bool contact; float d_static, d_moving; int k_first, k_need; float lb_end; };
 
-template <bool SELF, bool AUTO, bool fin, class HB>
+// frame of body l at time t of the step's cubic
+template <bool SELF>
+__device__ __forceinline__ Xf lane_frame(const DScene &S, int l, const LaneInput &in, float t) {
+    const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
+    Xf T = fk_base(S);
+    for (int j = 0; j < chain; ++j)                     // FK up to this body's link; joint values straight from the cubic
+        fk_advance(S, j, interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt), T);
+    if (SELF && l >= SMR_NLINK) T = mounted_frame(S, l, T);
+    return T;
+}
+
+template <bool SELF, bool AUTO, class HB>
 __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &LP, const HB &hull, const LaneInput &in,
                                           const float *lds_pv, const float *lds_pd, uint32_t *keys, int kstride) {
-    LaneResult out = {false, S.static_max, S.moving_max + 0.002f, 0, 0};
+    LaneResult out = {false, S.static_max, S.moving_max + 0.002f, 1, 0, -1.f};
     const int N = S.checks_per_step, upd = S.updates_per_step / N;
     const bool con_link = (S.contact_mask >> l) & 1u;
-    bool want_contact, moving_alive = true;
-    int k_last = N - 1;                                 // sweep: last sample to test
+    bool want_contact, sweep_contact, moving_alive = true;
+    int k_last = N - 1;                                 // last intermediate sample that is tested at all
     if (S.use_ball) {
         // the ball is tested at a sample only while it is in flight (ctlp.py:2836-2861): not yet retired by the
         // update counters, and inside the 1.25 m cylinder around the robot
         const int u_end = ball_retire_update(S, in.ball_k0, in.ball_kmax, in.ball_khit);
         moving_alive = in.ball_active && (N * upd < u_end);       // at the end-of-step sample
-        want_contact = (fin ? moving_alive : in.ball_active != 0) && con_link;
+        want_contact = moving_alive && con_link;
+        sweep_contact = in.ball_active != 0 && con_link;
         const int kl = (u_end - 1) / upd;                          // samples with k upd < u_end
         k_last = kl < k_last ? kl : k_last;
     } else {
-        want_contact = S.term_moving && S.n_planets > 0 && in.moving_hit == 0 && con_link;
+        want_contact = sweep_contact = S.term_moving && S.n_planets > 0 && in.moving_hit == 0 && con_link;
     }
-    const bool want_static = fin && ((S.static_mask >> l) & 1u);
-    const bool want_moving = fin && moving_alive && ((S.moving_mask >> l) & 1u);
-    int k = fin ? N : 1;
-    bool alive = fin ? (want_static || want_moving || want_contact) : (want_contact && k <= k_last);
-    if (!alive) return out;
-    const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
-    float step = 0.f;                                   // sweep: no point of the body or of a moving piece moves farther between two samples
-    if (!fin) {
+    if (k_last < 1) sweep_contact = false;
+    const bool want_static = (S.static_mask >> l) & 1u;
+    const bool want_moving = moving_alive && ((S.moving_mask >> l) & 1u);
+    if (!(want_static || want_moving || want_contact || sweep_contact)) return out;
+    const Xf T = lane_frame<SELF>(S, l, in, S.dt);
+    float lb = -1.f;                                    // lower bound of the distance to every moving piece at t = dt (< 0: none)
+    Sample r;
+    if (S.use_ball) {
+        const Xf XB = ball_pose(S, in.ball, in.ball_k0 + N * upd, nullptr);
+        const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
+        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near);
+        if (moving_alive && sweep_contact) lb = ball_lower_bound(S, LP, T, XB);
+    } else {
+        int idx[SMR_MAX_PLANETS] = {0, 0};
+#pragma unroll
+        for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+            if (p < S.n_planets) idx[p] = (in.planet_idx[p] + N * upd) % S.planet[p].n_orbit;
+        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, nullptr, AUTO);
+        if (AUTO) {
+            float cutoff_max = want_moving ? S.moving_max : S.contact_dist;
+            if (want_contact) cutoff_max = fmaxf(cutoff_max, S.contact_dist);
+            lb = planet_keys(S, keys, kstride, LP, T, idx, want_moving || want_contact, cutoff_max);
+            planet_gjk(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, want_contact, S.moving_max, r);
+            if (!(want_moving || want_contact)) lb = -1.f;
+        } else if (sweep_contact && N > 1) {
+            lb = planets_lower_bound(S, LP, T, idx, S.moving_max);
+        }
+    }
+    out.contact = r.contact; out.d_static = r.d_static; out.d_moving = r.d_moving;
+    if (N > 1 && sweep_contact && !r.contact) {
+        // motion between two samples: the body's points and the moving pieces
+        const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
+        float step = 0.f;
         for (int j = 0; j < chain; ++j) step += cubic_speed_bound(in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], S.dt) * S.sweep_R[l][j];
         step *= S.dt / (float)N;
         if (S.use_ball) {
@@ -1442,48 +1512,41 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
             for (int p = 0; p < S.n_planets; ++p) ps = fmaxf(ps, S.planet_step[p]);
             step += ps * (float)upd;
         }
+        const int safe = lb > S.contact_dist ? sweep_skip(lb, S.contact_dist, step) : 0;      // samples N-1 .. N-safe are contact free
+        const int kn = N - 1 - safe;
+        out.k_need = kn < k_last ? (kn > 0 ? kn : 0) : k_last;
+        // ... and from the other end: the samples 1 .. m are covered by the bound at t = 0, the end-of-step bound of the previous step
+        out.k_first = 1 + (in.lb_start > S.contact_dist ? sweep_skip(in.lb_start, S.contact_dist, step) : 0);
     }
-    for (int round = 0; round < (fin ? 1 : N); ++round) {
-        Xf T = fk_base(S), XB = T;
-        int idx[SMR_MAX_PLANETS] = {0, 0};
-        bool pending = false;
-        while (alive && !pending) {                     // sweep: bound evaluations until a sample needs the real query (fin: once)
-            const float t = fin ? S.dt : S.dt * (float)k / (float)N;
-            T = fk_base(S);
-            for (int j = 0; j < chain; ++j)             // FK up to this body's link; joint values straight from the cubic
-                fk_advance(S, j, interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt), T);
-            if (SELF && l >= SMR_NLINK) T = mounted_frame(S, l, T);
-            if (S.use_ball) XB = ball_pose(S, in.ball, in.ball_k0 + k * upd, nullptr);
-            else {
-#pragma unroll
-                for (int p = 0; p < SMR_MAX_PLANETS; ++p)
-                    if (p < S.n_planets) idx[p] = (in.planet_idx[p] + k * upd) % S.planet[p].n_orbit;
-            }
-            if (fin) { pending = true; break; }
-            ++out.evals;
-            const float lb = S.use_ball ? ball_lower_bound(S, LP, T, XB)
-                                        : planets_lower_bound(S, LP, T, idx, S.contact_dist + step * (float)(k_last - k + 1));
-            if (lb > S.contact_dist) { k += 1 + sweep_skip(lb, S.contact_dist, step); alive = k <= k_last; }
-            else pending = true;
-        }
-        if (!__any(pending)) break;
-        const bool con = fin ? want_contact : pending;
-        if (pending) ++out.queries;
-        Sample r;
-        if (S.use_ball) {
-            const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-            r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, con && near);
-        } else {
-            r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, con, nullptr, AUTO);
-            if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, con, r);
-        }
-        if (fin) { out.contact = r.contact; out.d_static = r.d_static; out.d_moving = r.d_moving; return out; }
-        if (pending) {
-            if (r.contact) { out.contact = true; alive = false; }
-            else { k += 1; alive = k <= k_last; }
-        }
-    }
+    out.lb_end = r.contact ? -1.f : lb;
     return out;
+}
+
+// One work item: the contact test of body l at the intermediate sample k (1 <= k < N).  BOUND_ONLY: only whether the sample needs
+// the real test at all - a lower bound of the distance to every moving piece that does not clear the contact distance (the wavefront
+// gathers these and runs the GJK queries on them alone, in dense rounds of their own).
+template <bool SELF, bool AUTO, bool BOUND_ONLY, class HB>
+__device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, const HB &hull, const LaneInput &in, int k, bool live,
+                                    const float *lds_pv, const float *lds_pd, uint32_t *keys, int kstride) {
+    const int N = S.checks_per_step, upd = S.updates_per_step / N;
+    const Xf T = lane_frame<SELF>(S, l, in, S.dt * (float)k / (float)N);
+    if (S.use_ball) {
+        const Xf XB = ball_pose(S, in.ball, in.ball_k0 + k * upd, nullptr);
+        const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
+        if (BOUND_ONLY) return live && near && ball_lower_bound(S, LP, T, XB) <= S.contact_dist;
+        return collide_link(S, l, LP, hull, T, nullptr, &XB, false, false, live && near).contact;
+    }
+    int idx[SMR_MAX_PLANETS] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+        if (p < S.n_planets) idx[p] = (in.planet_idx[p] + k * upd) % S.planet[p].n_orbit;
+    if (BOUND_ONLY) {
+        const float lb = AUTO ? planet_keys(S, keys, kstride, LP, T, idx, live, S.contact_dist) : planets_lower_bound(S, LP, T, idx, S.contact_dist);
+        return live && lb <= S.contact_dist + kKeyStep;             // a candidate key (floor of the bound / kKeyStep) may exist
+    }
+    Sample r = collide_link(S, l, LP, hull, T, idx, nullptr, false, false, live, nullptr, AUTO);
+    if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, false, live, r);
+    return r.contact;
 }
 
 // A15: planet part of the observation (obs.py:262-292)

@@ -43,35 +43,37 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
 }
 
-// one lane per (env, body l); grid = (B / block, self pairs + n_bodies).  FIN: the end-of-step sample k = N (distances of the reward
-// + its contact test); !FIN: the intermediate contact samples 1 .. N-1 of a body, by conservative advancement in one lane
-// (smr_device.h, "contact sweep") - its own kernel so that its loop state does not cost the end-of-step path registers
+// one lane per (env, body l), grid = (B / block, self pairs + n_bodies): the end-of-step sample k = N (distances of the reward + its
+// contact test), then the intermediate contact samples the body still needs (smr_device.h, "A11") as work items that the lanes of
+// the wavefront share out among themselves.
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
+constexpr int kMaxItemsPerLane = 23;   // N - 1 <= 23 intermediate samples (N divides the 24 updates of a step)
 // SELF: the scene has self-collision pairs (ball machine); the plain robot runs the instantiation without that code
 // AUTO: lane-autonomous planet queries (planet_queries_auto); four wavefronts then share the LDS copies
-template <bool SELF, bool AUTO, bool FIN>
+template <bool SELF, bool AUTO>
 __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = AUTO ? 256 : 64;
     // grid y: first the self-collision pairs (SELF; they only work at the end-of-step sample), then the bodies, outer ones
     // (most planet work) first
-    const int n_pair_blocks = (SELF && FIN) ? S.n_self_pairs : 0;
-    const bool pair_block = SELF && FIN && (int)blockIdx.y < n_pair_blocks;
+    const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
+    const bool pair_block = SELF && (int)blockIdx.y < n_pair_blocks;
     const int pair = pair_block ? (int)blockIdx.y : 0;
     // the body whose hull this block climbs over: its own body, or for a pair block the partner link (the ball machine
     // piece is then the scanned A side; with the base adapter as partner the piece itself is staged)
     const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0])
                              : S.body_order[(int)blockIdx.y - n_pair_blocks];
-    if (!pair_block) {                                   // nothing to do for this (block kind, body): leave before anything is staged
-        constexpr bool fin = FIN;
-        const bool any = (fin && (((S.static_mask | S.moving_mask) >> l) & 1u)) || ((S.contact_mask >> l) & 1u) || (fin && SELF);
+    const int B = S.B, N = S.checks_per_step, NB = S.n_bodies;
+    if (!pair_block) {                                   // nothing to do for this body: leave before anything is staged
+        const bool any = (((S.static_mask | S.moving_mask | S.contact_mask) >> l) & 1u) || SELF;
         if (!any) {
             const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
-            if (e0 < S.B) {
-                if (fin) { st.dist[(size_t)l * S.B + e0] = S.static_max; st.dist[(size_t)(S.n_bodies + l) * S.B + e0] = S.moving_max + 0.002f; }   // finish reads these
-                st.res[((size_t)(FIN ? 0 : 1) * S.n_bodies + l) * S.B + e0] = 0.f;
+            if (e0 < B) {
+                st.dist[(size_t)l * B + e0] = S.static_max; st.dist[(size_t)(NB + l) * B + e0] = S.moving_max + 0.002f;   // finish reads these
+                st.res[(size_t)l * B + e0] = 0.f;
+                if (N > 1) st.lb_moving[(size_t)l * B + e0] = -1.f;
             }
             return;
         }
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     __shared__ float lds_pv[AUTO ? 4 * kMaxPlanetVerts : 4];
     __shared__ float lds_pd[AUTO ? kPlanetDescDwords * kMaxPlanetPieces : 4];
     __shared__ uint32_t lds_keys[AUTO ? 7 * kBlock : 4];
+    __shared__ uint16_t lds_items[kBlock * kMaxItemsPerLane];   // per wavefront: 64 x 23 entries (source lane << 5 | sample k)
+    __shared__ uint32_t lds_hit[kBlock];
     const int pl = S.link_piece[l];
     const DPiece LP = load_piece(S.pieces, pl);
     {
@@ -99,11 +103,11 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     }
     __syncthreads();
     const LocalHull hull{lds_v, lds_ids, (const uint8_t *)lds_start};
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S.B) return;
-    const int B = S.B, N = S.checks_per_step;
-    const int NB = S.n_bodies;
-    if (SELF && FIN && pair_block) {
+    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = e0 < B;                           // the wavefront shares out its items: no lane leaves early
+    const int e = valid ? e0 : B - 1;
+    if (SELF && pair_block) {
+        if (!valid) return;
         // A7 self, pair (a, partner) at the end of the step (ctlp.py:3345-3372): distance in dist[2 NB + pair]
         float qs[SMR_NJ];
 #pragma unroll
@@ -125,19 +129,70 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
         st.dist[(size_t)(2 * NB + pair) * B + e] = d <= S.static_max ? d : S.static_max;
         return;
     }
-    float *res = st.res + ((size_t)(FIN ? 0 : 1) * NB + l) * B;
-    LaneInput in;
-    in.q = st.q + e; in.v = st.v + e; in.a = st.a + e; in.a1 = st.a1 + e; in.stride = B;
-    in.planet_idx[0] = st.planet_idx[e]; in.planet_idx[1] = st.planet_idx[B + e];
-    in.moving_hit = st.moving_hit[e];
-    in.ball_k0 = 0; in.ball_kmax = 0; in.ball_khit = 0; in.ball_active = 0;
-    if (S.use_ball) {
-        in.ball = load_ball(st, B, e);
-        in.ball_k0 = st.ball_i[e]; in.ball_kmax = st.ball_i[B + e]; in.ball_khit = st.ball_i[2 * B + e]; in.ball_active = st.ball_i[3 * B + e];
+    auto lane_input = [&](int env) {
+        LaneInput in;
+        in.q = st.q + env; in.v = st.v + env; in.a = st.a + env; in.a1 = st.a1 + env; in.stride = B;
+        in.planet_idx[0] = st.planet_idx[env]; in.planet_idx[1] = st.planet_idx[B + env];
+        in.moving_hit = st.moving_hit[env];
+        in.ball_k0 = 0; in.ball_kmax = 0; in.ball_khit = 0; in.ball_active = 0; in.lb_start = -1.f;
+        if (S.use_ball) {
+            in.ball = load_ball(st, B, env);
+            in.ball_k0 = st.ball_i[env]; in.ball_kmax = st.ball_i[B + env]; in.ball_khit = st.ball_i[2 * B + env]; in.ball_active = st.ball_i[3 * B + env];
+        }
+        return in;
+    };
+    LaneInput in = lane_input(e);
+    // the bound the env's previous step left behind holds for t = 0 of this one while the episode goes on (a new episode starts with
+    // step_count 0; state injection clears the array) and, in a ball scene, while it is the same ball (its update counter moved on)
+    in.lb_start = (N > 1 && st.step_count[e] > 0 && !(S.use_ball && in.ball_k0 < S.updates_per_step)) ? st.lb_moving[(size_t)l * B + e] : -1.f;
+    const LaneResult r = collide_lane<SELF, AUTO>(S, l, LP, hull, in, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock);
+    if (valid) {
+        st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving;
+        if (N > 1) st.lb_moving[(size_t)l * B + e] = r.lb_end;
     }
-    const LaneResult r = collide_lane<SELF, AUTO, FIN>(S, l, LP, hull, in, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock);
-    res[e] = r.contact ? 1.f : 0.f;
-    if (FIN) { st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = r.d_moving; }
+    bool contact = r.contact;
+    if (N > 1) {
+        // The samples k_first .. k_need of every lane become work items of its WAVEFRONT: a queue in LDS (source lane, sample),
+        // worked off 64 items at a time by all lanes - dense rounds, however unevenly the items are spread over the lanes.
+        const int n = (valid && r.k_need >= r.k_first) ? r.k_need - r.k_first + 1 : 0;
+        if (__any(n > 0)) {
+            const int lane = (int)__lane_id(), wave0 = (int)threadIdx.x - lane;
+            uint16_t *queue = lds_items + wave0 * kMaxItemsPerLane;
+            int incl = n;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            const int total = __shfl(incl, 63);
+            for (int k = 0; k < n; ++k) queue[incl - n + k] = (uint16_t)((lane << 5) | (r.k_first + k));
+            lds_hit[threadIdx.x] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // rounds of 64 items: frame of the body at the sample + lower bound; the few items whose bound does not clear the contact
+            // distance are compacted to the front of the queue (behind the read position) ...
+            int pending = 0;
+            for (int base = 0; base < total; base += 64) {
+                const bool live = base + lane < total;
+                const int item = queue[live ? base + lane : 0];
+                const LaneInput it = lane_input(__shfl(e, item >> 5));
+                const bool cand = collide_item<SELF, AUTO, true>(S, l, LP, hull, it, item & 31, live, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock);
+                const unsigned long long m = __ballot(cand);
+                if (cand) queue[pending + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)item;
+                pending += __popcll(m);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ... and get the real test, again 64 at a time
+            for (int base = 0; base < pending; base += 64) {
+                const bool live = base + lane < pending;
+                const int item = queue[live ? base + lane : 0], src = item >> 5;
+                const LaneInput it = lane_input(__shfl(e, src));
+                if (collide_item<SELF, AUTO, false>(S, l, LP, hull, it, item & 31, live, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock) && live) lds_hit[wave0 + src] = 1u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            contact = contact || lds_hit[threadIdx.x] != 0u;
+        }
+    }
+    if (valid) st.res[(size_t)l * B + e] = contact ? 1.f : 0.f;
 }
 
 // env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
@@ -199,12 +254,12 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     if (e == 0 && st.refill_zero) *st.refill_zero = 0;                        // the list counters of the NEXT step
     if (e == 0 && st.tp_refill_zero) *st.tp_refill_zero = 0;
     if (e >= S.B) return;
-    const int B = S.B, N = S.checks_per_step;
+    const int B = S.B;
     const int steps = st.step_count[e] + 1;                                   // base.py:1044
     int hit = st.moving_hit[e];
     int contact = 0;
     const int NB = S.n_bodies;
-    for (int k = 0; k < (N > 1 ? 2 : 1) * NB; ++k) contact |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;   // end-of-step sample | samples 1 .. N-1
+    for (int k = 0; k < NB; ++k) contact |= (st.res[(size_t)k * B + e] != 0.f) ? 1 : 0;   // any of the N contact samples of body k
     if (S.term_moving && S.n_planets > 0) hit |= contact;                     // ctlp.py:2631-2637
     float d_static = S.static_max, d_self = S.static_max, d_moving = S.moving_max + 0.002f;
     for (int l = 0; l < NB; ++l) {                                            // minimum over bodies, ctlp.py:3263-3278,3294-3372
@@ -1237,7 +1292,7 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
 static int check_scene(const smr_scene_t *s, int32_t num_envs, std::string &err) {
     if (!s) { err = "scene is NULL"; return SMR_E_INVALID; }
     if (s->version != SMR_SCENE_VERSION) { err = "smr_scene_t version mismatch"; return SMR_E_INVALID; }
-    if (num_envs <= 0) { err = "num_envs must be positive"; return SMR_E_INVALID; }
+    if (num_envs <= 0 || num_envs > (1 << 26)) { err = "num_envs must be in 1 .. 2^26"; return SMR_E_INVALID; }
     if (s->collision_checks_per_step <= 0 || s->updates_per_step <= 0 || s->updates_per_step % s->collision_checks_per_step) {
         err = "collision_checks_per_step must divide updates_per_step"; return SMR_E_INVALID;
     }
@@ -1299,11 +1354,11 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)2 * scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)) || (rc = dev_alloc(env, &env->spawn_tag_lists, 3 * B)))
         return fail(rc);
-    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12) || hipMemset(st.lb_moving, 0xFF, (size_t)scene->n_bodies * B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts; st.spawn_tags = env->spawn_tag_lists;
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
@@ -1632,22 +1687,14 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     }
     SMR_HIP(hipGetLastError());
     {
+        LaunchTimer t(env, SMR_K_COLLIDE);
         const bool self = env->hscene.n_self_pairs > 0, autop = env->hscene.planets_auto != 0;
         const int block = autop ? 256 : 64;
-        // first the contact sweeps over the samples 1 .. N-1 (short, uniform lanes), then the end-of-step sample
-        const dim3 sweep((B + block - 1) / block, env->hscene.n_bodies), grid((B + block - 1) / block, env->hscene.n_bodies + env->hscene.n_self_pairs);
-        if (env->N > 1) {
-            LaunchTimer t(env, SMR_K_SWEEP);
-            if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true, false>), sweep, dim3(block), 0, env->stream, env->dscene, env->st);
-            else if (self) hipLaunchKernelGGL((collide_kernel<true, false, false>), sweep, dim3(block), 0, env->stream, env->dscene, env->st);
-            else if (autop) hipLaunchKernelGGL((collide_kernel<false, true, false>), sweep, dim3(block), 0, env->stream, env->dscene, env->st);
-            else hipLaunchKernelGGL((collide_kernel<false, false, false>), sweep, dim3(block), 0, env->stream, env->dscene, env->st);
-        }
-        LaunchTimer t(env, SMR_K_COLLIDE);
-        if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else if (self) hipLaunchKernelGGL((collide_kernel<true, false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL((collide_kernel<false, false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        const dim3 grid((B + block - 1) / block, env->hscene.n_bodies + env->hscene.n_self_pairs);
+        if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
     }
     SMR_HIP(hipGetLastError());
     const bool staged = env->staged && env->auto_reset;
@@ -1735,6 +1782,7 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
         (rc = state_set(env, h->ball, env->st.ball, 10)) || (rc = state_set(env, h->ball_i, env->st.ball_i, 5)) ||
         (rc = state_set(env, h->target, env->st.tp, 5)) || (rc = state_set(env, h->target_count, env->st.tp_count, 1)))
         return rc;
+    SMR_HIP(hipMemset(env->st.lb_moving, 0xFF, (size_t)env->hscene.n_bodies * env->B * 4));     // NaN: the bounds of the last step no longer hold
     SMR_HIP(hipDeviceSynchronize());
     if (env->staged && h->reset_count) {               // the staged start states belong to the old reset counters
         if ((rc = staged_prepare_all(env, 0)) || (rc = staged_prepare_all(env, 1))) return rc;

@@ -18,8 +18,8 @@ INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 
 ABI_VERSION = 4
 INFO_N = 8
-K_COUNT = 6
-KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn", "sweep")
+K_COUNT = 5
+KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn")
 
 #: every symbol include/safemotions_hip.h declares
 EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "smr_last_error", "smr_num_envs",

@@ -1,25 +1,50 @@
-"""profiles/<name>_pmc.json from rocprofv3 --pmc output directories (one per counter group): mean per launch and kernel,
-hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section: gfx950 FETCH_SIZE counts 128-B requests as 64 B).
-usage: make_pmc_json.py out.json dir1 [dir2 ...]"""
+"""profiles/<round>_pmc_<config>.json from rocprofv3 --pmc output directories (one per counter group): mean per launch and kernel.
+hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section: rocprofv3 reports KiB and gfx950 counts a 128-B
+fetch as 64 B); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (the share of the issued VALU lanes switched on).
+usage: make_pmc_json.py out.json config envs_per_gpu checks dir1 [dir2 ...]"""
 import collections, csv, glob, json, re, sys
-out, roots = sys.argv[1], sys.argv[2:]
+out, config, envs, checks, roots = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5:]
+
+
+def short(name):
+    """template arguments dropped; staged instantiations of reset / spawn / target marked"""
+    k = name.split("(")[0].replace("void ", "").strip()
+    m = re.match(r"(smr::\w+?)_kernel<(.*)>", k)
+    if not m:
+        return re.sub(r"<.*", "", k)
+    base, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    if base.endswith("collide"):
+        return base + "_kernel"
+    if base.endswith("reset"):
+        return "%s_kernel<%s>" % (base, "staged" if args[0] == "true" else "sync")
+    if base.endswith("spawn") or base.endswith("target"):
+        return "%s_kernel<%s>" % (base, "staged" if args[-1] == "true" else "live")
+    return base + "_kernel"
+
+
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
 for root in roots:
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"]
-            if "smr::" not in k: continue
-            k = re.sub(r"<.*", "", k.split("(")[0].replace("void ", "")).strip()         # template arguments dropped
+            if "smr::" not in r["Kernel_Name"]:
+                continue
+            k = short(r["Kernel_Name"])
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 kernels = {}
+steps = max((max(v.values()) for k, v in n.items() if "finish" in k), default=1)
 for k in sorted(acc):
     d = {c: acc[k][c] / n[k][c] for c in sorted(acc[k])}
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d: d["hbm_bytes"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        d["hbm_bytes"] = (2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024
+    if d.get("SQ_ACTIVE_INST_VALU"):
+        d["lane_utilisation"] = d.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * d["SQ_ACTIVE_INST_VALU"])
     d["launches_sampled"] = max(n[k].values())
+    d["launches_per_step"] = round(max(n[k].values()) / steps, 3)
     kernels[k] = d
-json.dump({"command": "rocprofv3 --kernel-trace --output-format csv --pmc <counters> -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline "
-                      "(one pass per counter group: FETCH_SIZE | WRITE_SIZE | SQ_*), 65536 envs, space scene, N=3",
+json.dump({"command": "rocprofv3 --kernel-trace --output-format csv --pmc <counters> -- python3 bench.py --config %s --steps 40 --warmup 5 --no-cpu-baseline "
+                      "(one pass per counter group)" % config,
+           "run": {"config": config, "envs_per_gpu": envs, "collision_checks_per_step": checks},
            "units": "mean per launch; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                     "(gfx950: FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md \"HBM\"); SQ_*_CYCLES in quad-cycles",
            "kernels": kernels}, open(out, "w"), indent=1)
-print(out, {k: v.get("hbm_bytes") for k, v in kernels.items()})
+print(out, {k: (v.get("hbm_bytes"), v.get("SQ_INSTS_VALU"), v.get("lane_utilisation")) for k, v in kernels.items()})

@@ -186,11 +186,12 @@ extern "C" float emul_pos_margin(double plo, double phi, double V, double A, dou
     return pos_margin(gap, v, a, a1, 1e-5f * L.V, L);
 }
 
-// one lane of the collide kernel (collide_lane): body l, end-of-step sample (fin) or the contact sweep over samples 1 .. N-1 of the
-// cubic (q, v, a -> a1); out = contact, d_static, d_moving, bound evaluations, real queries.  literal != 0: every sample
-// 1 .. N-1 is tested instead (what the sweep must reproduce).  ball: NULL or the 10 floats of smr_host_state_t.ball + counters
-extern "C" void emul_collide_lane(void *h, int l, const float *q, const float *v, const float *a, const float *a1, const int *idx0, int N, int fin,
-                                  int literal, const float *ball, const int *ball_i, float *out) {
+// one lane of the collide kernel (collide_lane) and the work items it asks for (collide_item): body l over the step's cubic
+// (q, v, a -> a1).  mode 0: out = contact at the end-of-step sample, d_static, d_moving, k_need (intermediate samples still to test),
+// contact at any of those samples (the item kernel's work), the lower bound at t = dt.  lb_start: the bound at t = 0 (< 0: none).  mode 1: every sample 1 .. N-1 is tested (what mode 0 must
+// reproduce): out[4] = contact at any of them.  ball: NULL or the 10 floats of smr_host_state_t.ball + ball_i counters
+extern "C" void emul_collide_lane(void *h, int l, const float *q, const float *v, const float *a, const float *a1, const int *idx0, int N,
+                                  int mode, const float *ball, const int *ball_i, float lb_start, float *out) {
     HostScene *H = (HostScene *)h;
     DScene &S = H->d;
     S.checks_per_step = N;
@@ -204,38 +205,40 @@ extern "C" void emul_collide_lane(void *h, int l, const float *q, const float *v
     in.q = q; in.v = v; in.a = a; in.a1 = a1; in.stride = 1;
     in.planet_idx[0] = idx0[0]; in.planet_idx[1] = idx0[1]; in.moving_hit = 0;
     in.ball_k0 = in.ball_kmax = in.ball_khit = in.ball_active = 0;
+    in.lb_start = lb_start;
     if (ball) {
         for (int c = 0; c < 3; ++c) { in.ball.p0[c] = ball[c]; in.ball.v0[c] = ball[3 + c]; in.ball.e0[c] = ball[6 + c]; }
         in.ball.omega = ball[9];
         in.ball_k0 = ball_i[0]; in.ball_kmax = ball_i[1]; in.ball_khit = ball_i[2]; in.ball_active = ball_i[3];
     }
-    if (!literal) {
-        const LaneResult r = S.planets_auto ? (fin ? collide_lane<true, true, true>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1)
-                                                   : collide_lane<true, true, false>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1))
-                                            : (fin ? collide_lane<true, false, true>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1)
-                                                   : collide_lane<true, false, false>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1));
-        out[0] = r.contact ? 1.f : 0.f; out[1] = r.d_static; out[2] = r.d_moving; out[3] = (float)r.evals; out[4] = (float)r.queries;
+    const bool con_link = (S.contact_mask >> l) & 1u;
+    auto item_full = [&](int k) {
+        return S.planets_auto ? collide_item<true, true, false>(S, l, LP, hull, in, k, true, pv.data(), pd.data(), keys, 1)
+                              : collide_item<true, false, false>(S, l, LP, hull, in, k, true, pv.data(), pd.data(), keys, 1);
+    };
+    // as the kernel works an item: the bound first, the real test only when it does not clear the contact distance
+    auto item = [&](int k) {
+        const bool cand = S.planets_auto ? collide_item<true, true, true>(S, l, LP, hull, in, k, true, pv.data(), pd.data(), keys, 1)
+                                         : collide_item<true, false, true>(S, l, LP, hull, in, k, true, pv.data(), pd.data(), keys, 1);
+        return cand && item_full(k);
+    };
+    if (mode == 0) {
+        const LaneResult r = S.planets_auto ? collide_lane<true, true>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1)
+                                            : collide_lane<true, false>(S, l, LP, hull, in, pv.data(), pd.data(), keys, 1);
+        bool any = false;
+        for (int k = r.k_first; k <= r.k_need; ++k) any = any || item(k);
+        out[0] = r.contact ? 1.f : 0.f; out[1] = r.d_static; out[2] = r.d_moving; out[3] = (float)(r.k_need >= r.k_first ? r.k_need - r.k_first + 1 : 0);
+        out[4] = any ? 1.f : 0.f; out[5] = r.lb_end;
         return;
     }
     const int upd = S.updates_per_step / N;
-    const bool con_link = (S.contact_mask >> l) & 1u;
     bool contact = false;
     const int u_end = ball ? ball_retire_update(S, in.ball_k0, in.ball_kmax, in.ball_khit) : 0;
     for (int k = 1; k < N && !contact && con_link; ++k) {
         if (ball && !(in.ball_active && k * upd < u_end)) continue;
-        float qk[SMR_NJ];
-        for (int j = 0; j < SMR_NJ; ++j) qk[j] = interp_pos(q[j], v[j], a[j], a1[j], S.dt * (float)k / (float)N, S.dt);
-        const Xf T = body_frame(S, qk, l);
-        if (ball) {
-            const Xf XB = ball_pose(S, in.ball, in.ball_k0 + k * upd, nullptr);
-            const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-            contact = collide_link(S, l, LP, hull, T, nullptr, &XB, false, false, near).contact;
-        } else {
-            int idx[2] = {(idx0[0] + k * upd) % S.planet[0].n_orbit, S.n_planets > 1 ? (idx0[1] + k * upd) % S.planet[1].n_orbit : 0};
-            contact = collide_link(S, l, LP, hull, T, idx, nullptr, false, false, true).contact;
-        }
+        contact = item_full(k);
     }
-    out[0] = contact ? 1.f : 0.f; out[1] = out[2] = out[3] = out[4] = 0.f;
+    out[0] = out[1] = out[2] = out[3] = 0.f; out[4] = contact ? 1.f : 0.f;
 }
 extern "C" float emul_sweep_R(void *h, int b, int j) { return ((HostScene *)h)->d.sweep_R[b][j]; }
 extern "C" float emul_planet_step(void *h, int p) { return ((HostScene *)h)->d.planet_step[p]; }
