@@ -513,6 +513,32 @@ __device__ __forceinline__ void fk_advance(const DScene &S, int k, float qk, Xf 
     for (int i = 0; i < 9; ++i) T.r[i] = n[i];
 }
 
+// the same with the hardware sine / cosine (v_sin_f32 / v_cos_f32, absolute error ~1e-6): for BOUNDS only - link frames that feed
+// a distance or a flag always come from fk_advance
+__device__ __forceinline__ void fk_advance_fast(const DScene &S, int k, float qk, Xf &T) {
+    T.t = apply(T, F3{S.joint_xyz[k][0], S.joint_xyz[k][1], S.joint_xyz[k][2]});
+    float ax = S.joint_axis[k][0], ay = S.joint_axis[k][1], az = S.joint_axis[k][2];
+#ifdef SMR_HOST_EMUL
+    float s = std::sin(qk), c = std::cos(qk);
+#else
+    float s = __sinf(qk), c = __cosf(qk);
+#endif
+    float C = 1.f - c;
+    float j0 = c + ax * ax * C, j1 = ax * ay * C - az * s, j2 = ax * az * C + ay * s;
+    float j3 = ay * ax * C + az * s, j4 = c + ay * ay * C, j5 = ay * az * C - ax * s;
+    float j6 = az * ax * C - ay * s, j7 = az * ay * C + ax * s, j8 = c + az * az * C;
+    float n[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float r0 = T.r[3 * i], r1 = T.r[3 * i + 1], r2 = T.r[3 * i + 2];
+        n[3 * i] = r0 * j0 + r1 * j3 + r2 * j6;
+        n[3 * i + 1] = r0 * j1 + r1 * j4 + r2 * j7;
+        n[3 * i + 2] = r0 * j2 + r1 * j5 + r2 * j8;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) T.r[i] = n[i];
+}
+
 __device__ __forceinline__ Xf quat_pose(const SMR_GLOBAL float *row) {   // row: pos xyz, quat xyzw
     float x = row[3], y = row[4], z = row[5], w = row[6];
     float n = x * x + y * y + z * z + w * w;
@@ -1438,12 +1464,14 @@ struct LaneInput {
 struct LaneResult { bool contact; float d_static, d_moving; int k_first, k_need; float lb_end; };
 
 // frame of body l at time t of the step's cubic
-template <bool SELF>
+template <bool SELF, bool FAST = false>
 __device__ __forceinline__ Xf lane_frame(const DScene &S, int l, const LaneInput &in, float t) {
     const int chain = l < SMR_NLINK ? l : SMR_NLINK - 1;
     Xf T = fk_base(S);
-    for (int j = 0; j < chain; ++j)                     // FK up to this body's link; joint values straight from the cubic
-        fk_advance(S, j, interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt), T);
+    for (int j = 0; j < chain; ++j) {                   // FK up to this body's link; joint values straight from the cubic
+        const float qj = interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt);
+        if (FAST) fk_advance_fast(S, j, qj, T); else fk_advance(S, j, qj, T);
+    }
     if (SELF && l >= SMR_NLINK) T = mounted_frame(S, l, T);
     return T;
 }
@@ -1529,11 +1557,12 @@ template <bool SELF, bool AUTO, bool BOUND_ONLY, class HB>
 __device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, const HB &hull, const LaneInput &in, int k, bool live,
                                     const float *lds_pv, const float *lds_pd, uint32_t *keys, int kstride) {
     const int N = S.checks_per_step, upd = S.updates_per_step / N;
-    const Xf T = lane_frame<SELF>(S, l, in, S.dt * (float)k / (float)N);
+    const Xf T = lane_frame<SELF, BOUND_ONLY>(S, l, in, S.dt * (float)k / (float)N);      // bounds: hardware sine / cosine, covered by kBoundSlack
+    constexpr float kBoundSlack = 1e-4f;
     if (S.use_ball) {
         const Xf XB = ball_pose(S, in.ball, in.ball_k0 + k * upd, nullptr);
         const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-        if (BOUND_ONLY) return live && near && ball_lower_bound(S, LP, T, XB) <= S.contact_dist;
+        if (BOUND_ONLY) return live && near && ball_lower_bound(S, LP, T, XB) <= S.contact_dist + kBoundSlack;
         return collide_link(S, l, LP, hull, T, nullptr, &XB, false, false, live && near).contact;
     }
     int idx[SMR_MAX_PLANETS] = {0, 0};
@@ -1542,7 +1571,7 @@ __device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, co
         if (p < S.n_planets) idx[p] = (in.planet_idx[p] + k * upd) % S.planet[p].n_orbit;
     if (BOUND_ONLY) {
         const float lb = AUTO ? planet_keys(S, keys, kstride, LP, T, idx, live, S.contact_dist) : planets_lower_bound(S, LP, T, idx, S.contact_dist);
-        return live && lb <= S.contact_dist + kKeyStep;             // a candidate key (floor of the bound / kKeyStep) may exist
+        return live && lb <= S.contact_dist + kKeyStep + kBoundSlack;   // a candidate key (floor of the bound / kKeyStep) may exist
     }
     Sample r = collide_link(S, l, LP, hull, T, idx, nullptr, false, false, live, nullptr, AUTO);
     if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, false, live, r);
