@@ -39,6 +39,9 @@ CONFIGS = {
     "space_bm": ("SPACE", dict(ball_machine_mode=True), {}, 342, "space scene on robot_ball_machine.urdf = trained_networks/backup_networks/space/params.json"),
     "ball_bm": ("BALL", dict(ball_machine_mode=True), {}, 422, "ball scene on robot_ball_machine.urdf = trained_networks/backup_networks/ball/params.json"),
     "reach": ("REACH", {}, {}, 390, "target-point reaching task (SafeMotionsEnv, TargetPointReachingReward), ball machine mounted, 8 s episodes"),
+    "reach_brake": ("REACH", dict(check_braking_trajectory_collisions=True), {}, 390,
+                    "reaching task with the braking-trajectory safety layer (README.md:95: --check_braking_trajectory_collisions "
+                    "--closest_point_safety_distance=0.01 --collision_check_time=0.033)"),
 }
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 4
+#define SMR_ABI_VERSION 5
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
@@ -52,7 +52,12 @@ extern "C" {
 #define SMR_INFO_R_STATIC 5           /* static_obstacles_collision_reward,         rewards.py:128-131 */
 #define SMR_INFO_R_MOVING 6           /* moving_obstacles_collision_reward,         rewards.py:157-159 */
 #define SMR_INFO_EPISODE_LENGTH 7     /* _episode_length of the step just taken,    base.py:1044,1374 */
-#define SMR_INFO_N 8
+#define SMR_INFO_BRAKED 8             /* 1: the braking trajectory was executed instead of the action (adaptation_punishment,
+                                         ctlp.py:3060,3077-3078); 0 without check_braking_trajectory_collisions */
+#define SMR_INFO_TARGET_REACHED 9     /* 1: the target point was reached in this step, ctlp.py:2787-2821 */
+#define SMR_INFO_BALL_EVENT 10        /* final state of a ball retired in this step: 1 hit_robot, 2 hit_obstacle, 3 missed_robot
+                                         (ctlp.py:2839-2861); 0 none */
+#define SMR_INFO_N 11
 
 /* kernels timed by smr_get_profile */
 #define SMR_K_PLAN 0      /* A2/A4: safe acceleration range + action mapping            */
@@ -60,7 +65,8 @@ extern "C" {
 #define SMR_K_FINISH 2    /* A1/A12/A13/A15/A16: state update, reward, termination, obs  */
 #define SMR_K_RESET 3     /* A17/A9: start-state and planet-phase sampling               */
 #define SMR_K_SPAWN 4     /* A10: a new ball for the envs whose ball was retired         */
-#define SMR_K_COUNT 5
+#define SMR_K_BRAKE 5     /* braking-trajectory safety layer (adapt_action, ctlp.py:3055-3153) */
+#define SMR_K_COUNT 6
 
 typedef struct smr_env smr_env_t;   /* opaque */
 

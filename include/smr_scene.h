@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SMR_SCENE_VERSION 6
+#define SMR_SCENE_VERSION 7
 #define SMR_NJ 7          /* manipulator joints (iiwa_joint_1..7, robot.urdf)            */
 #define SMR_NLINK 8       /* chain links iiwa_link_0..7; link k moves with joints 1..k      */
 #define SMR_MAX_BODIES 10 /* collision bodies = the 8 chain links + convex pieces rigidly mounted on one of them
@@ -179,6 +179,20 @@ typedef struct smr_scene {
     double low_vel_max_reward, low_vel_threshold;
     double termination_bonus, early_termination_punishment;
     double collision_distance;          /* 0.001, rewards.py:115,119,153 */
+
+    /* ---- braking-trajectory safety layer: btg.py:44-93, ctlp.py:3026-3207,3468-3506, adapt_action :3055-3153 ----
+     * An action is executed only if the step it commands, followed by braking to a standstill, keeps every observed link at least
+     * brake_safety_distance from the static obstacles and the self-collision partners at brake_checks_per_step samples per step;
+     * otherwise the braking acceleration replaces it. */
+    int32_t check_braking_trajectory_collisions;   /* base.py:122 */
+    int32_t brake_checks_per_step;      /* _collision_checks_per_time_step = round(max(1, dt / collision_check_time)), ctlp.py:99-103 */
+    int32_t brake_timeout_steps;        /* first number of braking steps m with m dt > braking_timeout = 2.0 s, ctlp.py:3468-3473 */
+    int32_t _pad4;
+    double brake_safety_distance;       /* closest_point_safety_distance, ctlp.py:3307,3364 */
+    double brake_acc_max[SMR_NJ];       /* acc_limit_factor_braking x max accelerations, actions.py:76-77 */
+    double brake_jerk_max[SMR_NJ];      /* actions.py:78-82 */
+    double brake_stop_velocity;         /* 0.01: below it (and brake_stop_acceleration) a joint counts as stopped, btg.py:45,75-77 */
+    double brake_stop_acceleration;
 
     /* ---- reset (A17), ctlp.py:1461-1656,1980-2138 ---- */
     double start_box[3][2];             /* ctlp.py:172-183 */

@@ -10,7 +10,7 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_DIR, "libsmr_oracle.so")
-INFO_N = 8
+INFO_N = 11
 NJ = 7
 
 
@@ -45,6 +45,7 @@ def lib():
         L.smo_vel_upper_a1max.argtypes = [C.c_double] * 6
         L.smo_vel_peak_bruteforce.restype = C.c_double
         L.smo_vel_peak_bruteforce.argtypes = [C.c_double] * 7
+        L.smo_braking_trajectory_unsafe.restype = C.c_int32
         L.smo_philox_word.restype = C.c_uint32
         L.smo_philox_word.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         _lib = L
@@ -164,6 +165,16 @@ class OracleEnv:
 
     def self_pair_distance(self, q, i):
         return self.L.smo_self_pair_distance(self.h, _p(_d(q)), C.c_int32(i))
+
+    def braking_acceleration(self, q, v, a):
+        """(braking acceleration clipped into the safe range, robot_stopped): ctlp.py:3494-3506, btg.py:44-93"""
+        b = np.zeros(NJ)
+        stopped = self.L.smo_braking_acceleration(self.h, _p(_d(q)), _p(_d(v)), _p(_d(a)), _p(b))
+        return b, bool(stopped)
+
+    def braking_trajectory_unsafe(self, q, v, a, a1):
+        """check_braking_trajectory_method, ctlp.py:3026-3053"""
+        return bool(self.L.smo_braking_trajectory_unsafe(self.h, _p(_d(q)), _p(_d(v)), _p(_d(a)), _p(_d(a1))))
 
     def position_is_valid(self, q):
         return bool(self.L.smo_position_is_valid(self.h, _p(_d(q))))

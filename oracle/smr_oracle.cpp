@@ -846,6 +846,99 @@ void spawn_ball(Oracle &O, int e) {
     st.ball_active = 1;
 }
 
+/* ------------------------------------------------------------------------------------------- *
+ * Braking-trajectory safety layer.
+ *   braking acceleration: BrakingTrajectoryGenerator.get_clipped_braking_acceleration, btg.py:44-93 - a second klimits
+ *     PosVelJerkLimitation with velocity limits [0, 0], position limits off, acceleration / jerk limits of the braking
+ *     factors; for v >= 0 the LOWER end of its range is taken, for v < 0 the upper end (btg.py:63-65), then clipped
+ *     into the safe range of the full limits (btg.py:80-93).  klimits' braking mode is not in /root/reference
+ *     (PARITY UNPINNED, as A4).  Restated as the discrete-time law of its paper (Kiemel & Kroeger 2021, "reach the velocity
+ *     limit with zero acceleration at a time step"): the lowest end acceleration a1 inside the jerk / acceleration box from
+ *     which the acceleration can be taken back to zero, by at most D = J dt per knot, without the velocity crossing zero:
+ *         v + (a0 + a1) dt / 2 + R(a1) >= 0,   R(a1) = dt [(n + 1/2) a1 + n (n + 1) D / 2],  n D < |a1| <= (n + 1) D
+ *     (velocity after the step plus the velocity lost while a1 < 0 returns to zero; mirrored for v < 0).  If the velocity
+ *     crosses zero within the step even with a1 = 0, a1 > 0 is the smallest value that keeps the dip inside the step at zero.
+ *     Following it the joint reaches (v, a) = (0, 0) at a knot and stays there - no oscillation about zero.
+ *   check: _check_if_braking_trajectory_is_collision_free, ctlp.py:3155-3207 with get_minimum_distance :3282-3374.
+ * ------------------------------------------------------------------------------------------- */
+double braking_acceleration_joint(const smr_scene_t &S, int j, double v, double a) {
+    if (std::fabs(v) < S.brake_stop_velocity && std::fabs(a) < S.brake_stop_acceleration) return 0.0;   /* btg.py:75-77 */
+    const double A = S.brake_acc_max[j], dt = S.dt, D = S.brake_jerk_max[j] * dt;
+    const double sgn = v < 0 ? -1.0 : 1.0, vm = sgn * v, am = sgn * a;      /* mirrored: vm >= 0, decelerate with a1 < 0 */
+    double blo = std::max(-A, am - D), bhi = std::min(A, am + D);
+    if (blo > bhi) blo = bhi = std::min(std::max(am, -A), A);
+    const double tol = kVelTolRel * S.vel_max[j];                            /* velocity limits [0, 0] with the range's design tolerance */
+    const double c = vm + tol + 0.5 * am * dt;                               /* velocity after the step if a1 = 0 */
+    double a1;
+    if (c >= 0) {                                                            /* a1 <= 0: n whole knots of D, then the rest, back to zero */
+        a1 = -A;
+        for (int n = 0; n < 64; ++n) {
+            double x = (-c / dt - 0.5 * n * (n + 1) * D) / (n + 1);
+            if (x >= -(n + 1) * D - 1e-12) { a1 = std::min(x, 0.0); break; }
+        }
+    } else if (am < 0 && vm + tol > 0) a1 = am + am * am * dt / (2.0 * (vm + tol));   /* the dip inside the step stays at zero */
+    else a1 = bhi;
+    return sgn * std::max(blo, std::min(a1, bhi));
+}
+
+/* _compute_braking_acceleration, ctlp.py:3494-3506: braking acceleration of every joint clipped into the safe range of
+ * the state; returns robot_stopped (btg.py:45-47) */
+bool braking_acceleration(const smr_scene_t &S, const double q[SMR_NJ], const double v[SMR_NJ], const double a[SMR_NJ], double b[SMR_NJ]) {
+    bool stopped = true;
+    for (int j = 0; j < SMR_NJ; ++j)
+        if (!(std::fabs(v[j]) < S.brake_stop_velocity && std::fabs(a[j]) < S.brake_stop_acceleration)) stopped = false;
+    for (int j = 0; j < SMR_NJ; ++j) {
+        if (stopped) { b[j] = 0.0; continue; }
+        double lo, hi;
+        int code;
+        safe_acc_range_joint(joint_lim(S, j), q[j], v[j], a[j], lo, hi, code);
+        b[j] = std::min(std::max(braking_acceleration_joint(S, j, v[j], a[j]), lo), hi);
+    }
+    return stopped;
+}
+
+/* get_minimum_distance with check_safety_distance, ctlp.py:3282-3374: a static obstacle or a self-collision partner closer
+ * than the safety distance */
+bool closer_than_safety_distance(const Oracle &O, const double q[SMR_NJ]) {
+    const smr_scene_t &S = O.S;
+    Xf link[SMR_MAX_BODIES];
+    forward_kinematics(S, q, link);
+    Xf I = identity_xf();
+    const double thr = S.brake_safety_distance;
+    for (int s = 0; s < S.n_static; ++s)
+        for (int k = 0; k < S.n_bodies; ++k) {
+            if (!(S.static_link_mask & (1u << k))) continue;
+            double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], thr + 0.005);
+            if (d <= thr + 0.005 && d < thr) return true;
+        }
+    return !self_pairs_clear(O, link, thr);
+}
+
+/* check_braking_trajectory_method, ctlp.py:3026-3053: true = executing target acceleration a1 and braking afterwards is NOT
+ * collision free (or does not stop within the braking timeout): the braking trajectory has to be executed instead */
+bool braking_trajectory_unsafe(const Oracle &O, const double q0[SMR_NJ], const double v0[SMR_NJ], const double a0[SMR_NJ],
+                               const double a1[SMR_NJ]) {
+    const smr_scene_t &S = O.S;
+    double p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ];
+    std::memcpy(p, q0, sizeof p); std::memcpy(v, v0, sizeof v); std::memcpy(ap, a0, sizeof ap); std::memcpy(an, a1, sizeof an);
+    const int Nb = S.brake_checks_per_step;
+    for (int m = 0;; ++m) {
+        for (int sidx = 1; sidx <= Nb; ++sidx) {                                  /* time_since_start = linspace(dt / Nb, dt, Nb), ctlp.py:3167-3169 */
+            double t = sidx == Nb ? S.dt : S.dt * sidx / Nb, qs[SMR_NJ];
+            for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt);
+            if (closer_than_safety_distance(O, qs)) return true;
+        }
+        if (m >= S.brake_timeout_steps) return true;                              /* braking_timeout, ctlp.py:3468-3473 */
+        double p1[SMR_NJ], v1[SMR_NJ], b[SMR_NJ];
+        for (int j = 0; j < SMR_NJ; ++j) {
+            p1[j] = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt);
+            v1[j] = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
+        }
+        if (braking_acceleration(S, p1, v1, an, b)) return false;                 /* robot stopped, nothing hit */
+        std::memcpy(p, p1, sizeof p); std::memcpy(v, v1, sizeof v); std::memcpy(ap, an, sizeof ap); std::memcpy(an, b, sizeof an);
+    }
+}
+
 void reset_env(Oracle &O, int e) {
     const smr_scene_t &S = O.S;
     EnvState &st = O.st[e];
@@ -957,7 +1050,7 @@ void reset_env(Oracle &O, int e) {
 
 /* info columns written by step (mirrors the product's SMR_INFO_* layout) */
 enum { INFO_D_STATIC = 0, INFO_D_SELF, INFO_D_MOVING, INFO_ACTION_PUNISHMENT, INFO_R_SELF, INFO_R_STATIC,
-       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_N };
+       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_BRAKED, INFO_TARGET_REACHED, INFO_BALL_EVENT, INFO_N };
 
 /* A1/A2/A3/A11/A12/A13/A16: SafeMotionsBase.step + process_step_outcome for one env. */
 void step_env(Oracle &O, int e, const double *action, float *obs, double *reward, uint8_t *done,
@@ -973,6 +1066,13 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         int code;
         safe_acc_range_joint(joint_lim(S, j), st.q[j], st.v[j], st.a[j], lo, hi, code);
         a1[j] = lo + 0.5 * (action[j] + 1.0) * (hi - lo);
+    }
+    /* adapt_action, ctlp.py:3055-3153 / actions.py:340-361: the braking acceleration replaces an action whose step + braking
+     * trajectory is not collision free (the stored valid braking trajectory continues from exactly this state) */
+    bool braked = false;
+    if (S.check_braking_trajectory_collisions && braking_trajectory_unsafe(O, st.q, st.v, st.a, a1)) {
+        braking_acceleration(S, st.q, st.v, st.a, a1);
+        braked = true;
     }
 
     /* A11: moving-obstacle contact latch along the segment, ctlp.py:2626-2637 (N samples per step) */
@@ -1034,11 +1134,15 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
     if (S.static_max_reward != 0) { double r = std::min(1.0, d_static / S.static_max_reward_distance); r_static = r * r; }
     double d_moving;
     bool ball_retired = false;
+    int ball_event = 0;                                                      /* 1 hit_robot, 2 hit_obstacle, 3 missed_robot */
     if (S.use_ball) {                                                        /* ctlp.py:3217-3256 */
         d_moving = S.moving_max_distance + 0.002;
         if (ball_active0) {
-            if (ball_hit) { d_moving = 0.0; ball_retired = true; }           /* final state hit_robot, ctlp.py:3224-3227 */
-            else if (u_end <= S.updates_per_step) ball_retired = true;       /* missed the robot / hit an obstacle */
+            if (ball_hit) { d_moving = 0.0; ball_retired = true; ball_event = 1; }   /* final state hit_robot, ctlp.py:3224-3227 */
+            else if (u_end <= S.updates_per_step) {                          /* missed the robot / hit an obstacle, ctlp.py:2839-2848 */
+                ball_retired = true;
+                ball_event = (st.ball_k + u_end > st.ball_kmax) ? 3 : 2;
+            }
             else {
                 st.ball_k += S.updates_per_step;
                 d_moving = ball_min_distance(O, link, ball_pose(O, st, st.ball_k, nullptr));
@@ -1113,6 +1217,7 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         info[INFO_D_STATIC] = d_static; info[INFO_D_SELF] = d_self; info[INFO_D_MOVING] = d_moving;
         info[INFO_ACTION_PUNISHMENT] = action_punishment; info[INFO_R_SELF] = r_self;
         info[INFO_R_STATIC] = r_static; info[INFO_R_MOVING] = r_moving; info[INFO_EPISODE_LENGTH] = st.step_count;
+        info[INFO_BRAKED] = braked ? 1.0 : 0.0; info[INFO_TARGET_REACHED] = tp_reached ? 1.0 : 0.0; info[INFO_BALL_EVENT] = ball_event;
     }
     if (d && S.auto_reset) reset_env(O, e);
     else {
@@ -1334,6 +1439,13 @@ void smo_ball_distances(void *h, const double *q, const double *ball, int32_t k,
     Xf Xb = ball_pose(O, st, k, nullptr);
     out[2] = ball_min_distance(O, link, Xb);
     out[3] = ball_contact(O, link, Xb) ? 1.0 : 0.0;
+}
+
+int32_t smo_braking_acceleration(void *h, const double *q, const double *v, const double *a, double *b) {
+    return braking_acceleration(((Oracle *)h)->S, q, v, a, b) ? 1 : 0;
+}
+int32_t smo_braking_trajectory_unsafe(void *h, const double *q, const double *v, const double *a, const double *a1) {
+    return braking_trajectory_unsafe(*(Oracle *)h, q, v, a, a1) ? 1 : 0;
 }
 
 int32_t smo_position_is_valid(void *h, const double *q) { return position_is_valid(*(Oracle *)h, q) ? 1 : 0; }

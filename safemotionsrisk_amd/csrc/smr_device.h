@@ -118,6 +118,9 @@ struct DScene {
     float self_max_reward, self_max_dist, static_max_reward, static_max_dist, moving_max_reward, moving_max_dist;
     float low_acc_reward, low_acc_thr, low_vel_reward, low_vel_thr;
     float term_bonus, early_term_pun, collision_dist;
+    // braking-trajectory safety layer (btg.py, ctlp.py:3026-3207)
+    int check_braking, brake_checks, brake_timeout_steps;
+    float brake_safety, brake_acc_max[SMR_NJ], brake_jerk_max[SMR_NJ], brake_stop_v, brake_stop_a;
     float start_box[3][2];
     float start_min_static, start_min_self;
     int kin_mode;
@@ -135,6 +138,7 @@ struct DState {
     float *a1;                 // [7][B]   plan -> collide/finish
     float *res;                // [n_bodies][B] collide -> finish: contact of body l at any of the N contact samples of the step
     float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
+    int *braked;               // [B] 1: the braking acceleration replaced this step's action (adapt_action, ctlp.py:3055-3153)
     float *lb_moving;          // [n_bodies][B] lower bound of the body's distance to every moving piece at the end of the last step
                                // (< 0: none - new episode, injected state); the next step's lanes rule out their first samples with it
     int *done_list;            // [B]
@@ -479,6 +483,41 @@ __device__ __forceinline__ JointLim joint_lim(const DScene &S, int j) {
     JointLim L = {S.pos_lo[j], S.pos_hi[j], S.vel_max[j], S.acc_max[j], S.jerk_max[j], S.dt, S.pos_lo_res[j], S.pos_hi_res[j], S.vel_max_res[j], 0.f, 0.f};
     L.derive();
     return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Braking acceleration of one joint (BrakingTrajectoryGenerator.get_braking_acceleration, btg.py:44-78; klimits' braking mode
+// restated as in the CPU restatement under oracle/: PARITY UNPINNED).  The lowest end acceleration a1 inside the jerk / acceleration box
+// from which the acceleration can be taken back to zero, by at most D = J dt per knot, without the velocity crossing zero
+// (mirrored for v < 0): the joint reaches (v, a) = (0, 0) at a knot and stays there.
+// ---------------------------------------------------------------------------------------------
+__device__ inline float braking_acceleration_joint(const DScene &S, int j, float v, float a) {
+    if (fabsf(v) < S.brake_stop_v && fabsf(a) < S.brake_stop_a) return 0.f;        // btg.py:75-77
+    const float A = S.brake_acc_max[j], dt = S.dt, D = S.brake_jerk_max[j] * dt;
+    const float sgn = v < 0.f ? -1.f : 1.f, vm = sgn * v, am = sgn * a;
+    float blo = fmaxf(-A, am - D), bhi = fminf(A, am + D);
+    if (blo > bhi) blo = bhi = fminf(fmaxf(am, -A), A);
+    const float tol = 1e-5f * S.vel_max[j];
+    const float c = vm + tol + 0.5f * am * dt;                                     // velocity after the step if a1 = 0
+    float a1;
+    if (c >= 0.f) {                                                                // n whole knots of D, then the rest, back to zero
+        a1 = -A;
+        for (int n = 0; n < 64; ++n) {
+            const float x = (-c / dt - 0.5f * (float)(n * (n + 1)) * D) / (float)(n + 1);
+            if (x >= -(float)(n + 1) * D - 1e-6f) { a1 = fminf(x, 0.f); break; }
+        }
+    } else if (am < 0.f && vm + tol > 0.f) a1 = am + am * am * dt / (2.0f * (vm + tol));   // the dip inside the step stays at zero
+    else a1 = bhi;
+    return sgn * fmaxf(blo, fminf(a1, bhi));
+}
+
+// Can a position limit shape the safe range of (p, v, a)?  No if the joint cannot get there even at full speed-up for one step and
+// the gentlest stop the range computation considers afterwards (then the range is the velocity range inside the jerk /
+// acceleration box, which contains the braking acceleration); a factor of two on top.
+__device__ __forceinline__ bool position_limit_in_reach(const JointLim &L, float p, float v) {
+    const float vm = fabsf(v) + L.A * L.dt;
+    const float reach = 2.0f * (vm * (2.0f * L.dt + L.A * L.iJ) + 0.5f * vm * vm / L.A);
+    return (L.phi - p) < reach || (p - L.plo) < reach;
 }
 
 // ---------------------------------------------------------------------------------------------

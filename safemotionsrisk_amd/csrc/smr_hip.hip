@@ -312,16 +312,17 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     // ball bookkeeping (ctlp.py:2823-2861, 3217-3228): hit robot -> distance 0 and a new ball; passed the robot or
     // reached table/ground -> a new ball; otherwise 24 more updates
     BallState ball;
-    int ball_k = 0, ball_active = 0;
+    int ball_k = 0, ball_active = 0, ball_event = 0;                           // 1 hit_robot, 2 hit_obstacle, 3 missed_robot
     bool ball_respawn = false;
     if (S.use_ball) {
         ball = load_ball(st, B, e);
         ball_k = st.ball_i[e];
         ball_active = st.ball_i[3 * B + e];
         if (ball_active) {
-            const int u_end = ball_retire_update(S, ball_k, st.ball_i[B + e], st.ball_i[2 * B + e]);
-            if (contact) { d_moving = 0.f; ball_active = 0; }
-            else if (u_end <= S.updates_per_step) { d_moving = S.moving_max + 0.002f; ball_active = 0; }
+            const int kmax = st.ball_i[B + e];
+            const int u_end = ball_retire_update(S, ball_k, kmax, st.ball_i[2 * B + e]);
+            if (contact) { d_moving = 0.f; ball_active = 0; ball_event = 1; }
+            else if (u_end <= S.updates_per_step) { d_moving = S.moving_max + 0.002f; ball_active = 0; ball_event = ball_k + u_end > kmax ? 3 : 2; }   // ctlp.py:2839-2848
             else ball_k += S.updates_per_step;
         } else {
             d_moving = S.moving_max + 0.002f;
@@ -382,6 +383,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         row[SMR_INFO_D_STATIC] = d_static; row[SMR_INFO_D_SELF] = d_self; row[SMR_INFO_D_MOVING] = d_moving;
         row[SMR_INFO_ACTION_PUNISHMENT] = action_pun; row[SMR_INFO_R_SELF] = r_self; row[SMR_INFO_R_STATIC] = r_static;
         row[SMR_INFO_R_MOVING] = r_moving; row[SMR_INFO_EPISODE_LENGTH] = (float)steps;
+        row[SMR_INFO_BRAKED] = S.check_braking ? (float)st.braked[e] : 0.f; row[SMR_INFO_TARGET_REACHED] = tp_reached ? 1.f : 0.f;
+        row[SMR_INFO_BALL_EVENT] = (float)ball_event;
     }
 
 #pragma unroll
@@ -527,6 +530,81 @@ __device__ inline bool group_ball_contact(const DScene &S, const Group &G, const
             contact = contact || d <= S.contact_dist;
         }
     return G.any(contact);
+}
+
+// ---- braking-trajectory safety layer: btg.py:44-93, ctlp.py:3026-3207,3468-3506 ----
+// get_minimum_distance with check_safety_distance (ctlp.py:3282-3374) for joint vector q: no static obstacle and no self-collision
+// partner closer than the safety distance; lane g of the group tests bodies g, g + 8 and self pairs g, g + 8
+template <bool EXTRA>
+__device__ inline bool group_brake_clear(const DScene &S, const Group &G, const float q[SMR_NJ]) {
+    bool ok = true;
+    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear<EXTRA>(S, b, q, body_frame(S, q, b), S.brake_safety);
+    if (EXTRA) ok = ok && lane_self_pairs_clear(S, G, q, S.brake_safety);
+    return G.all(ok);
+}
+
+// _compute_braking_acceleration (ctlp.py:3494-3506) for the joint of lane g (lanes 0..6): braking acceleration, clipped into the safe
+// range of the state where a position limit can shape that range.  All 8 lanes of the group call together.
+__device__ inline float group_braking_acceleration(const DScene &S, const Group &G, const JointLim &L, int jj, float p, float v, float a, bool joint_lane) {
+    float b = joint_lane ? braking_acceleration_joint(S, jj, v, a) : 0.f;
+    const bool want = joint_lane && position_limit_in_reach(L, p, v);
+    if (G.any(want)) {
+        float lo, hi;
+        int code;
+        safe_acc_range_joint<8>(L, p, v, a, lo, hi, code, want);
+        if (want) b = fminf(fmaxf(b, lo), hi);                                          // btg.py:80-93
+    }
+    return b;
+}
+
+// check_braking_trajectory_method (ctlp.py:3026-3053, _check_if_braking_trajectory_is_collision_free :3155-3207): lane g < 7 holds joint g
+// of the state (q, v, a) and of the target acceleration a1.  True: the step with a1 followed by braking to a standstill is NOT collision
+// free (or does not stop within the braking timeout).
+template <bool EXTRA>
+__device__ inline bool group_braking_unsafe(const DScene &S, const Group &G, const JointLim &L, int jj, float qj, float vj, float aj, float a1j) {
+    const bool joint_lane = G.g < SMR_NJ;
+    float p = qj, v = vj, ap = aj, an = a1j;
+    const int Nb = S.brake_checks;
+    for (int m = 0;; ++m) {
+        for (int sidx = 1; sidx <= Nb; ++sidx) {                                        // linspace(dt / Nb, dt, Nb), ctlp.py:3167-3169
+            const float t = sidx == Nb ? S.dt : S.dt * (float)sidx / (float)Nb;
+            float qs[SMR_NJ];
+            G.gather(interp_pos(p, v, ap, an, t, S.dt), qs);
+            if (!group_brake_clear<EXTRA>(S, G, qs)) return true;
+        }
+        if (m >= S.brake_timeout_steps) return true;                                    // braking_timeout, ctlp.py:3468-3473
+        const float p1 = interp_pos(p, v, ap, an, S.dt, S.dt), v1 = interp_vel(v, ap, an, S.dt, S.dt);
+        const bool stopped = !joint_lane || (fabsf(v1) < S.brake_stop_v && fabsf(an) < S.brake_stop_a);
+        if (G.all(stopped)) return false;                                               // robot stopped, nothing hit (btg.py:45-47)
+        const float b = group_braking_acceleration(S, G, L, jj, p1, v1, an, joint_lane);
+        p = p1; v = v1; ap = an; an = b;
+    }
+}
+
+// adapt_action (ctlp.py:3055-3153, actions.py:340-361): one group of 8 lanes per env; the end acceleration the plan kernel derived from
+// the action is replaced by the braking acceleration when its braking trajectory is not collision free
+template <bool EXTRA>
+__global__ __launch_bounds__(64) void brake_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t >> 3, g = t & 7;
+    if (e >= S.B) return;
+    const int B = S.B;
+    const Group G{g, (int)(threadIdx.x & 63) & ~7};
+    const int jj = g < SMR_NJ ? g : 0;
+    const JointLim L = joint_lim(S, jj);
+    const float qj = st.q[jj * B + e], vj = st.v[jj * B + e], aj = st.a[jj * B + e], a1j = st.a1[jj * B + e];
+    const bool unsafe = group_braking_unsafe<EXTRA>(S, G, L, jj, qj, vj, aj, a1j);
+    if (G.any(unsafe)) {                                 // group uniform; the stored valid braking trajectory continues from exactly this state
+        float all_v[SMR_NJ], all_a[SMR_NJ];
+        G.gather(vj, all_v); G.gather(aj, all_a);
+        bool stopped = true;
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) stopped = stopped && fabsf(all_v[j]) < S.brake_stop_v && fabsf(all_a[j]) < S.brake_stop_a;
+        const float b = group_braking_acceleration(S, G, L, jj, qj, vj, aj, g < SMR_NJ);
+        if (g < SMR_NJ) st.a1[g * B + e] = stopped ? 0.f : b;
+    }
+    if (g == 7) st.braked[e] = unsafe ? 1 : 0;
 }
 
 // end-effector point in float64 (the ball is aimed at it; its launch arithmetic runs in float64 so that the
@@ -1281,6 +1359,9 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     d.collision_dist = (float)s.collision_distance;
     for (int c = 0; c < 3; ++c) { d.start_box[c][0] = (float)s.start_box[c][0]; d.start_box[c][1] = (float)s.start_box[c][1]; }
     d.start_min_static = (float)s.start_min_dist_static; d.start_min_self = (float)s.start_min_dist_self;
+    d.check_braking = s.check_braking_trajectory_collisions; d.brake_checks = s.brake_checks_per_step; d.brake_timeout_steps = s.brake_timeout_steps;
+    d.brake_safety = (float)s.brake_safety_distance; d.brake_stop_v = (float)s.brake_stop_velocity; d.brake_stop_a = (float)s.brake_stop_acceleration;
+    copy3(d.brake_acc_max, s.brake_acc_max, SMR_NJ); copy3(d.brake_jerk_max, s.brake_jerk_max, SMR_NJ);
     d.kin_mode = s.kinematic_state_sampling_mode; d.kin_prob = (float)s.kinematic_state_sampling_probability;
     d.stay_prob = (float)s.stay_in_state_probability;
     d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32);
@@ -1302,6 +1383,10 @@ static int check_scene(const smr_scene_t *s, int32_t num_envs, std::string &err)
                  (s->use_target_points ? 3 * ((s->obs_target_pos ? 1 : 0) + (s->obs_target_rel ? 1 : 0)) : 0);
     if (s->obs_size != expect) { err = "obs_size does not match the scene"; return SMR_E_INVALID; }
     if (!(s->dt > 0) || s->episode_steps <= 0) { err = "bad time parameters"; return SMR_E_INVALID; }
+    if (s->check_braking_trajectory_collisions) {
+        if (s->collision_avoidance_mode) { err = "check_braking_trajectory_collisions with collision_avoidance_mode is not supported (start-state sampling, ctlp.py:1499-1545)"; return SMR_E_INVALID; }
+        if (s->brake_checks_per_step < 1 || s->brake_timeout_steps < 1 || !(s->brake_safety_distance >= 0)) { err = "bad braking parameters"; return SMR_E_INVALID; }
+    }
     return SMR_OK;
 }
 
@@ -1354,11 +1439,11 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)) || (rc = dev_alloc(env, &env->spawn_tag_lists, 3 * B)))
         return fail(rc);
-    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12) || hipMemset(st.lb_moving, 0xFF, (size_t)scene->n_bodies * B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12) || hipMemset(st.lb_moving, 0xFF, (size_t)scene->n_bodies * B * 4) || hipMemset(st.braked, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts; st.spawn_tags = env->spawn_tag_lists;
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
@@ -1686,6 +1771,13 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
     }
     SMR_HIP(hipGetLastError());
+    if (env->hscene.check_braking) {                    // adapt_action: the braking acceleration replaces actions whose braking trajectory collides
+        LaunchTimer t(env, SMR_K_BRAKE);
+        const dim3 grid(((size_t)B * 8 + 63) / 64);
+        if (scene_extra(env)) hipLaunchKernelGGL((brake_kernel<true>), grid, dim3(64), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((brake_kernel<false>), grid, dim3(64), 0, env->stream, env->dscene, env->st);
+        SMR_HIP(hipGetLastError());
+    }
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
         const bool self = env->hscene.n_self_pairs > 0, autop = env->hscene.planets_auto != 0;

@@ -43,7 +43,8 @@ class VecSafeMotionsEnv:
 
     INFO_COLUMNS = ("minimum_distance_to_static_obstacles", "minimum_distance_self_collision",
                     "minimum_distance_to_moving_obstacles", "action_punishment", "self_collision_reward",
-                    "static_obstacles_collision_reward", "moving_obstacles_collision_reward", "episode_length")
+                    "static_obstacles_collision_reward", "moving_obstacles_collision_reward", "episode_length",
+                    "braking_trajectory_executed", "target_point_reached", "moving_object_final_state")
 
     def __init__(self, num_envs, device=0, seed=None, auto_reset=True, collision_checks_per_step=None,
                  contact_distance=None, return_info=True, env_index_offset=0, **env_config):

@@ -16,10 +16,10 @@ LIB_PATH = os.path.join(_PKG, "libsmr_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 
-ABI_VERSION = 4
-INFO_N = 8
-K_COUNT = 5
-KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn")
+ABI_VERSION = 5
+INFO_N = 11
+K_COUNT = 6
+KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn", "brake")
 
 #: every symbol include/safemotions_hip.h declares
 EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "smr_last_error", "smr_num_envs",

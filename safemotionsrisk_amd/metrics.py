@@ -35,6 +35,11 @@ TERMINATION_RATE_KEYS = {
 }
 
 
+#: event columns of the info matrix: folded into the episode-end statistics of ObstacleWrapperSim.get_info_and_print_stats
+#: (ctlp.py:1141-1309) instead of the per-step average / max / min scalars
+EVENT_COLUMNS = ("braking_trajectory_executed", "target_point_reached", "moving_object_final_state")
+
+
 def step_scalar_names(info_columns):
     """Names of the per-step scalars, in the order of the columns of EpisodeMetrics' accumulators.
     obs-derived: observations.py:376-403 (joint_{j}_{pos,vel,acc}[_abs], joint_vel_norm); info-derived: the library's
@@ -45,7 +50,7 @@ def step_scalar_names(info_columns):
     for kind in ("pos", "vel", "acc"):
         names += ["joint_%d_%s_abs" % (j, kind) for j in range(NJ)]
     names += ["joint_vel_norm"]
-    names += [c for c in info_columns if c != "episode_length"]
+    names += [c for c in info_columns if c != "episode_length" and c not in EVENT_COLUMNS]
     names += ["collision_rate_self", "collision_rate_static_obstacles", "collision_rate_moving_obstacles", "reward"]
     return names
 
@@ -74,7 +79,8 @@ class EpisodeMetrics:
         self.num_envs, self.auto_reset = int(num_envs), bool(auto_reset)
         self.info_columns = tuple(info_columns)
         self.names = step_scalar_names(self.info_columns)
-        self._info_sel = [i for i, c in enumerate(self.info_columns) if c != "episode_length"]
+        self._info_sel = [i for i, c in enumerate(self.info_columns) if c != "episode_length" and c not in EVENT_COLUMNS]
+        self._event_cols = [self.info_columns.index(c) if c in self.info_columns else None for c in EVENT_COLUMNS]
         self._len_col = self.info_columns.index("episode_length")
         self._d_cols = [self.info_columns.index(c) for c in ("minimum_distance_self_collision", "minimum_distance_to_static_obstacles",
                                                              "minimum_distance_to_moving_obstacles")]
@@ -85,6 +91,9 @@ class EpisodeMetrics:
         self.max = torch.full((self.num_envs, K), -float("inf"), **kw)
         self.min = torch.full((self.num_envs, K), float("inf"), **kw)
         self.count = torch.zeros((self.num_envs, K), **kw)
+        # episode-end statistics of the obstacle wrapper (ctlp.py:1141-1309): steps, steps with the braking trajectory executed,
+        # target points reached, balls by final state (hit_robot, hit_obstacle, missed_robot)
+        self.events = torch.zeros((self.num_envs, 6), **kw)
 
     def step_scalars(self, obs, reward, info_values):
         """[B, K] per-step scalars (the values of the reference's info['average'] entries of this step)."""
@@ -110,6 +119,9 @@ class EpisodeMetrics:
         self.count += valid.float()
         self.max = t.where(valid, t.maximum(self.max, x), self.max)
         self.min = t.where(valid, t.minimum(self.min, x), self.min)
+        v = info["values"]
+        braked, reached, ball = [v[:, c].float() if c is not None and c < v.shape[1] else t.zeros_like(reward, dtype=t.float32) for c in self._event_cols]
+        self.events += t.stack([t.ones_like(braked), braked, reached, (ball == 1).float(), (ball == 2).float(), (ball == 3).float()], dim=1)
         idx = d.nonzero(as_tuple=True)[0]
         if idx.numel() == 0:
             e = idx.new_zeros((0,))
@@ -130,11 +142,43 @@ class EpisodeMetrics:
             metrics["trajectory_length"] = t.full_like(metrics["episode_length"], float(self.trajectory_length))
         for code, name in TERMINATION_RATE_KEYS.items():
             metrics[name] = (reason == code).float()
+        metrics.update(self._obstacle_stats(self.events[idx]))
+        self.events[idx] = 0
         self.sum[idx] = 0
         self.count[idx] = 0
         self.max[idx] = -float("inf")
         self.min[idx] = float("inf")
         return FinishedEpisodes(idx, length, reason, metrics)
+
+
+    def _obstacle_stats(self, ev):
+        """ObstacleWrapperSim.get_info_and_print_stats (ctlp.py:1141-1309), the part this path produces: the braking-trajectory
+        influence (torque checks are physics: 0), target points reached, final states of the balls of the episode.  Not produced:
+        the sampling-attempt counts (ctlp.py:1151,1171-1176) and obstacles_link_data_* (log_obstacle_data)."""
+        t = self._t
+        steps, braked, reached, hit_robot, hit_obstacle, missed = ev.unbind(dim=1)
+        infl = braked / steps.clamp(min=1)
+        zero = t.zeros_like(infl)
+        out = {"obstacles_time_influenced_by_braking_trajectory": infl,
+               "obstacles_time_influenced_by_braking_trajectory_collision": infl,
+               "obstacles_time_influenced_by_braking_trajectory_torque": zero,
+               "obstacles_episodes_without_influence_by_braking_trajectory": (infl == 0).float(),
+               "obstacles_episodes_without_influence_by_braking_trajectory_collision": (infl == 0).float(),
+               "obstacles_episodes_without_influence_by_braking_trajectory_torque": t.ones_like(infl),
+               "obstacles_episodes_with_braking_timeout": zero,                  # a timed-out braking trajectory counts as a collision here
+               "obstacles_num_target_points_reached": reached}
+        if self._event_cols[2] is not None:
+            total = hit_robot + hit_obstacle + missed
+            out.update({"moving_object_hit_robot_total": hit_robot, "moving_object_hit_obstacle_total": hit_obstacle,
+                        "moving_object_hit_robot_or_obstacle_total": hit_robot + hit_obstacle, "moving_object_missed_robot_total": missed,
+                        "moving_object_hit_robot_r0": hit_robot, "moving_object_hit_obstacle_r0": hit_obstacle,
+                        "moving_object_hit_robot_or_obstacle_r0": hit_robot + hit_obstacle, "moving_object_missed_robot_r0": missed})
+            safe = total.clamp(min=1)
+            nan = t.full_like(total, float("nan"))                               # the reference omits the fractions of an episode without a final state
+            for k, x in (("hit_robot", hit_robot), ("hit_obstacle", hit_obstacle), ("hit_robot_or_obstacle", hit_robot + hit_obstacle),
+                         ("missed_robot", missed)):
+                out["moving_object_%s_fraction" % k] = t.where(total > 0, x / safe, nan)
+        return out
 
 
 class RllibVectorEnv:

@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-SCENE_VERSION = 6
+SCENE_VERSION = 7
 NJ = 7
 NLINK = 8
 MAX_BODIES = 10
@@ -98,6 +98,9 @@ class Scene(C.Structure):
         ("low_vel_max_reward", C.c_double), ("low_vel_threshold", C.c_double),
         ("termination_bonus", C.c_double), ("early_termination_punishment", C.c_double),
         ("collision_distance", C.c_double),
+        ("check_braking_trajectory_collisions", C.c_int32), ("brake_checks_per_step", C.c_int32), ("brake_timeout_steps", C.c_int32),
+        ("_pad4", C.c_int32), ("brake_safety_distance", C.c_double), ("brake_acc_max", _D7), ("brake_jerk_max", _D7),
+        ("brake_stop_velocity", C.c_double), ("brake_stop_acceleration", C.c_double),
         ("start_box", (C.c_double * 2) * 3), ("start_min_dist_static", C.c_double),
         ("start_min_dist_self", C.c_double),
         ("kinematic_state_sampling_mode", C.c_int32), ("_pad2", C.c_int32),
@@ -144,6 +147,12 @@ BALL_ENV_CONFIG = dict(
     moving_object_speed_meter_per_second=6.0, moving_object_check_invalid_target_link_point_positions=True,
     moving_object_random_initial_position=True, use_moving_objects=True,
 )
+
+#: ... and with the braking-trajectory safety layer of the README's reaching-task commands (README.md:95
+#: --check_braking_trajectory_collisions --closest_point_safety_distance=0.01 --collision_check_time=0.033)
+def reach_brake_env_config():
+    return dict(REACH_ENV_CONFIG, experiment_name="reaching_task_space_braking", check_braking_trajectory_collisions=True)
+
 
 #: the target-point reaching task in the space scene: trained_networks/task_networks/reaching_task/space/state_action/
 #: params.json without its risk network (risk_config_dir) - SafeMotionsEnv with
@@ -193,10 +202,11 @@ _DEFAULTS = dict(
     target_point_radius=0.05, target_point_sequence=0, target_point_reached_reward_bonus=0.0,
     target_point_use_actual_position=False, obs_add_target_point_pos=False, obs_add_target_point_relative_pos=False,
     normalize_reward_to_initial_target_point_distance=False, target_point_reward_factor=1.0,
+    check_braking_trajectory_collisions=False, acc_limit_factor_braking=1.0, jerk_limit_factor_braking=1.0,
 )
 
 # features of the reference outside the hot-path scope ("out of scope"/"next")
-_UNSUPPORTED_TRUE = ("use_real_robot", "check_braking_trajectory_collisions", "punish_adaptation", "punish_end_min_distance",
+_UNSUPPORTED_TRUE = ("use_real_robot", "punish_adaptation", "punish_end_min_distance",
                      "punish_end_max_torque", "punish_braking_trajectory_min_distance", "punish_braking_trajectory_max_torque",
                      "target_point_use_actual_position",
                      "check_braking_trajectory_torque_limits", "use_gui", "render_video",
@@ -239,6 +249,14 @@ def validate_env_config(config):
         raise NotImplementedError("moving_object_sequence != 0")
     if config.get("planet_mode") and config.get("use_moving_objects"):
         raise NotImplementedError("planet_mode together with use_moving_objects")
+    if config.get("check_braking_trajectory_collisions") and config.get("collision_avoidance_mode"):
+        # with the braking method the collision-avoidance start-state sampling re-draws velocities / accelerations at the SAME start
+        # position until its braking trajectory is collision free (ctlp.py:1499-1545); positions are accepted from 1 mm off the
+        # table (ctlp.py:1468-1472) while braking needs closest_point_safety_distance, so that loop need not end.  The reference
+        # only documents the braking method with the reaching task (README.md:95: collision_avoidance_mode off, start at rest)
+        raise NotImplementedError("check_braking_trajectory_collisions together with collision_avoidance_mode: the reference's "
+                                  "start-state sampling (ctlp.py:1499-1545) does not terminate for start positions closer to the "
+                                  "table than closest_point_safety_distance; use it with the target-point task (SafeMotionsEnv)")
     if config.get("max_resampling_attempts", 0):
         # base.py:1663 unpacks 4 values from a 2-tuple: the reference itself raises here
         raise ValueError("max_resampling_attempts > 0 is broken in the reference (base.py:1663)")
@@ -681,6 +699,20 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     s.termination_bonus = float(_cfg(config, "collision_avoidance_episode_termination_bonus"))
     s.early_termination_punishment = float(_cfg(config, "collision_avoidance_episode_early_termination_punishment"))
     s.collision_distance = 0.001                                                         # rewards.py:115,119,153
+
+    # ---- braking-trajectory safety layer (btg.py, ctlp.py:3026-3207) ----
+    s.check_braking_trajectory_collisions = int(bool(_cfg(config, "check_braking_trajectory_collisions")))
+    cct = _cfg(config, "collision_check_time")
+    s.brake_checks_per_step = int(round(max(1, dt / (0.05 if cct is None else cct))))      # ctlp.py:99-103
+    s.brake_timeout_steps = int(np.floor(2.0 / dt + 1e-9)) + 1                             # braking_timeout=2.0, ctlp.py:3468-3473
+    s.brake_safety_distance = float(_cfg(config, "closest_point_safety_distance"))
+    for j in range(NJ):                                                                    # actions.py:76-82
+        ab = float(_cfg(config, "acc_limit_factor_braking")) * acc[j]
+        s.brake_acc_max[j] = ab
+        s.brake_jerk_max[j] = min(2 * float(_cfg(config, "jerk_limit_factor_braking")) * ab / dt, jerk[j])
+    s.brake_stop_velocity, s.brake_stop_acceleration = 0.01, 0.01                          # btg.py:45,75-77
+    if s.check_braking_trajectory_collisions and s.static_max_distance < s.brake_safety_distance:
+        raise ValueError("closest_point_safety_distance beyond the distance the closest-point queries report")
 
     # ---- reset ----
     box = {0: [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]], 1: [[-1.1, 1.1], [-1.1, 1.1], [-0.1, 1.5]],

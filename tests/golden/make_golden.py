@@ -2,7 +2,9 @@
 
 The reference itself cannot produce vectors (pybullet/klimits are not installable), so
 these fixtures pin the oracle against accidental change and give the GPU tests a data-only target that
-needs no oracle build on the box.  Run from the repo root:  python tests/golden/make_golden.py [--bm | --reach] [--checks N]
+needs no oracle build on the box.  Run from the repo root:  python tests/golden/make_golden.py [--bm | --reach | --brake] [--checks N]
+(--brake: the reaching task with the braking-trajectory safety layer -> reach_brake_step.npz; its start states are pushed towards the
+table so that braking trajectories are executed inside the fixture)
 (--checks N: N contact samples per step instead of the default 24 = the reference's cadence -> space_step_n<N>.npz)
 """
 import os
@@ -14,15 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from oracle.oracle import OracleEnv                                   # noqa: E402
-from safemotionsrisk_amd.scene import REACH_ENV_CONFIG, SPACE_ENV_CONFIG, build_scene   # noqa: E402
+from safemotionsrisk_amd.scene import REACH_ENV_CONFIG, SPACE_ENV_CONFIG, build_scene, reach_brake_env_config   # noqa: E402
 
 
-def main(ball_machine=False, reach=False, checks=None):
+def main(ball_machine=False, reach=False, checks=None, brake=False):
     """ball_machine: the same scene on robot_ball_machine.urdf (-> space_bm_step.npz; info column 1 = self distance);
     reach: the target-point reaching task (-> reach_step.npz; extra state: target [B][5], target_count)"""
     B, T = 512, 6
-    scene = build_scene(REACH_ENV_CONFIG if reach else dict(SPACE_ENV_CONFIG, ball_machine_mode=ball_machine), auto_reset=False,
-                        collision_checks_per_step=checks)
+    scene = build_scene(reach_brake_env_config() if brake else REACH_ENV_CONFIG if reach else dict(SPACE_ENV_CONFIG, ball_machine_mode=ball_machine),
+                        auto_reset=False, collision_checks_per_step=checks)
     env = OracleEnv(scene, B, seed=11, num_threads=4)
     env.reset()
     st0 = env.get_state()
@@ -36,6 +38,10 @@ def main(ball_machine=False, reach=False, checks=None):
         st0["target"][::4, :3] = (near + off).astype(np.float32)
         st0["target"][::4, 3] = st0["target"][::4, 4] = np.linalg.norm(st0["target"][::4, :3] - near, axis=1)
         st0["target"] = st0["target"].astype(np.float32).astype(np.float64)
+    if brake:                               # every third env: elbow bent down towards the table, moving on down
+        st0["q"][::3, 1] = rng.uniform(1.2, 1.9, len(st0["q"][::3])) * rng.choice([-1, 1], len(st0["q"][::3]))
+        st0["q"][::3, 3] = rng.uniform(-1.0, 1.0, len(st0["q"][::3]))
+        st0["v"][::3, 1] = np.sign(st0["q"][::3, 1]) * rng.uniform(0.2, 1.2, len(st0["q"][::3]))
     env.set_state(**st0)
     out = dict(B=B, T=T, seed=11, checks=int(scene.struct.collision_checks_per_step), q0=st0["q"].astype(np.float32), v0=st0["v"].astype(np.float32),
                a0=st0["a"].astype(np.float32), planet_idx0=st0["planet_idx"], step_count0=st0["step_count"],
@@ -73,12 +79,12 @@ def main(ball_machine=False, reach=False, checks=None):
     out.update(comp_p=p, comp_v=v, comp_a=a, comp_lo=np.array([r[0] for r in rr]), comp_hi=np.array([r[1] for r in rr]),
                comp_code=np.array([r[2] for r in rr]))
     dst = os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                       "reach_step.npz" if reach else "space_bm_step.npz" if ball_machine else
+                       "reach_brake_step.npz" if brake else "reach_step.npz" if reach else "space_bm_step.npz" if ball_machine else
                        "space_step.npz" if checks is None else "space_step_n%d.npz" % checks)
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes; done fraction", np.mean(out["done"]), "reasons", np.unique(out["reason"]))
 
 
 if __name__ == "__main__":
-    main(ball_machine="--bm" in sys.argv, reach="--reach" in sys.argv,
+    main(ball_machine="--bm" in sys.argv, reach="--reach" in sys.argv or "--brake" in sys.argv, brake="--brake" in sys.argv,
          checks=int(sys.argv[sys.argv.index("--checks") + 1]) if "--checks" in sys.argv else None)

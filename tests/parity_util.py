@@ -55,3 +55,31 @@ def explain_mismatches(ora, scene, st0, st1, bad, tie=TIE):
             d = ora.ball_distances(qn, st0["ball"][e].astype(np.float64), 0) if s.use_ball else ora.distances(qn, np.zeros(2, np.int32))
             out[n] = bool((np.abs(np.asarray(d[:2]) - float(s.collision_distance)) < tie).any())
     return out
+
+
+def braking_decision_is_tie(ora, scene, q, v, a, action, tie=TIE):
+    """The braking-trajectory check of one env (ctlp.py:3155-3207) replayed with the oracle's component functions: True when one of
+    its decisions sits on a threshold - a static / self distance of a sample within `tie` of the safety distance, or a joint
+    within 1e-6 of the stop band that ends the braking trajectory (btg.py:45) - so that float32 may decide the other way."""
+    s = scene.struct
+    dt, Nb, safety = float(s.dt), int(s.brake_checks_per_step), float(s.brake_safety_distance)
+    q, v, a = (np.asarray(x, dtype=np.float64) for x in (q, v, a))
+    lo, hi, _ = ora.safe_acc_range(q, v, a)
+    an = lo + 0.5 * (np.asarray(action, dtype=np.float64) + 1.0) * (hi - lo)
+    p, vv, ap = q.copy(), v.copy(), a.copy()
+    for m in range(int(s.brake_timeout_steps) + 1):
+        for k in range(1, Nb + 1):
+            d = ora.distances(cubic(p, vv, ap, an, dt if k == Nb else dt * k / Nb, dt), np.zeros(2, np.int32))
+            if (np.abs(np.asarray(d[:2]) - safety) < tie).any():
+                return True
+            if min(d[0], d[1]) < safety:
+                return False                                # a clear collision ends the check
+        p1 = cubic(p, vv, ap, an, dt, dt)
+        v1 = vv + 0.5 * (ap + an) * dt
+        if (np.abs(np.abs(v1) - float(s.brake_stop_velocity)) < 1e-6).any() or (np.abs(np.abs(an) - float(s.brake_stop_acceleration)) < 1e-6).any():
+            return True
+        b, stopped = ora.braking_acceleration(p1, v1, an)
+        if stopped:
+            return False
+        p, vv, ap, an = p1, v1, an, b
+    return False

@@ -28,7 +28,7 @@ def test_self_launch_fails_without_devices():
 def test_every_baseline_config_has_a_bench_mode():
     sys.path.insert(0, ROOT)
     import bench
-    assert {"space", "space4096", "ball", "space_n3", "space_bm", "ball_bm", "reach"} <= set(bench.CONFIGS)
+    assert {"space", "space4096", "ball", "space_n3", "space_bm", "ball_bm", "reach", "reach_brake"} <= set(bench.CONFIGS)
     for name in bench.CONFIGS:
         cfg, kw, algo, what = bench._env_config(name)
         from safemotionsrisk_amd.scene import build_scene

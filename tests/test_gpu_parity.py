@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from parity_util import TIE, explain_mismatches
+from parity_util import TIE, braking_decision_is_tie, explain_mismatches
 
 pytestmark = pytest.mark.gpu
 
@@ -59,14 +59,16 @@ def test_components_against_golden(built):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["space_step.npz", "space_step_n3.npz", "space_step_n1.npz", "space_bm_step.npz", "reach_step.npz"])
+@pytest.mark.parametrize("name", ["space_step.npz", "space_step_n3.npz", "space_step_n1.npz", "space_bm_step.npz", "reach_step.npz",
+                                  "reach_brake_step.npz"])
 def test_step_against_golden(built, name):
-    """space_step.npz: 24 contact samples per step (the reference's cadence = the default); _n3 / _n1: the opt-in variants"""
+    """space_step.npz: 24 contact samples per step (the reference's cadence = the default); _n3 / _n1: the opt-in variants;
+    reach_brake: the reaching task with the braking-trajectory safety layer (executed in ~12 % of the fixture's env-steps)"""
     import torch
     g = np.load(os.path.join(os.path.dirname(GOLD), name))
     B, T = int(g["B"]), int(g["T"])
-    reach = "reach" in name
-    env = (_reach_env if reach else _bm_env if "bm" in name else _env)(B, seed=int(g["seed"]), collision_checks_per_step=int(g["checks"]))
+    reach, brake = "reach" in name, "brake" in name
+    env = (_brake_env if brake else _reach_env if reach else _bm_env if "bm" in name else _env)(B, seed=int(g["seed"]), collision_checks_per_step=int(g["checks"]))
     assert int(env.scene.struct.collision_checks_per_step) == int(g["checks"]) == (int(name.split("_n")[1].split(".")[0]) if "_n" in name else 24)
     env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], planet_idx=g["planet_idx0"], step_count=g["step_count0"],
                   moving_hit=g["moving_hit0"], **(dict(target=g["target0"], target_count=g["target_count0"]) if reach else {}))
@@ -85,6 +87,13 @@ def test_step_against_golden(built, name):
             why = explain_mismatches(ora, env.scene, st0, st, bad)
             assert why.all(), "%d unexplained done / reason mismatches at step %d" % (int((~why).sum()), t)
             excluded += int(bad.sum())
+        if brake:                                   # the braking decision itself: exact, threshold ties aside (they change the whole step)
+            diff = vals[:, 8] != g["info"][t][:, 8]
+            for e in np.nonzero(diff)[0]:
+                assert braking_decision_is_tie(ora, env.scene, st0["q"][e], st0["v"][e], st0["a"][e], g["actions"][t][e]), (t, e)
+            excluded += int(diff.sum())
+            bad = bad | diff
+            assert g["info"][t][:, 8].sum() > 20
         ok = ~bad
         tol = np.broadcast_to(REACH_OBS_TOL if reach else OBS_TOL, obs.shape)
         if reach:                                   # a freshly drawn target comes from float32 FK of a random pose
@@ -99,8 +108,8 @@ def test_step_against_golden(built, name):
         assert np.abs(vals[ok & ~near, :3] - gi[ok & ~near, :3]).max() < 5e-6
         gs = g["state"][t]
         A = np.array(env.scene.struct.acc_max)
-        assert np.abs(st["q"] - gs[:, :7]).max() < 2e-6 and np.abs(st["v"] - gs[:, 7:14]).max() < 2e-5
-        assert np.abs((st["a"] - gs[:, 14:]) / A).max() < 2e-5
+        assert np.abs(st["q"] - gs[:, :7])[ok].max() < 2e-6 and np.abs(st["v"] - gs[:, 7:14])[ok].max() < 2e-5
+        assert np.abs((st["a"] - gs[:, 14:]) / A)[ok].max() < 2e-5
         # golden protocol: continue from the float32 image of the ORACLE state
         env.set_state(q=gs[:, :7].astype(np.float32), v=gs[:, 7:14].astype(np.float32), a=gs[:, 14:].astype(np.float32),
                       step_count=np.where(g["done"][t], 0, st["step_count"]), moving_hit=np.where(g["done"][t], 0, st["moving_hit"]),
@@ -459,6 +468,15 @@ def test_ball_machine_rollout_and_reset_against_oracle(built):
 
 # ---- target-point reaching task (A14): SafeMotionsEnv with TargetPointReachingReward, shipped task config minus its risk network ----
 
+def _brake_env(B, **kw):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from safemotionsrisk_amd import VecSafeMotionsEnv
+    from safemotionsrisk_amd.scene import reach_brake_env_config
+    kw.setdefault("auto_reset", False)
+    return VecSafeMotionsEnv(B, device=0, **kw, **reach_brake_env_config())
+
+
 REACH_OBS_TOL = np.concatenate([np.full(7, 2e-6), np.full(7, 1e-5), np.full(7, 2e-5), np.full(6, 2e-6), np.full(2, 1e-6)])
 
 
@@ -812,3 +830,67 @@ def test_limits_hold_under_adversarial_actions_on_the_gpu(built):
         assert (worst <= 1.001).all(), worst
         assert worst[0] > 0.999 and worst[2] > 0.999                         # the limits were actually reached
         env.close()
+
+
+@pytest.mark.gpu
+def test_braking_layer_rollout_against_oracle(built):
+    """the reaching task with check_braking_trajectory_collisions (README.md:95): 2048 envs x 16 steps with state injection; a third of the
+    envs are pushed towards the table so that braking trajectories are executed.  The braking decision (info column 8) and
+    done / reason are exact, threshold ties aside; where the decisions agree, observations and rewards agree to rounding; and with the
+    layer on no episode of the auto-reset run that follows ends by a collision with the table or the robot itself."""
+    import torch
+    from oracle.oracle import OracleEnv
+    B, T = 2048, 16
+    env = _brake_env(B, seed=5)
+    env.reset()
+    ora = OracleEnv(env.scene, B, seed=5, num_threads=16)
+    ora1 = OracleEnv(env.scene, 1)
+    rng = np.random.default_rng(9)
+    st = env.get_state()
+    st["q"][::3, 1] = rng.uniform(1.2, 1.9, len(st["q"][::3])) * rng.choice([-1, 1], len(st["q"][::3]))
+    st["q"][::3, 3] = rng.uniform(-1.0, 1.0, len(st["q"][::3]))
+    st["v"][::3, 1] = np.sign(st["q"][::3, 1]) * rng.uniform(0.2, 1.2, len(st["q"][::3]))
+    env.set_state(q=st["q"], v=st["v"])
+    mism = braked = ties = 0
+    for t in range(T):
+        st = env.get_state()
+        ora.set_state(**{k: st[k] for k in env.STATE_KEYS})
+        act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        o_obs, o_rew, o_done, o_reason, o_info = ora.step(act.astype(np.float64))
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        reason, vals = info["termination_reason"].cpu().numpy(), info["values"].cpu().numpy()
+        st1, ost1 = env.get_state(), ora.get_state()
+        diff = vals[:, 8] != o_info[:, 8]
+        for e in np.nonzero(diff)[0]:
+            if braking_decision_is_tie(ora1, env.scene, st["q"][e], st["v"][e], st["a"][e], act[e]):
+                ties += 1
+            else:
+                mism += 1
+        bad = (done != o_done) | (reason != o_reason) | (st1["target_count"] != ost1["target_count"])
+        if (bad & ~diff).any():
+            mism += int((~explain_mismatches(ora1, env.scene, st, st1, bad & ~diff)).sum())
+        good = ~bad & ~diff
+        braked += int(o_info[:, 8].sum())
+        A = np.array(env.scene.struct.acc_max)
+        assert np.abs((st1["a"][good] - ost1["a"][good]) / A).max() < 2e-5              # the executed (braking) accelerations
+        new = good & (st1["target_count"] != st["target_count"])
+        assert (np.abs(obs[good & ~new] - o_obs[good & ~new]) < REACH_OBS_TOL).all()
+        assert np.abs(rew[good] - o_rew[good]).max() < 2e-4
+        if done.any():
+            env.reset(mask=torch.from_numpy(done).cuda())
+    assert mism == 0, "%d unexplained mismatches" % mism
+    assert braked > 500 and ties <= 10
+    env.close()
+    env = _brake_env(B, seed=6, auto_reset=True)
+    env.reset()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    reasons, n_braked = [], 0
+    for t in range(100):
+        obs, rew, done, info = env.step(torch.rand((B, 7), device="cuda", generator=gen) * 2 - 1)
+        d = done.cpu().numpy().astype(bool)
+        reasons += info["termination_reason"].cpu().numpy()[d].tolist()
+        n_braked += int(info["values"][:, 8].sum().item())
+    env.synchronize()
+    assert not set(reasons) & {3, 4} and 5 in reasons and n_braked > 1000
+    env.close()

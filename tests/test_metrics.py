@@ -12,7 +12,10 @@ COLS = VecSafeMotionsEnv.INFO_COLUMNS
 def _random_rollout(B, T, rng, p_done=0.15):
     obs = rng.uniform(-1, 1, (T, B, 23)).astype(np.float32)
     rew = rng.uniform(0, 5, (T, B)).astype(np.float32)
-    vals = rng.uniform(0, 1, (T, B, 8)).astype(np.float32)
+    vals = rng.uniform(0, 1, (T, B, len(COLS))).astype(np.float32)
+    vals[..., 8] = rng.random((T, B)) < 0.2                           # braking trajectory executed
+    vals[..., 9] = rng.random((T, B)) < 0.1                           # target point reached
+    vals[..., 10] = rng.choice([0, 0, 0, 1, 2, 3], (T, B))            # final state of a retired ball
     vals[..., 0][rng.random((T, B)) < 0.1] = 0.0                      # static collisions
     done = rng.random((T, B)) < p_done
     reason = np.where(done, rng.choice([1, 2, 4, 5], (T, B)), -1).astype(np.int8)
@@ -36,8 +39,11 @@ def test_episode_metrics_match_a_per_env_python_fold(auto_reset):
     names = step_scalar_names(COLS)
     assert len(names) == len(set(names)) and "joint_3_vel_abs" in names and "collision_rate_static_obstacles" in names
     hist = [[] for _ in range(B)]
+    ev_hist = [[] for _ in range(B)]
     checked = 0
     for t in range(T):
+        for e in range(B):
+            ev_hist[e].append(vals[t, e, 8:11].copy())
         info = {"values": torch.from_numpy(vals[t]), "termination_reason": torch.from_numpy(reason[t])}
         fin = m.update(torch.from_numpy(obs[t]), torch.from_numpy(rew[t]), torch.from_numpy(done[t]), info)
         x = m.step_scalars(torch.from_numpy(obs[t]), torch.from_numpy(rew[t]), info["values"]).numpy()
@@ -57,7 +63,18 @@ def test_episode_metrics_match_a_per_env_python_fold(auto_reset):
             assert fin.episode_length[i].item() == len(rows) and fin.metrics["trajectory_length"][i].item() == 21
             assert fin.metrics["success_rate"][i].item() == (0.0 if reason[t, e] == 1 else 1.0)
             assert fin.metrics["collision_static_obstacles_termination_rate"][i].item() == float(reason[t, e] == 4)
+            # episode-end statistics of the obstacle wrapper (ctlp.py:1141-1309) from the event columns of the episode's steps
+            ev = np.array(ev_hist[e])
+            assert fin.metrics["obstacles_time_influenced_by_braking_trajectory_collision"][i].item() == pytest.approx(ev[:, 0].mean(), abs=1e-6)
+            assert fin.metrics["obstacles_episodes_without_influence_by_braking_trajectory"][i].item() == float(ev[:, 0].sum() == 0)
+            assert fin.metrics["obstacles_num_target_points_reached"][i].item() == ev[:, 1].sum()
+            assert fin.metrics["moving_object_hit_robot_total"][i].item() == (ev[:, 2] == 1).sum()
+            assert fin.metrics["moving_object_missed_robot_total"][i].item() == (ev[:, 2] == 3).sum()
+            n_final = (ev[:, 2] > 0).sum()
+            frac = fin.metrics["moving_object_hit_obstacle_fraction"][i].item()
+            assert (np.isnan(frac) and n_final == 0) or frac == pytest.approx((ev[:, 2] == 2).sum() / max(n_final, 1), abs=1e-6)
             hist[e] = []
+            ev_hist[e] = []
             checked += 1
         if len(fin):
             assert set(fin.mean()) == set(fin.metrics)

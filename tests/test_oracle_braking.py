@@ -1,0 +1,111 @@
+"""Braking-trajectory safety layer of the oracle: btg.py:44-93, ctlp.py:3026-3207,3468-3506.
+klimits' braking mode is absent from /root/reference (PARITY UNPINNED): these tests pin the restated law by its properties."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from safemotionsrisk_amd.scene import REACH_ENV_CONFIG, SPACE_ENV_CONFIG, build_scene, reach_brake_env_config
+
+
+@pytest.fixture(scope="module")
+def brake_scene(built):
+    return build_scene(reach_brake_env_config(), auto_reset=False)
+
+
+def test_config(brake_scene):
+    s = brake_scene.struct
+    assert s.check_braking_trajectory_collisions == 1 and s.brake_checks_per_step == 3       # round(max(1, 0.1 / 0.033)), ctlp.py:99-103
+    assert s.brake_timeout_steps == 21 and s.brake_safety_distance == pytest.approx(0.01)     # braking_timeout 2.0 s, ctlp.py:3468-3473
+    assert list(s.brake_acc_max) == list(s.acc_max) and list(s.brake_jerk_max) == list(s.jerk_max)   # braking factors 1.0, actions.py:76-82
+    half = build_scene(dict(reach_brake_env_config(), acc_limit_factor_braking=0.5, collision_check_time=None)).struct
+    assert half.brake_checks_per_step == 2 and np.allclose(list(half.brake_acc_max), 0.5 * np.array(list(s.acc_max)))
+    assert np.allclose(list(half.brake_jerk_max), np.minimum(2 * 0.5 * np.array(list(s.acc_max)) / 0.1, list(s.jerk_max)))
+    with pytest.raises(NotImplementedError):            # the reference's start-state sampling does not terminate there (ctlp.py:1499-1545)
+        build_scene(dict(SPACE_ENV_CONFIG, check_braking_trajectory_collisions=True))
+    assert build_scene(REACH_ENV_CONFIG).struct.check_braking_trajectory_collisions == 0
+
+
+@pytest.mark.parametrize("jerk_factor", [1.0, 0.3])
+def test_braking_law_stops_every_joint_without_reversing(built, jerk_factor):
+    """from any state inside the limits the braking accelerations bring every joint to a standstill: the velocity never changes
+    sign (beyond the 1e-5 design tolerance), acceleration and jerk limits hold, the joint then stays at rest; no oscillation."""
+    scene = build_scene(dict(reach_brake_env_config(), jerk_limit_factor_braking=jerk_factor), auto_reset=False)
+    s = scene.struct
+    env = O.OracleEnv(scene, 1)
+    rng = np.random.default_rng(0)
+    V, A, Jb = (np.array(list(x)) for x in (s.vel_max, s.brake_acc_max, s.brake_jerk_max))
+    dt, longest = 0.1, 0
+    q = np.zeros(7)                                     # mid range: the position limits stay out of reach of the clipping
+    for trial in range(300):
+        while True:                                     # a state the safe range itself calls feasible
+            v = rng.uniform(-1, 1, 7) * V * rng.choice([0.05, 0.5, 1.0])
+            a = rng.uniform(-1, 1, 7) * A
+            if (env.safe_acc_range(q, v, a)[2] == 0).all():
+                break
+        sign0 = np.sign(v)
+        p = q.copy()
+        for m in range(60):
+            b, stopped = env.braking_acceleration(p, v, a)
+            if stopped:
+                break
+            # inside the braking box, or where the clip into the safe range (btg.py:80-93) moved it, inside the full one
+            assert (np.abs(b) <= np.array(list(s.acc_max)) + 1e-9).all() and (np.abs(b - a) <= np.array(list(s.jerk_max)) * dt + 1e-9).all()
+            p = p + v * dt + 0.5 * a * dt * dt + (b - a) / dt * dt ** 3 / 6
+            v_new = v + 0.5 * (a + b) * dt
+            # once a joint's acceleration opposes its velocity it never crosses zero: reversal only where the start state forces it
+            forced = (np.sign(a) == -sign0) & (np.abs(v) + 0.5 * a * sign0 * dt < 0)
+            ok = (v_new * np.sign(v) >= -2e-5 * V) | forced | (np.abs(v_new) < 0.01)      # or inside the stop band, where btg.py:75-77 sets the acceleration to zero
+            # (with a braking jerk below the trajectory's a large acceleration cannot always be taken back before the velocity reverses)
+            assert ok.all() or jerk_factor < 1.0, (trial, m, v, a, b)
+            v, a = v_new, b
+        else:
+            raise AssertionError("did not stop: %s %s" % (v, a))
+        longest = max(longest, m)
+        b, stopped = env.braking_acceleration(p, v, a)
+        assert stopped and (b == 0).all() and (np.abs(v) < 0.01).all() and (np.abs(a) < 0.01).all()
+    assert longest <= (12 if jerk_factor == 1.0 else 30)
+
+
+def test_unsafe_actions_are_detected_and_replaced(brake_scene):
+    s = brake_scene.struct
+    env = O.OracleEnv(brake_scene, 4)
+    up = np.zeros(7)
+    zero = np.zeros(7)
+    lo, hi, _ = env.safe_acc_range(up, zero, zero)
+    for u in (-1.0, 0.3, 1.0):                          # arm straight up, at rest: every action can brake in time
+        assert not env.braking_trajectory_unsafe(up, zero, zero, lo + 0.5 * (u + 1) * (hi - lo))
+    # elbow over the table, moving down fast: continuing is unsafe, and so is the full state step
+    down = np.array([0.0, 1.45, 0.0, -0.4, 0.0, 0.0, 0.0])
+    d0 = env.distances(down, [0, 0])
+    assert 0.01 < d0[0] < 0.1
+    v = np.array([0.0, 1.2, 0.0, 0.0, 0.0, 0.0, 0.0])
+    lo, hi, _ = env.safe_acc_range(down, v, zero)
+    assert env.braking_trajectory_unsafe(down, v, zero, hi)
+    env.set_state(q=down, v=v, a=0, step_count=0, moving_hit=1, planet_idx=[0, 720],
+                  target=[0.3, 0.3, 0.6, 0.5, 0.5], target_count=1)
+    obs, rew, done, reason, info = env.step(np.ones((4, 7)))
+    st = env.get_state()
+    b, stopped = env.braking_acceleration(down, v, zero)
+    assert info[0, 8] == 1.0 and np.allclose(st["a"][0], b) and not stopped and b[1] < -5.0     # the braking acceleration was executed
+    assert brake_scene.struct.brake_checks_per_step == 3
+
+
+def test_braking_layer_prevents_table_and_self_collisions(built):
+    """rollouts of random actions: with the braking layer no episode ends by a collision with the table or the robot itself
+    (reasons 3 / 4); without it such episodes occur.  The layer is blind to the planets (ctlp.py:3294-3372: static obstacles
+    and self-collision pairs only), so reason 5 stays."""
+    reasons = {}
+    for name, cfg in (("brake", reach_brake_env_config()), ("plain", REACH_ENV_CONFIG)):
+        env = O.OracleEnv(build_scene(cfg, auto_reset=False), 384, seed=3, num_threads=8)
+        env.reset()
+        rng = np.random.default_rng(1)
+        rs, braked = [], 0
+        for t in range(80):
+            o, r, d, reason, info = env.step(rng.uniform(-1, 1, (384, 7)))
+            rs += reason[d.astype(bool)].tolist(); braked += int(info[:, 8].sum())
+            if d.any():
+                env.reset(mask=d)
+        reasons[name] = rs
+        assert (braked > 300) == (name == "brake")
+    assert not set(reasons["brake"]) & {3, 4} and 5 in reasons["brake"]
+    assert set(reasons["plain"]) & {3, 4}

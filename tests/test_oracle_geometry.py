@@ -212,3 +212,50 @@ def test_self_pairs_against_qp(built, bm_scene):
             Bv = np.concatenate([np.c_[ring, np.full(90, z)] for z in (-pc.cyl_half_length, pc.cyl_half_length)]) + np.array(list(pc.center))
             tol = 1.2e-4                                # the polygon is inside the disc by r (1 - cos(pi/90)) = 1e-4
         assert ora.self_pair_distance(q, i) == pytest.approx(qp_distance(A, Bv) - 0.002, abs=tol)
+
+
+def test_planets_never_touch_the_table_each_other_or_the_base_adapter(bm_scene):
+    """Planet._collision_detected comes from getContactPoints(bodyA=planet) without a bodyB (ctlp.py:4572): contact with the table, the
+    other planet or the robot's base adapter would latch a hit too.  The kernels and the oracle test robot bodies only
+    (contact_link_mask).  For the README orbits that is exact: over all 1200 orbit indices (planet two follows planet one with its
+    index shift) every planet piece stays far beyond the 0.02 m contact distance of the table, the adapter and the other planet."""
+    s = bm_scene.struct
+    V = bm_scene.verts
+    I3, Z3 = np.eye(3), np.zeros(3)
+
+    def piece(i):
+        p = s.pieces[i]
+        return V[p.vert_begin:p.vert_begin + p.vert_count], p.margin
+
+    def pose(p, i):
+        row = np.ctypeslib.as_array(s.planet[p].orbit_pose, shape=(s.planet[p].n_orbit, 7))[i]
+        x, y, z, w = row[3:]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        return R, row[:3].copy()
+
+    table, table_m = piece(s.static_piece[0])
+    adapter_i = -(s.self_pair[0][1] + 1)
+    assert s.self_pair[0][1] < 0 and s.pieces[adapter_i].kind == 1          # the base adapter's cylinder (its bounding box here: conservative)
+    adapter, adapter_m = piece(adapter_i)
+    assert s.n_planets == 2 and s.planet[1].coupled == 1 and s.planet[0].n_orbit == s.planet[1].n_orbit == 1200
+    worst = dict(table=np.inf, adapter=np.inf, planets=np.inf)
+    for i in range(0, 1200, 2):                                              # every other index: the planets move < 8 mm per index
+        j = (i + s.planet[1].index_shift) % 1200
+        frames = [pose(0, i), pose(1, j)]
+        pieces = [[piece(s.planet[p].piece_begin + c) for c in range(s.planet[p].piece_count)] for p in range(2)]
+        for p in range(2):
+            R, t = frames[p]
+            for v, m in pieces[p]:
+                lo = (v @ R.T + t)[:, 2].min()
+                worst["table"] = min(worst["table"], lo - m - 0.0)           # table top at z = 0: cheap exact bound for a hull above it
+                if np.linalg.norm(t - adapter.mean(axis=0)) < 0.9:
+                    worst["adapter"] = min(worst["adapter"], O.gjk(v, R, t, adapter, I3, Z3) - m - adapter_m)
+        (R0, t0), (R1, t1) = frames
+        if np.linalg.norm(t0 - t1) < 1.2:
+            for v0, m0 in pieces[0]:
+                for v1, m1 in pieces[1]:
+                    worst["planets"] = min(worst["planets"], O.gjk(v0, R0, t0, v1, R1, t1, 0.5) - m0 - m1)
+    assert table[:, 2].max() + table_m <= 1e-9                               # the table's top face is z = 0
+    assert worst["table"] > 0.15 and worst["adapter"] > 0.15 and worst["planets"] > 0.10, worst
