@@ -139,6 +139,9 @@ struct DState {
     float *res;                // [n_bodies][B] collide -> finish: contact of body l at any of the N contact samples of the step
     float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
     int *braked;               // [B] 1: the braking acceleration replaced this step's action (adapt_action, ctlp.py:3055-3153)
+    float *brake_acc;          // [brake_timeout_steps + 1][7][B] end acceleration of braking segment m >= 1 behind the planned step
+                               // ([0]: the braking acceleration at the current state, what adapt_action puts in place of the action)
+    int *brake_steps;          // [B] braking segments until the robot stands (-1: not within the braking timeout)
     float *lb_moving;          // [n_bodies][B] lower bound of the body's distance to every moving piece at the end of the last step
                                // (< 0: none - new episode, injected state); the next step's lanes rule out their first samples with it
     int *done_list;            // [B]
@@ -511,13 +514,22 @@ __device__ inline float braking_acceleration_joint(const DScene &S, int j, float
     return sgn * fmaxf(blo, fminf(a1, bhi));
 }
 
-// Can a position limit shape the safe range of (p, v, a)?  No if the joint cannot get there even at full speed-up for one step and
-// the gentlest stop the range computation considers afterwards (then the range is the velocity range inside the jerk /
-// acceleration box, which contains the braking acceleration); a factor of two on top.
-__device__ __forceinline__ bool position_limit_in_reach(const JointLim &L, float p, float v) {
+// Does the clip of braking acceleration b into the safe range of (p, v, a) (btg.py:80-93) change it?  No when b lies inside the
+// velocity-admissible interval and both position margins hold for it (the two tests the range itself is made of); the position
+// margins are only evaluated where a limit is within a generous stopping distance.
+__device__ inline bool braking_clip_needed(const JointLim &L, float p, float v, float a, float b) {
+    const float D = L.J * L.dt, eps = 1e-6f * L.A;
+    float blo = fmaxf(-L.A, a - D), bhi = fminf(L.A, a + D);
+    if (blo > bhi) blo = bhi = fminf(fmaxf(a, -L.A), L.A);
+    const float vtol = 1e-5f * L.V, ptol = 1e-6f * (L.phi - L.plo);
+    const float vhi = fminf(bhi, fmaxf(blo, vel_upper_a1max(v, a, L.V, vtol, L))), vlo = fmaxf(blo, fminf(bhi, -vel_upper_a1max(-v, -a, L.V, vtol, L)));
+    if (b < vlo - eps || b > vhi + eps) return true;
     const float vm = fabsf(v) + L.A * L.dt;
     const float reach = 2.0f * (vm * (2.0f * L.dt + L.A * L.iJ) + 0.5f * vm * vm / L.A);
-    return (L.phi - p) < reach || (p - L.plo) < reach;
+    const float gap_hi = (L.phi - p) + L.phi_res, gap_lo = (p - L.plo) - L.plo_res;
+    if (gap_hi < reach && pos_margin(gap_hi + ptol, v, a, b, vtol, L) < 0.f) return true;
+    if (gap_lo < reach && pos_margin(gap_lo + ptol, -v, -a, -b, vtol, L) < 0.f) return true;
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     int code;
     safe_acc_range_joint<64>(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code, live);
     if (!live) return;
+    if (j == 0 && S.check_braking) st.braked[e] = 0;   // set by brake_check_kernel
     float u = actions[(size_t)e * SMR_NJ + j];
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
 }
@@ -533,78 +534,148 @@ __device__ inline bool group_ball_contact(const DScene &S, const Group &G, const
 }
 
 // ---- braking-trajectory safety layer: btg.py:44-93, ctlp.py:3026-3207,3468-3506 ----
-// get_minimum_distance with check_safety_distance (ctlp.py:3282-3374) for joint vector q: no static obstacle and no self-collision
-// partner closer than the safety distance; lane g of the group tests bodies g, g + 8 and self pairs g, g + 8
-template <bool EXTRA>
-__device__ inline bool group_brake_clear(const DScene &S, const Group &G, const float q[SMR_NJ]) {
-    bool ok = true;
-    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear<EXTRA>(S, b, q, body_frame(S, q, b), S.brake_safety);
-    if (EXTRA) ok = ok && lane_self_pairs_clear(S, G, q, S.brake_safety);
-    return G.all(ok);
-}
-
-// _compute_braking_acceleration (ctlp.py:3494-3506) for the joint of lane g (lanes 0..6): braking acceleration, clipped into the safe
-// range of the state where a position limit can shape that range.  All 8 lanes of the group call together.
-__device__ inline float group_braking_acceleration(const DScene &S, const Group &G, const JointLim &L, int jj, float p, float v, float a, bool joint_lane) {
-    float b = joint_lane ? braking_acceleration_joint(S, jj, v, a) : 0.f;
-    const bool want = joint_lane && position_limit_in_reach(L, p, v);
-    if (G.any(want)) {
+// _compute_braking_acceleration (ctlp.py:3494-3506) for the joint of this lane: braking acceleration, clipped into the safe range where
+// that changes it; the lanes of the wavefront share the root finding of the clipped joints (all must call together)
+__device__ inline float braking_acceleration_lane(const DScene &S, const JointLim &L, int j, float p, float v, float a, bool active) {
+    float b = braking_acceleration_joint(S, j, v, a);
+    const bool want = active && braking_clip_needed(L, p, v, a, b);
+    if (__any(want)) {
         float lo, hi;
         int code;
-        safe_acc_range_joint<8>(L, p, v, a, lo, hi, code, want);
-        if (want) b = fminf(fmaxf(b, lo), hi);                                          // btg.py:80-93
+        safe_acc_range_joint<64>(L, p, v, a, lo, hi, code, want);
+        if (want) b = fminf(fmaxf(b, lo), hi);                                            // btg.py:80-93
     }
     return b;
 }
 
-// check_braking_trajectory_method (ctlp.py:3026-3053, _check_if_braking_trajectory_is_collision_free :3155-3207): lane g < 7 holds joint g
-// of the state (q, v, a) and of the target acceleration a1.  True: the step with a1 followed by braking to a standstill is NOT collision
-// free (or does not stop within the braking timeout).
-template <bool EXTRA>
-__device__ inline bool group_braking_unsafe(const DScene &S, const Group &G, const JointLim &L, int jj, float qj, float vj, float aj, float a1j) {
-    const bool joint_lane = G.g < SMR_NJ;
-    float p = qj, v = vj, ap = aj, an = a1j;
-    const int Nb = S.brake_checks;
-    for (int m = 0;; ++m) {
-        for (int sidx = 1; sidx <= Nb; ++sidx) {                                        // linspace(dt / Nb, dt, Nb), ctlp.py:3167-3169
-            const float t = sidx == Nb ? S.dt : S.dt * (float)sidx / (float)Nb;
-            float qs[SMR_NJ];
-            G.gather(interp_pos(p, v, ap, an, t, S.dt), qs);
-            if (!group_brake_clear<EXTRA>(S, G, qs)) return true;
-        }
-        if (m >= S.brake_timeout_steps) return true;                                    // braking_timeout, ctlp.py:3468-3473
+// The braking trajectory behind the planned step, once per env (ctlp.py:3155-3207 without the distance checks): the braking
+// accelerations of its segments until the robot stands, or the braking timeout.  [0]: the braking acceleration at the current state.
+// A group of 8 lanes per env, lane g < 7 = joint g.
+__global__ __launch_bounds__(256) void brake_plan_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    const int B = S.B;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e0 = t >> 3, g = t & 7;
+    const bool valid = e0 < B;
+    const int e = valid ? e0 : B - 1;
+    const Group G{g, (int)(threadIdx.x & 63) & ~7};
+    const bool joint_lane = g < SMR_NJ;
+    const int j = joint_lane ? g : 0;
+    const JointLim L = joint_lim(S, j);
+    float p = st.q[j * B + e], v = st.v[j * B + e], ap = st.a[j * B + e], an = st.a1[j * B + e];
+    bool stopped = G.all(!joint_lane || (fabsf(v) < S.brake_stop_v && fabsf(ap) < S.brake_stop_a));
+    float b = braking_acceleration_lane(S, L, j, p, v, ap, valid && joint_lane && !stopped);
+    if (valid && joint_lane) st.brake_acc[(size_t)j * B + e] = stopped ? 0.f : b;
+    bool active = valid;
+    int steps = -1;
+    for (int m = 0; m < S.brake_timeout_steps && __any(active); ++m) {                   // the state after segment m, the braking acceleration behind it
         const float p1 = interp_pos(p, v, ap, an, S.dt, S.dt), v1 = interp_vel(v, ap, an, S.dt, S.dt);
-        const bool stopped = !joint_lane || (fabsf(v1) < S.brake_stop_v && fabsf(an) < S.brake_stop_a);
-        if (G.all(stopped)) return false;                                               // robot stopped, nothing hit (btg.py:45-47)
-        const float b = group_braking_acceleration(S, G, L, jj, p1, v1, an, joint_lane);
-        p = p1; v = v1; ap = an; an = b;
+        p = p1; v = v1; ap = an;
+        stopped = G.all(!joint_lane || (fabsf(v) < S.brake_stop_v && fabsf(ap) < S.brake_stop_a));
+        if (active && stopped) { steps = m; active = false; }                             // robot stopped (btg.py:45-47)
+        b = braking_acceleration_lane(S, L, j, p, v, ap, active && joint_lane);
+        an = b;
+        if (active && joint_lane) st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e] = b;
+    }
+    if (valid && g == 7) st.brake_steps[e] = steps;
+}
+
+// check_braking_trajectory_method (ctlp.py:3026-3053, _check_if_braking_trajectory_is_collision_free :3155-3207) on the grid of the
+// collide kernel: one lane per (env, body) and per (env, self-collision pair), the body's hull staged in LDS.  The lane walks the
+// planned step and the braking segments behind it and tests ITS body / pair at the samples: closer than the safety distance
+// (get_minimum_distance with check_safety_distance, ctlp.py:3282-3374) -> braked[env] = 1.  A sample is only evaluated when the joints
+// have moved far enough since the last evaluation to use up the clearance found there (every value piece_distance returns is a
+// lower bound of the distance; joint travel x lever arms bounds the motion of the body's points).
+template <bool SELF>
+__global__ __launch_bounds__(256) void brake_check_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    constexpr int kBlock = 256;
+    const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
+    const bool pair_block = SELF && (int)blockIdx.y < n_pair_blocks;
+    const int pair = pair_block ? (int)blockIdx.y : 0;
+    const int body = pair_block ? S.self_pair[pair][0] : S.body_order[(int)blockIdx.y - n_pair_blocks];
+    const int partner = pair_block ? S.self_pair[pair][1] : -1;
+    const int l = pair_block ? (partner >= 0 ? partner : body) : body;                    // the body whose hull is staged (see collide_kernel)
+    if (!pair_block && !((S.static_mask >> body) & 1u)) return;                            // nothing of this body is observed by a static obstacle
+    __shared__ float lds_v[4 * kMaxPieceVerts];
+    __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
+    __shared__ uint32_t lds_start[kStartCells / 4];
+    const int pl = S.link_piece[l];
+    const DPiece LP = load_piece(S.pieces, pl);
+    {
+        const SMR_GLOBAL float4 *gv = (const SMR_GLOBAL float4 *)S.verts + LP.begin;
+        const SMR_GLOBAL uint32_t *gi = (const SMR_GLOBAL uint32_t *)S.ids4 + LP.ids_begin,
+                                  *gm = (const SMR_GLOBAL uint32_t *)S.start + (kStartCells / 4) * (size_t)pl;
+        for (int i = threadIdx.x; i < LP.count; i += kBlock) {
+            const SMR_GLOBAL float *f = (const SMR_GLOBAL float *)(gv + i);
+            lds_v[4 * i] = f[0]; lds_v[4 * i + 1] = f[1]; lds_v[4 * i + 2] = f[2]; lds_v[4 * i + 3] = f[3];
+        }
+        for (int i = threadIdx.x; i < LP.ids_count; i += kBlock) lds_ids[i] = gi[i];
+        for (int i = threadIdx.x; i < kStartCells / 4; i += kBlock) lds_start[i] = gm[i];
+    }
+    __syncthreads();
+    const LocalHull hull{lds_v, lds_ids, (const uint8_t *)lds_start};
+    const int B = S.B;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    const int steps = st.brake_steps[e];
+    if (steps < 0) { st.braked[e] = 1; return; }         // no standstill within the braking timeout counts as a collision, ctlp.py:3201-3203
+    float p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ], q_ref[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) { p[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; ap[j] = st.a[j * B + e]; an[j] = st.a1[j * B + e]; q_ref[j] = p[j]; }
+    // levers of the joints on the points of what this lane tests.  A pair of bodies on the chain: the joints below the partner link
+    // carry both along, only the joints from the partner link on move the body relative to it.
+    float lever[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) lever[j] = (partner >= 0 && j < partner) ? 0.f : S.sweep_R[body][j];
+    const float thr = S.brake_safety;
+    float margin = -1.f;                                 // clearance beyond the safety distance found at q_ref (< 0: nothing evaluated yet)
+    for (int m = 0; m <= steps; ++m) {
+        for (int sidx = 1; sidx <= S.brake_checks; ++sidx) {                              // linspace(dt / Nb, dt, Nb), ctlp.py:3167-3169
+            const float t = sidx == S.brake_checks ? S.dt : S.dt * (float)sidx / (float)S.brake_checks;
+            float qs[SMR_NJ], moved = 0.f;
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) { qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt); moved += fabsf(qs[j] - q_ref[j]) * lever[j]; }
+            if (moved * 1.0001f + 1e-6f < margin) continue;
+            float d;
+            if (pair_block) {
+                const int link_a = body < SMR_NLINK ? body : SMR_NLINK - 1;
+                Xf Ta = fk_base(S), Tp = Ta;
+#pragma unroll
+                for (int j = 0; j < SMR_NJ; ++j) {
+                    if (j == partner) Tp = Ta;
+                    if (j < link_a) fk_advance(S, j, qs[j], Ta);
+                }
+                if (partner >= link_a) Tp = body_frame(S, qs, partner);
+                if (body >= SMR_NLINK) Ta = mounted_frame(S, body, Ta);
+                if (partner >= 0) d = piece_distance<false>(S, S.link_piece[body], Ta, LP, hull, Tp, S.static_max, thr);
+                else d = self_pair_distance(S, pair, qs, LP, hull, Ta, S.static_max, thr);
+            } else {
+                const Xf T = body_frame(S, qs, body);
+                d = 3.0e38f;
+                for (int sp = 0; sp < S.n_static; ++sp) d = fminf(d, piece_distance<true>(S, S.static_piece[sp], T, LP, hull, T, S.static_max, thr));
+            }
+            if (d < thr) { st.braked[e] = 1; return; }                                    // ctlp.py:3307-3312,3364-3368; several lanes of an env may write the same 1
+            margin = d - thr - 1e-5f;
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = qs[j];
+        }
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) {
+            const float p1 = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt), v1 = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
+            p[j] = p1; v[j] = v1; ap[j] = an[j];
+            if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
+        }
     }
 }
 
-// adapt_action (ctlp.py:3055-3153, actions.py:340-361): one group of 8 lanes per env; the end acceleration the plan kernel derived from
-// the action is replaced by the braking acceleration when its braking trajectory is not collision free
-template <bool EXTRA>
-__global__ __launch_bounds__(64) void brake_kernel(const DScene *__restrict__ Sp, DState st) {
+// adapt_action (ctlp.py:3055-3153, actions.py:340-361): where the braking trajectory of the planned end acceleration is not collision free
+// the braking acceleration replaces it (the stored valid braking trajectory of the reference continues from exactly this state)
+__global__ __launch_bounds__(256) void brake_apply_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int e = t >> 3, g = t & 7;
-    if (e >= S.B) return;
-    const int B = S.B;
-    const Group G{g, (int)(threadIdx.x & 63) & ~7};
-    const int jj = g < SMR_NJ ? g : 0;
-    const JointLim L = joint_lim(S, jj);
-    const float qj = st.q[jj * B + e], vj = st.v[jj * B + e], aj = st.a[jj * B + e], a1j = st.a1[jj * B + e];
-    const bool unsafe = group_braking_unsafe<EXTRA>(S, G, L, jj, qj, vj, aj, a1j);
-    if (G.any(unsafe)) {                                 // group uniform; the stored valid braking trajectory continues from exactly this state
-        float all_v[SMR_NJ], all_a[SMR_NJ];
-        G.gather(vj, all_v); G.gather(aj, all_a);
-        bool stopped = true;
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) stopped = stopped && fabsf(all_v[j]) < S.brake_stop_v && fabsf(all_a[j]) < S.brake_stop_a;
-        const float b = group_braking_acceleration(S, G, L, jj, qj, vj, aj, g < SMR_NJ);
-        if (g < SMR_NJ) st.a1[g * B + e] = stopped ? 0.f : b;
-    }
-    if (g == 7) st.braked[e] = unsafe ? 1 : 0;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (e >= S.B || !st.braked[e]) return;
+    st.a1[(size_t)j * S.B + e] = st.brake_acc[(size_t)j * S.B + e];
 }
 
 // end-effector point in float64 (the ball is aimed at it; its launch arithmetic runs in float64 so that the
@@ -1439,7 +1510,8 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) ||
+        (rc = dev_alloc(env, &st.brake_acc, scene->check_braking_trajectory_collisions ? (size_t)(scene->brake_timeout_steps + 1) * SMR_NJ * B : 1)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)) || (rc = dev_alloc(env, &env->spawn_tag_lists, 3 * B)))
         return fail(rc);
@@ -1773,9 +1845,11 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipGetLastError());
     if (env->hscene.check_braking) {                    // adapt_action: the braking acceleration replaces actions whose braking trajectory collides
         LaunchTimer t(env, SMR_K_BRAKE);
-        const dim3 grid(((size_t)B * 8 + 63) / 64);
-        if (scene_extra(env)) hipLaunchKernelGGL((brake_kernel<true>), grid, dim3(64), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL((brake_kernel<false>), grid, dim3(64), 0, env->stream, env->dscene, env->st);
+        hipLaunchKernelGGL(brake_plan_kernel, dim3(((size_t)B * 8 + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st);
+        const dim3 grid((B + 255) / 256, env->hscene.n_bodies + env->hscene.n_self_pairs);
+        if (env->hscene.n_self_pairs > 0) hipLaunchKernelGGL((brake_check_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((brake_check_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+        hipLaunchKernelGGL(brake_apply_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st);
         SMR_HIP(hipGetLastError());
     }
     {
