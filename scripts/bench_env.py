@@ -1,8 +1,15 @@
-"""One scene under several values of an environment switch of the library (GPU box): python scripts/bench_env.py VAR v1,v2,.. [config] [extra VAR=val ...]"""
-import os, subprocess, sys
-var = sys.argv[1]; vals = sys.argv[2].split(","); cfg = sys.argv[3] if len(sys.argv) > 3 else "space"
-extra = dict(a.split("=") for a in sys.argv[4:])
-code = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_ab.py")).read().split("code = r'''")[1].split("'''")[0]
+"""One bench configuration under several values of an environment switch of the library (GPU box):
+    python scripts/bench_env.py VAR v1,v2,.. [config] [extra bench.py arguments]
+e.g. python scripts/bench_env.py SMR_SYNC_RESET 0,1 space --envs-per-gpu 262144"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+var, vals = sys.argv[1], sys.argv[2].split(",")
+cfg = sys.argv[3] if len(sys.argv) > 3 else "space"
 for val in vals:
-    env = dict(os.environ, **extra, **{var: val})
-    print(var + "=" + val, subprocess.run([sys.executable, "-c", code, cfg], env=env, capture_output=True, text=True).stdout.strip(), flush=True)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "100", "--warmup", "20", "--no-cpu-baseline"] + sys.argv[4:],
+                       env=dict(os.environ, **{var: val}), capture_output=True, text=True)
+    try:
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+        print("%s=%s  %.2f M env-steps/s" % (var, val, d["value"] / 1e6), {k: round(v, 4) for k, v in d["kernel_ms"].items()}, flush=True)
+    except Exception:
+        print("%s=%s failed: %s" % (var, val, p.stderr[-300:]), flush=True)
