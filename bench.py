@@ -39,6 +39,9 @@ CONFIGS = {
     "space_bm": ("SPACE", dict(ball_machine_mode=True), {}, 342, "space scene on robot_ball_machine.urdf = trained_networks/backup_networks/space/params.json"),
     "ball_bm": ("BALL", dict(ball_machine_mode=True), {}, 422, "ball scene on robot_ball_machine.urdf = trained_networks/backup_networks/ball/params.json"),
     "reach": ("REACH", {}, {}, 390, "target-point reaching task (SafeMotionsEnv, TargetPointReachingReward), ball machine mounted, 8 s episodes"),
+    "reach_risk": ("REACH", {}, dict(risk_networks=True), 390,
+                   "reaching task with risk-aware stepping (actions.py:303-340): risk network 30-256-128-1 and backup policy 23-256-128-14 "
+                   "on the MFMA units, synthetic weights"),
     "reach_brake": ("REACH", dict(check_braking_trajectory_collisions=True), {}, 390,
                     "reaching task with the braking-trajectory safety layer (README.md:95: --check_braking_trajectory_collisions "
                     "--closest_point_safety_distance=0.01 --collision_check_time=0.033)"),
@@ -62,6 +65,7 @@ def cpu_baseline(config_name, seconds_target=8.0):
     cfg, kw, _, _ = _env_config(config_name)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))
+    kw = {k: v for k, v in kw.items() if k != "risk_networks"}
     scene = build_scene(cfg, auto_reset=True, **kw)
 
     def run(B, threads, budget, max_steps):
@@ -193,7 +197,17 @@ def main():
     B = args.envs_per_gpu or (4096 if args.config == "space4096" else 65536)
     if args.checks is not None:
         kw = dict(kw, collision_checks_per_step=args.checks)
+    risk_nets = kw.pop("risk_networks", False)
     env = VecSafeMotionsEnv(B, device=local_rank, seed=0, auto_reset=True, return_info=not args.no_info, env_index_offset=rank, **kw, **cfg)
+    if risk_nets:                                       # synthetic weights of the shipped architectures (the checkpoints are not loaded)
+        import numpy as np
+        from safemotionsrisk_amd import backup_policy, risk_network
+        wrng = np.random.default_rng(0)
+        mk = lambda sizes: ([(wrng.normal(size=(a, b)) * 2 / np.sqrt(a)).astype(np.float32) for a, b in zip(sizes[:-1], sizes[1:])],
+                            [np.zeros(b, np.float32) for b in sizes[1:]])
+        r = env.risk_observation_size
+        nets = (risk_network(*mk([r + 7, 256, 128, 1]), device=local_rank), backup_policy(*mk([r, 256, 128, 14]), device=local_rank))
+        env.set_risk_networks(*nets, risk_threshold=0.5)
     rollout = ShardedRollout(env) if (distributed and not args.no_gather) else None
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)

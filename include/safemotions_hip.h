@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 5
+#define SMR_ABI_VERSION 6
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
@@ -57,7 +57,9 @@ extern "C" {
 #define SMR_INFO_TARGET_REACHED 9     /* 1: the target point was reached in this step, ctlp.py:2787-2821 */
 #define SMR_INFO_BALL_EVENT 10        /* final state of a ball retired in this step: 1 hit_robot, 2 hit_obstacle, 3 missed_robot
                                          (ctlp.py:2839-2861); 0 none */
-#define SMR_INFO_N 11
+#define SMR_INFO_RISKY 11             /* 1: the risk network rated the action risky and the backup policy's action was executed
+                                         (risky_action_rate, actions.py:303-340); 0 without risk networks */
+#define SMR_INFO_N 12
 
 /* kernels timed by smr_get_profile */
 #define SMR_K_PLAN 0      /* A2/A4: safe acceleration range + action mapping            */
@@ -66,7 +68,8 @@ extern "C" {
 #define SMR_K_RESET 3     /* A17/A9: start-state and planet-phase sampling               */
 #define SMR_K_SPAWN 4     /* A10: a new ball for the envs whose ball was retired         */
 #define SMR_K_BRAKE 5     /* braking-trajectory safety layer (adapt_action, ctlp.py:3055-3153) */
-#define SMR_K_COUNT 6
+#define SMR_K_RISK 6      /* risk network + backup policy (actions.py:303-340, base.py:1498-1502,1598-1603) */
+#define SMR_K_COUNT 7
 
 typedef struct smr_env smr_env_t;   /* opaque */
 
@@ -127,6 +130,36 @@ int smr_synchronize(smr_env_t *env);
  * SMR_K_* kernel since the last call and clears them). */
 int smr_set_profiling(smr_env_t *env, int32_t enable);
 int smr_get_profile(smr_env_t *env, double ms_out[SMR_K_COUNT], int64_t launches_out[SMR_K_COUNT]);
+
+/* ---- fully connected networks on the GPU (the backup policy model/keras_fcnet_last_layer_activation.py and the
+ * risk network train_risk_network.py:273-282).  Weights come as plain host arrays - a Keras Dense kernel [in][out] row major and
+ * its bias per layer; nothing is deserialised here (the reference's checkpoints are pickle files / SavedModels: a maintainer
+ * exports the arrays once). ---- */
+#define SMR_ACT_LINEAR 0
+#define SMR_ACT_TANH 1
+#define SMR_ACT_SWISH 2
+#define SMR_ACT_RELU 3
+#define SMR_ACT_SIGMOID 4
+#define SMR_ACT_SELU 5
+#define SMR_MLP_MAX_LAYERS 4
+#define SMR_MLP_MAX_WIDTH 256
+
+typedef struct smr_mlp smr_mlp_t;   /* opaque */
+
+/* sizes [n_layers + 1]: input width, the layers' output widths (each <= SMR_MLP_MAX_WIDTH); activations [n_layers] = SMR_ACT_*.
+ * On failure returns a negative SMR_E_* code and leaves the message in smr_last_error(NULL). */
+int smr_mlp_create(int32_t n_layers, const int32_t *sizes, const float *const *weights_host, const float *const *biases_host,
+                   const int32_t *activations, int32_t device, smr_mlp_t **out);
+int smr_mlp_destroy(smr_mlp_t *mlp);
+/* y_dev [n_rows][ldy] <- network(x_dev [n_rows][ldx]); device pointers, enqueued on `stream` (hipStream_t or NULL) */
+int smr_mlp_forward(smr_mlp_t *mlp, const float *x_dev, int32_t ldx, float *y_dev, int32_t ldy, int32_t n_rows, void *stream);
+
+/* Risk-aware stepping (actions.py:303-340 with a state-action risk network, base.py:1498-1502,1598-1603): before the action is
+ * planned, risk = risk_network([risk observation, action]); where risk >= threshold the deterministic action of the backup
+ * policy for the risk observation (the first 7 outputs) replaces it.  The risk observation is the observation without the
+ * target-point columns (obs.py:419-431).  risk: input obs_size - target columns + 7, one output; backup: input obs_size - target
+ * columns, >= 7 outputs.  Pass NULL networks to switch it off.  The handles must outlive the env's use of them. */
+int smr_set_risk_networks(smr_env_t *env, smr_mlp_t *risk, smr_mlp_t *backup, float risk_threshold);
 
 /* ---- component entry points (parity tests): each runs the same device functions the step kernels
  * use on n host-provided inputs and copies the results back; all synchronise ---- */

@@ -1050,7 +1050,7 @@ void reset_env(Oracle &O, int e) {
 
 /* info columns written by step (mirrors the product's SMR_INFO_* layout) */
 enum { INFO_D_STATIC = 0, INFO_D_SELF, INFO_D_MOVING, INFO_ACTION_PUNISHMENT, INFO_R_SELF, INFO_R_STATIC,
-       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_BRAKED, INFO_TARGET_REACHED, INFO_BALL_EVENT, INFO_N };
+       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_BRAKED, INFO_TARGET_REACHED, INFO_BALL_EVENT, INFO_RISKY, INFO_N };
 
 /* A1/A2/A3/A11/A12/A13/A16: SafeMotionsBase.step + process_step_outcome for one env. */
 void step_env(Oracle &O, int e, const double *action, float *obs, double *reward, uint8_t *done,
@@ -1217,7 +1217,7 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         info[INFO_D_STATIC] = d_static; info[INFO_D_SELF] = d_self; info[INFO_D_MOVING] = d_moving;
         info[INFO_ACTION_PUNISHMENT] = action_punishment; info[INFO_R_SELF] = r_self;
         info[INFO_R_STATIC] = r_static; info[INFO_R_MOVING] = r_moving; info[INFO_EPISODE_LENGTH] = st.step_count;
-        info[INFO_BRAKED] = braked ? 1.0 : 0.0; info[INFO_TARGET_REACHED] = tp_reached ? 1.0 : 0.0; info[INFO_BALL_EVENT] = ball_event;
+        info[INFO_BRAKED] = braked ? 1.0 : 0.0; info[INFO_TARGET_REACHED] = tp_reached ? 1.0 : 0.0; info[INFO_BALL_EVENT] = ball_event; info[INFO_RISKY] = 0.0;     /* the risk check sits above step() (tests/test_gpu_policy.py) */
     }
     if (d && S.auto_reset) reset_env(O, e);
     else {

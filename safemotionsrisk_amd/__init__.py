@@ -8,3 +8,4 @@ interface (metrics.py).
 from .scene import SPACE_ENV_CONFIG, BALL_ENV_CONFIG, REACH_ENV_CONFIG, build_scene  # noqa: F401
 from .env import VecSafeMotionsEnv, SafeMotionsEnvCollisionAvoidance, SafeMotionsEnv  # noqa: F401
 from .metrics import EpisodeMetrics, RllibVectorEnv  # noqa: F401
+from .policy import Mlp, backup_policy, risk_network  # noqa: F401

@@ -139,6 +139,7 @@ struct DState {
     float *res;                // [n_bodies][B] collide -> finish: contact of body l at any of the N contact samples of the step
     float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
     int *braked;               // [B] 1: the braking acceleration replaced this step's action (adapt_action, ctlp.py:3055-3153)
+    int *risky;                // [B] 1: the risk network rated this step's action risky, the backup policy's action was executed
     float *brake_acc;          // [brake_timeout_steps + 1][7][B] end acceleration of braking segment m >= 1 behind the planned step
                                // ([0]: the braking acceleration at the current state, what adapt_action puts in place of the action)
     int *brake_steps;          // [B] braking segments until the robot stands (-1: not within the braking timeout)

@@ -21,6 +21,7 @@
 
 #include "smr_device.h"
 #include "smr_tables.h"
+#include "smr_mlp.h"
 
 namespace smr {
 
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         row[SMR_INFO_ACTION_PUNISHMENT] = action_pun; row[SMR_INFO_R_SELF] = r_self; row[SMR_INFO_R_STATIC] = r_static;
         row[SMR_INFO_R_MOVING] = r_moving; row[SMR_INFO_EPISODE_LENGTH] = (float)steps;
         row[SMR_INFO_BRAKED] = S.check_braking ? (float)st.braked[e] : 0.f; row[SMR_INFO_TARGET_REACHED] = tp_reached ? 1.f : 0.f;
-        row[SMR_INFO_BALL_EVENT] = (float)ball_event;
+        row[SMR_INFO_BALL_EVENT] = (float)ball_event; row[SMR_INFO_RISKY] = st.risky ? (float)st.risky[e] : 0.f;
     }
 
 #pragma unroll
@@ -1239,6 +1240,45 @@ __global__ void test_ball_distances_kernel(const DScene *__restrict__ Sp, const 
     out[4 * i] = dst; out[4 * i + 1] = dsf; out[4 * i + 2] = dmv; out[4 * i + 3] = contact ? 1.f : 0.f;
 }
 
+// ---- risk-aware stepping: actions.py:303-340, base.py:1498-1502,1598-1603 ----
+// row e of x: the risk observation of env e (obs.py:419-431: the observation without its target-point columns) followed by the
+// action the caller asks for
+__global__ void risk_input_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions, float *__restrict__ x, int ldx) {
+    const DScene &S = *Sp;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.B) return;
+    const int B = S.B;
+    float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) { q[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; a[j] = st.a[j * B + e]; }
+    float *row = x + (size_t)e * ldx;
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) {
+        row[j] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (q[j] - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
+        row[SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, v[j] / S.vel_max[j]));
+        row[2 * SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, a[j] / S.acc_max[j]));
+    }
+    int o = 3 * SMR_NJ;
+    if (S.use_ball) { write_ball_observation(S, load_ball(st, B, e), st.ball_i[e], row + o); o += 6; }     // moving object, then planets: obs.py:424-427
+    const int idx[SMR_MAX_PLANETS] = {st.planet_idx[e], st.planet_idx[B + e]};
+    write_planet_observation(S, idx, row + o);
+    o += S.obs_num_planets * S.obs_planet_size;
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) row[o + j] = actions[(size_t)e * SMR_NJ + j];
+}
+
+__global__ void risk_apply_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions, const float *__restrict__ risk,
+                                  const float *__restrict__ backup, int ldb, float threshold, float *__restrict__ actions_out) {
+    const DScene &S = *Sp;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S.B) return;
+    const bool risky = risk[e] >= threshold;                                                // base.py:1602-1603
+    st.risky[e] = risky ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j)
+        actions_out[(size_t)e * SMR_NJ + j] = risky ? fminf(1.f, fmaxf(-1.f, backup[(size_t)e * ldb + j])) : actions[(size_t)e * SMR_NJ + j];
+}
+
 }  // namespace smr
 
 // ---------------------------------------------------------------------------------------------
@@ -1270,6 +1310,10 @@ struct smr_env {
     int *spawn_lists = nullptr, *spawn_counts = nullptr;   // two spawn lists: the side stream re-stages from one while finish fills the other
     bool stage_balls = false;
     int parity = 0;
+    struct smr_mlp *risk_net = nullptr, *backup_net = nullptr;     // risk-aware stepping (smr_set_risk_networks)
+    float risk_threshold = 0.05f;
+    float *risk_x = nullptr, *risk_y = nullptr, *backup_y = nullptr, *actions_eff = nullptr;
+    int *risky_buf = nullptr;
     bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
     DState st;
@@ -1286,6 +1330,12 @@ struct smr_env {
 };
 
 static thread_local std::string g_create_error;
+
+struct smr_mlp {
+    int device = 0;
+    DMlp d;
+    std::vector<void *> allocs;
+};
 
 #define SMR_HIP(call)                                                                                   \
     do {                                                                                                \
@@ -1838,9 +1888,22 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
     }
     if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
+    const float *planned_actions = actions_dev;         // what the plan kernel maps into the safe range
+    if (env->risk_net) {                                // actions.py:303-340: the backup policy's action where the risk network objects
+        LaunchTimer t(env, SMR_K_RISK);
+        const int robs = env->obs_size - env->hscene.obs_target_size, ldx = robs + SMR_NJ, ldb = env->backup_net->d.out_size;
+        hipLaunchKernelGGL(risk_input_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, env->risk_x, ldx);
+        const dim3 mgrid((B + kMlpRows - 1) / kMlpRows);
+        hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->risk_net->d, (const float *)env->risk_x, ldx, env->risk_y, 1, B);
+        hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->backup_net->d, (const float *)env->risk_x, ldx, env->backup_y, ldb, B);
+        hipLaunchKernelGGL(risk_apply_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, (const float *)env->risk_y,
+                           (const float *)env->backup_y, ldb, env->risk_threshold, env->actions_eff);
+        SMR_HIP(hipGetLastError());
+        planned_actions = env->actions_eff;
+    }
     {
         LaunchTimer t(env, SMR_K_PLAN);
-        hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
+        hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, planned_actions);
     }
     SMR_HIP(hipGetLastError());
     if (env->hscene.check_braking) {                    // adapt_action: the braking acceleration replaces actions whose braking trajectory collides
@@ -1991,6 +2054,83 @@ int smr_get_profile(smr_env_t *env, double ms_out[SMR_K_COUNT], int64_t launches
         env->prof_ms[k] = 0; env->prof_n[k] = 0;
     }
     return staged_check(env);
+}
+
+int smr_mlp_create(int32_t n_layers, const int32_t *sizes, const float *const *weights_host, const float *const *biases_host,
+                   const int32_t *activations, int32_t device, smr_mlp_t **out) {
+    if (!out) { g_create_error = "out is NULL"; return SMR_E_INVALID; }
+    *out = nullptr;
+    if (n_layers < 1 || n_layers > SMR_MLP_MAX_LAYERS || !sizes || !weights_host || !biases_host || !activations) { g_create_error = "smr_mlp_create: bad arguments"; return SMR_E_INVALID; }
+    for (int l = 0; l <= n_layers; ++l)
+        if (sizes[l] < 1 || sizes[l] > SMR_MLP_MAX_WIDTH) { g_create_error = "smr_mlp_create: layer width out of range (1 .. 256)"; return SMR_E_INVALID; }
+    for (int l = 0; l < n_layers; ++l)
+        if (!weights_host[l] || !biases_host[l] || activations[l] < 0 || activations[l] > SMR_ACT_SELU) { g_create_error = "smr_mlp_create: bad layer"; return SMR_E_INVALID; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { g_create_error = "smr_mlp_create: no such HIP device (the library has no CPU path)"; return SMR_E_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { g_create_error = "hipSetDevice failed"; return SMR_E_HIP; }
+    smr_mlp *m = new smr_mlp();
+    m->device = device;
+    std::memset(&m->d, 0, sizeof m->d);
+    m->d.n_layers = n_layers; m->d.in_size = sizes[0]; m->d.out_size = sizes[n_layers];
+    auto fail = [&](const char *msg) { g_create_error = msg; smr_mlp_destroy(m); return SMR_E_HIP; };
+    for (int l = 0; l < n_layers; ++l) {
+        // zero padded: K to a multiple of 4 (the k depth of one MFMA), N to a multiple of 64 (four 16-column tiles per pass), the
+        // last layer's N to a multiple of 16; a hidden layer's padded N is the next layer's K
+        const int K = l == 0 ? (sizes[0] + 3) / 4 * 4 : m->d.N[l - 1];
+        const int N = l == n_layers - 1 ? (sizes[l + 1] + 15) / 16 * 16 : (sizes[l + 1] + 63) / 64 * 64;
+        m->d.K[l] = K; m->d.N[l] = N; m->d.act[l] = activations[l];
+        std::vector<float> W((size_t)K * N, 0.f), b((size_t)N, 0.f);
+        for (int k = 0; k < sizes[l]; ++k)
+            for (int n = 0; n < sizes[l + 1]; ++n) W[(size_t)k * N + n] = weights_host[l][(size_t)k * sizes[l + 1] + n];
+        for (int n = 0; n < sizes[l + 1]; ++n) b[n] = biases_host[l][n];
+        void *dW = nullptr, *db = nullptr;
+        if (hipMalloc(&dW, W.size() * 4) != hipSuccess) return fail("hipMalloc failed");
+        m->allocs.push_back(dW);
+        if (hipMalloc(&db, b.size() * 4) != hipSuccess) return fail("hipMalloc failed");
+        m->allocs.push_back(db);
+        if (hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+            return fail("hipMemcpy failed");
+        m->d.W[l] = (const float *)dW; m->d.b[l] = (const float *)db;
+    }
+    *out = m;
+    return SMR_OK;
+}
+
+int smr_mlp_destroy(smr_mlp_t *mlp) {
+    if (!mlp) return SMR_OK;
+    (void)hipSetDevice(mlp->device);
+    (void)hipDeviceSynchronize();
+    for (void *p : mlp->allocs) (void)hipFree(p);
+    delete mlp;
+    return SMR_OK;
+}
+
+int smr_mlp_forward(smr_mlp_t *mlp, const float *x_dev, int32_t ldx, float *y_dev, int32_t ldy, int32_t n_rows, void *stream) {
+    if (!mlp || !x_dev || !y_dev || n_rows <= 0 || ldx < mlp->d.in_size || ldy < mlp->d.out_size) { g_create_error = "smr_mlp_forward: bad arguments"; return SMR_E_INVALID; }
+    if (hipSetDevice(mlp->device) != hipSuccess) return SMR_E_HIP;
+    hipLaunchKernelGGL(mlp_forward_kernel, dim3((n_rows + kMlpRows - 1) / kMlpRows), dim3(64), 0, (hipStream_t)stream, mlp->d, x_dev, ldx, y_dev, ldy, n_rows);
+    return hipGetLastError() == hipSuccess ? SMR_OK : SMR_E_HIP;
+}
+
+int smr_set_risk_networks(smr_env_t *env, smr_mlp_t *risk, smr_mlp_t *backup, float risk_threshold) {
+    if (!env) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    if (!risk && !backup) { env->risk_net = env->backup_net = nullptr; env->st.risky = nullptr; return SMR_OK; }
+    const int robs = env->obs_size - env->hscene.obs_target_size;                         // obs.py:419-431: no target-point columns
+    if (!risk || !backup) { env->err = "smr_set_risk_networks: both networks are needed"; return SMR_E_INVALID; }
+    if (risk->device != env->device || backup->device != env->device) { env->err = "smr_set_risk_networks: networks live on another device"; return SMR_E_INVALID; }
+    if (risk->d.in_size != robs + SMR_NJ || risk->d.out_size != 1) { env->err = "smr_set_risk_networks: the risk network must map (risk observation, action) to one value"; return SMR_E_INVALID; }
+    if (backup->d.in_size != robs || backup->d.out_size < SMR_NJ) { env->err = "smr_set_risk_networks: the backup policy must map the risk observation to >= 7 outputs"; return SMR_E_INVALID; }
+    const size_t B = (size_t)env->B;
+    int rc;
+    if (!env->risk_x && ((rc = dev_alloc(env, &env->risk_x, B * (robs + SMR_NJ))) || (rc = dev_alloc(env, &env->risk_y, B)) ||
+                         (rc = dev_alloc(env, &env->backup_y, B * SMR_MLP_MAX_WIDTH)) || (rc = dev_alloc(env, &env->actions_eff, B * SMR_NJ)) ||
+                         (rc = dev_alloc(env, &env->risky_buf, B)))) return rc;
+    SMR_HIP(hipMemset(env->risky_buf, 0, B * 4));
+    env->st.risky = env->risky_buf;
+    env->risk_net = risk; env->backup_net = backup; env->risk_threshold = risk_threshold;
+    return SMR_OK;
 }
 
 int smr_test_fk(smr_env_t *env, const float *q_host, int32_t n, float *pos_out, float *rot_out) {

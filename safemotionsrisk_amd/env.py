@@ -44,7 +44,7 @@ class VecSafeMotionsEnv:
     INFO_COLUMNS = ("minimum_distance_to_static_obstacles", "minimum_distance_self_collision",
                     "minimum_distance_to_moving_obstacles", "action_punishment", "self_collision_reward",
                     "static_obstacles_collision_reward", "moving_obstacles_collision_reward", "episode_length",
-                    "braking_trajectory_executed", "target_point_reached", "moving_object_final_state")
+                    "braking_trajectory_executed", "target_point_reached", "moving_object_final_state", "risky_action")
 
     def __init__(self, num_envs, device=0, seed=None, auto_reset=True, collision_checks_per_step=None,
                  contact_distance=None, return_info=True, env_index_offset=0, **env_config):
@@ -125,6 +125,22 @@ class VecSafeMotionsEnv:
             info["columns"] = self.INFO_COLUMNS
             info["values"] = self.info
         return self.obs, self.reward, self.done, info
+
+    def set_risk_networks(self, risk, backup, risk_threshold=0.05):
+        """Risk-aware stepping (actions.py:303-340 with a state-action risk network, risk_threshold default base.py:222-223): inside
+        step(), where risk([risk observation, action]) >= risk_threshold the backup policy's deterministic action replaces the
+        action.  risk / backup: policy.Mlp objects on this env's device (None, None switches it off); info column ``risky_action``
+        reports it per step."""
+        self._risk_nets = (risk, backup)                # keep them alive
+        rc = self._L.smr_set_risk_networks(self._h, None if risk is None else risk._h, None if backup is None else backup._h,
+                                           C.c_float(float(risk_threshold)))
+        _lib.check(self._L, self._h, rc, "smr_set_risk_networks")
+
+    @property
+    def risk_observation_size(self):
+        """obs.py:419-431: the observation without its target-point columns"""
+        s = self.scene.struct
+        return self.observation_size - (3 * (int(s.obs_target_pos) + int(s.obs_target_rel)) if s.use_target_points else 0)
 
     def observe(self):
         rc = self._L.smr_observe(self._h, C.c_void_p(self.obs.data_ptr()))

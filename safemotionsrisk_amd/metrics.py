@@ -37,7 +37,7 @@ TERMINATION_RATE_KEYS = {
 
 #: event columns of the info matrix: folded into the episode-end statistics of ObstacleWrapperSim.get_info_and_print_stats
 #: (ctlp.py:1141-1309) instead of the per-step average / max / min scalars
-EVENT_COLUMNS = ("braking_trajectory_executed", "target_point_reached", "moving_object_final_state")
+EVENT_COLUMNS = ("braking_trajectory_executed", "target_point_reached", "moving_object_final_state", "risky_action")
 
 
 def step_scalar_names(info_columns):
@@ -93,7 +93,7 @@ class EpisodeMetrics:
         self.count = torch.zeros((self.num_envs, K), **kw)
         # episode-end statistics of the obstacle wrapper (ctlp.py:1141-1309): steps, steps with the braking trajectory executed,
         # target points reached, balls by final state (hit_robot, hit_obstacle, missed_robot)
-        self.events = torch.zeros((self.num_envs, 6), **kw)
+        self.events = torch.zeros((self.num_envs, 8), **kw)      # ... steps with a risky action, first such step (0: none)
 
     def step_scalars(self, obs, reward, info_values):
         """[B, K] per-step scalars (the values of the reference's info['average'] entries of this step)."""
@@ -120,8 +120,9 @@ class EpisodeMetrics:
         self.max = t.where(valid, t.maximum(self.max, x), self.max)
         self.min = t.where(valid, t.minimum(self.min, x), self.min)
         v = info["values"]
-        braked, reached, ball = [v[:, c].float() if c is not None and c < v.shape[1] else t.zeros_like(reward, dtype=t.float32) for c in self._event_cols]
-        self.events += t.stack([t.ones_like(braked), braked, reached, (ball == 1).float(), (ball == 2).float(), (ball == 3).float()], dim=1)
+        braked, reached, ball, risky = [v[:, c].float() if c is not None and c < v.shape[1] else t.zeros_like(reward, dtype=t.float32) for c in self._event_cols]
+        first = t.where((risky > 0) & (self.events[:, 7] == 0), self.events[:, 0] + 1, t.zeros_like(risky))   # 1-based step of the first risky action
+        self.events += t.stack([t.ones_like(braked), braked, reached, (ball == 1).float(), (ball == 2).float(), (ball == 3).float(), risky, first], dim=1)
         idx = d.nonzero(as_tuple=True)[0]
         if idx.numel() == 0:
             e = idx.new_zeros((0,))
@@ -156,7 +157,7 @@ class EpisodeMetrics:
         influence (torque checks are physics: 0), target points reached, final states of the balls of the episode.  Not produced:
         the sampling-attempt counts (ctlp.py:1151,1171-1176) and obstacles_link_data_* (log_obstacle_data)."""
         t = self._t
-        steps, braked, reached, hit_robot, hit_obstacle, missed = ev.unbind(dim=1)
+        steps, braked, reached, hit_robot, hit_obstacle, missed, risky, first_risky = ev.unbind(dim=1)
         infl = braked / steps.clamp(min=1)
         zero = t.zeros_like(infl)
         out = {"obstacles_time_influenced_by_braking_trajectory": infl,
@@ -167,6 +168,9 @@ class EpisodeMetrics:
                "obstacles_episodes_without_influence_by_braking_trajectory_torque": t.ones_like(infl),
                "obstacles_episodes_with_braking_timeout": zero,                  # a timed-out braking trajectory counts as a collision here
                "obstacles_num_target_points_reached": reached}
+        if self._event_cols[3] is not None:                                       # actions.py:306-340, base.py:1378
+            out["risky_action_rate_average"] = risky / steps.clamp(min=1)
+            out["risk_network_first_risky_action_step"] = t.where(first_risky > 0, first_risky - 1, t.full_like(first_risky, float("nan")))
         if self._event_cols[2] is not None:
             total = hit_robot + hit_obstacle + missed
             out.update({"moving_object_hit_robot_total": hit_robot, "moving_object_hit_obstacle_total": hit_obstacle,

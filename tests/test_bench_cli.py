@@ -32,4 +32,5 @@ def test_every_baseline_config_has_a_bench_mode():
     for name in bench.CONFIGS:
         cfg, kw, algo, what = bench._env_config(name)
         from safemotionsrisk_amd.scene import build_scene
+        kw = {k: v for k, v in kw.items() if k != "risk_networks"}
         assert build_scene(cfg, **kw).struct.obs_size > 0 and algo > 0
