@@ -2074,10 +2074,10 @@ int smr_mlp_create(int32_t n_layers, const int32_t *sizes, const float *const *w
     m->d.n_layers = n_layers; m->d.in_size = sizes[0]; m->d.out_size = sizes[n_layers];
     auto fail = [&](const char *msg) { g_create_error = msg; smr_mlp_destroy(m); return SMR_E_HIP; };
     for (int l = 0; l < n_layers; ++l) {
-        // zero padded: K to a multiple of 4 (the k depth of one MFMA), N to a multiple of 64 (four 16-column tiles per pass), the
-        // last layer's N to a multiple of 16; a hidden layer's padded N is the next layer's K
-        const int K = l == 0 ? (sizes[0] + 3) / 4 * 4 : m->d.N[l - 1];
-        const int N = l == n_layers - 1 ? (sizes[l + 1] + 15) / 16 * 16 : (sizes[l + 1] + 63) / 64 * 64;
+        // zero padded: K to a multiple of 16 (four MFMA k steps are fetched together), N to a multiple of 64 (four 16-column tiles per
+        // pass); a hidden layer's padded N is the next layer's K
+        const int K = l == 0 ? (sizes[0] + 15) / 16 * 16 : m->d.N[l - 1];
+        const int N = (sizes[l + 1] + 63) / 64 * 64;
         m->d.K[l] = K; m->d.N[l] = N; m->d.act[l] = activations[l];
         std::vector<float> W((size_t)K * N, 0.f), b((size_t)N, 0.f);
         for (int k = 0; k < sizes[l]; ++k)
