@@ -56,6 +56,10 @@ constexpr int kPlanetDescDwords = 8;
 constexpr float kKeyStep = 0.0025f;        // candidate key = floor(lower bound / kKeyStep), 255 = done / no candidate
 constexpr int kStartBins = 8;                                // cube-map resolution of the climb start table
 constexpr int kStartCells = 6 * kStartBins * kStartBins;     // entries per piece
+// the reset-side kernels (reset, spawn, target: smr_hip.hip) climb over the hulls of ALL bodies, a different one per lane: one LDS
+// pool per block with every body's tables (body_pool_tables, smr_tables.h), kBodyPoolHead dwords of offsets per body in front
+constexpr int kBodyPoolHead = 4;                             // vertices, id groups, start map (dword offsets into the pool), unused
+constexpr int kBodyPoolDwords = 14848;                       // 58 KB: two 256-lane blocks per CU
 
 struct DPlanet {
     int piece_begin, piece_count, n_orbit, index_shift, coupled;
@@ -81,6 +85,8 @@ struct DScene {
     int body_parent[SMR_MAX_BODIES], ee_body;
     float body_xyz[SMR_MAX_BODIES][3], body_rot[SMR_MAX_BODIES][9];   // parent link frame -> body frame
     int n_self_pairs, self_pair[SMR_MAX_SELF_PAIRS][2];               // (body, partner body | -(world piece + 1))
+    const uint32_t *body_pool;            // image of the reset-side kernels' LDS pool (body_pool_tables)
+    int body_pool_dwords;
     int n_static, static_piece[SMR_MAX_STATIC];
     unsigned static_mask;
     float static_max;
@@ -725,6 +731,15 @@ __device__ __forceinline__ GlobalHull global_hull(const DScene &S, int pi, const
                       (const SMR_GLOBAL uint32_t *)S.ids4 + P.ids_begin, (const SMR_GLOBAL uint8_t *)S.start + kStartCells * (size_t)pi};
 }
 
+// the hull of body b in a block's LDS copy of DScene::body_pool
+struct BodyPool {
+    const uint32_t *pool;
+    __device__ __forceinline__ LocalHull hull(int b) const {
+        const uint32_t *h = pool + kBodyPoolHead * b;
+        return LocalHull{(const float *)pool + h[0], pool + h[1], (const uint8_t *)(pool + h[2])};
+    }
+};
+
 // closest point of segment (a,b) to the origin; mask: bit0 a, bit1 b support it
 __device__ __forceinline__ F3 seg_closest(F3 a, F3 b, int &mask) {
     F3 e = b - a;
@@ -1058,9 +1073,10 @@ __device__ inline Xf body_frame(const DScene &S, const float q[SMR_NJ], int b) {
 // chain link (its hull climbed from the global tables, per lane) or the base adapter's cylinder in the world frame
 // (btCylinderShapeZ::localGetSupportingVertexWithoutMargin).  Margins subtracted; > cutoff means "farther than cutoff".
 // LANE: the pair index differs between lanes (reset groups deal the pairs to their lanes), so nothing is wave uniform.
+// bodies: when given, the partner link's hull comes from that LDS pool instead of the global tables.
 template <bool LANE = false, class HB>
 __device__ inline float self_pair_distance(const DScene &S, int i, const float q[SMR_NJ], const DPiece &LP, const HB &hull,
-                                           const Xf &T, float cutoff, float stop_below) {
+                                           const Xf &T, float cutoff, float stop_below, const BodyPool *bodies = nullptr) {
     const int partner = S.self_pair[i][1];
     const int pa = partner >= 0 ? S.link_piece[partner] : -(partner + 1);
     const DPiece A = LANE ? load_piece_lane(S.pieces, pa) : load_piece(S.pieces, pa);
@@ -1072,6 +1088,11 @@ __device__ inline float self_pair_distance(const DScene &S, int i, const float q
         const F3 d = apply(XA, F3{A.cx, A.cy, A.cz}) - cb;
         const float lb = sqrtf(dot(d, d)) - A.radius - LP.radius - margins;
         if (lb > cutoff) return lb;
+        if (bodies) {
+            const LocalHull ha = bodies->hull(partner);
+            const auto sa = [&](F3 dd, int &hint, bool first) { return apply(XA, ha.support(rot_t(XA, dd), hint, first)); };
+            return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins) - margins;
+        }
         const GlobalHull ha = global_hull(S, pa, A);
         const auto sa = [&](F3 dd, int &hint, bool first) { return apply(XA, ha.support(rot_t(XA, dd), hint, first)); };
         return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins) - margins;

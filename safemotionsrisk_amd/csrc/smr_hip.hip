@@ -45,9 +45,51 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
 }
 
+#ifdef SMR_PROFILE_ROWS
+// profiling build (scripts/profile_rows.py): shader-clock cycles of the collide kernel's wavefronts, summed per grid row
+__device__ unsigned long long g_row_cycles[128];       // [row]: cycles, [64 + row]: wavefronts
+struct RowClock {
+    unsigned long long t0;
+    int row;
+    __device__ RowClock(int r) : t0(__builtin_readcyclecounter()), row(r) {}
+    __device__ ~RowClock() {
+        if (__lane_id() == 0 && row < 64) { atomicAdd(&g_row_cycles[row], __builtin_readcyclecounter() - t0); atomicAdd(&g_row_cycles[64 + row], 1ull); }
+    }
+};
+extern "C" int smr_debug_row_cycles(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_cycles), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[128] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_row_cycles), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define SMR_ROW_CLOCK(r) RowClock row_clock_(r)
+// ... and of the phases of the reset-side kernels: slots 32 + phase (first active lane of the wavefront)
+struct PhaseClock {
+    unsigned long long t;
+    __device__ PhaseClock() : t(__builtin_readcyclecounter()) {}
+    __device__ void mark(int i) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) { atomicAdd(&g_row_cycles[32 + i], now - t); atomicAdd(&g_row_cycles[96 + i], 1ull); }
+        t = now;
+    }
+};
+#define SMR_PHASE_INIT PhaseClock phase_clock_
+#define SMR_PHASE(i) phase_clock_.mark(i)
+#else
+#define SMR_ROW_CLOCK(r)
+#define SMR_PHASE_INIT
+#define SMR_PHASE(i)
+#endif
+
 // one lane per (env, body l), grid = (B / block, self pairs + n_bodies): the end-of-step sample k = N (distances of the reward + its
 // contact test), then the intermediate contact samples the body still needs (smr_device.h, "A11") as work items that the lanes of
 // the wavefront share out among themselves.
+// The reset-side kernels (reset, spawn, target) run beside the step kernels.  Left to itself the compiler gives their wavefronts the
+// whole register file of a SIMD (256 VGPRs + 256 AGPRs as spill space): one such wavefront then keeps every collide wavefront off
+// its SIMD for as long as its rejection loops run.  SMR_SIDE_WAVES wavefronts per SIMD = 512 / SMR_SIDE_WAVES registers each.
+#ifndef SMR_SIDE_WAVES
+#define SMR_SIDE_WAVES 2
+#endif
+#define SMR_SIDE_KERNEL __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_SIDE_WAVES, SMR_SIDE_WAVES)))
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
@@ -58,6 +100,7 @@ template <bool SELF, bool AUTO>
 __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = AUTO ? 256 : 64;
+    SMR_ROW_CLOCK((int)blockIdx.y);
     // grid y: first the self-collision pairs (SELF; they only work at the end-of-step sample), then the bodies, outer ones
     // (most planet work) first
     const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
@@ -450,14 +493,23 @@ struct Group {
 };
 
 // Lane g of a group works the bodies g, g + 8, ... (8 chain links; the ball machine's pieces fold onto lanes 0, 1).
+// The lanes' bodies differ, so their hulls are climbed in the block's LDS copy of all bodies' tables (BodyPool).
+constexpr int kSideBlock = 256;
 
-// table and self-collision clearance of ONE body (ctlp.py:2140-2208, 1605-1619)
-// EXTRA: the scene has bodies beyond the chain and self-collision pairs (ball machine); false compiles that code out
-template <bool EXTRA>
-__device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ], const Xf &T, float thr) {
-    const int pl = S.link_piece[b];
-    const DPiece LP = load_piece_lane(S.pieces, pl);
-    const GlobalHull hull = global_hull(S, pl, LP);
+// the block's copy of DScene::body_pool; false (for the whole block) when none of its groups has an entry of the list to work
+__device__ inline bool stage_body_pool(const DScene &S, uint32_t *pool, int count, int group_stride) {
+    const int grp0 = (int)((blockIdx.x * blockDim.x) >> 3);
+    if ((grp0 + group_stride - 1) / group_stride >= count) return false;
+    const SMR_GLOBAL uint32_t *g = (const SMR_GLOBAL uint32_t *)S.body_pool;
+    for (int i = threadIdx.x; i < S.body_pool_dwords; i += kSideBlock) pool[i] = g[i];
+    __syncthreads();
+    return true;
+}
+
+// table clearance of ONE body (ctlp.py:2140-2208)
+__device__ inline bool body_clear(const DScene &S, const BodyPool &BP, int b, const Xf &T, float thr) {
+    const DPiece LP = load_piece_lane(S.pieces, S.link_piece[b]);
+    const LocalHull hull = BP.hull(b);
     bool ok = true;
     if ((S.static_mask >> b) & 1u)
         for (int s = 0; s < S.n_static; ++s) {
@@ -467,54 +519,50 @@ __device__ inline bool body_clear(const DScene &S, int b, const float q[SMR_NJ],
     return ok;
 }
 
-// the self-collision pairs dealt round-robin to the lanes of a group: lane g tests pairs g, g + 8, ... (ctlp.py:2170-2208)
-__device__ inline bool lane_self_pairs_clear(const DScene &S, const Group &G, const float q[SMR_NJ], float thr_self) {
+// the self-collision pairs dealt round-robin to the lanes of a group: lane g tests pairs g, g + 8, ... (ctlp.py:2170-2208, 1605-1619)
+__device__ inline bool lane_self_pairs_clear(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], float thr_self) {
     bool ok = true;
     for (int i = G.g; i < S.n_self_pairs; i += 8) {
-        const int a = S.self_pair[i][0], pl = S.link_piece[a];
-        const DPiece LP = load_piece_lane(S.pieces, pl);
-        float d = self_pair_distance<true>(S, i, q, LP, global_hull(S, pl, LP), body_frame(S, q, a), thr_self + 0.005f, 0.f);
+        const int a = S.self_pair[i][0];
+        const DPiece LP = load_piece_lane(S.pieces, S.link_piece[a]);
+        float d = self_pair_distance<true>(S, i, q, LP, BP.hull(a), body_frame(S, q, a), thr_self + 0.005f, 0.f, &BP);
         if (d <= thr_self + 0.005f && d < thr_self) ok = false;
     }
     return ok;
 }
 
+// table and self-collision clearance of a configuration, cheapest test first: the bodies against the table (mostly settled by the
+// capsule / lowest-point shortcuts of piece_distance), then - only if all are clear - the self-collision pairs
+// EXTRA: the scene has bodies beyond the chain and self-collision pairs (ball machine); false compiles that code out
+template <bool EXTRA>
+__device__ inline bool group_table_free(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], float thr, float thr_self) {
+    bool ok = true;
+    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear(S, BP, b, body_frame(S, q, b), thr);
+    if (!G.all(ok)) return false;
+    if (EXTRA) return G.all(lane_self_pairs_clear(S, BP, G, q, thr_self));
+    return true;
+}
+
 // A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138, for one candidate q.  box / thr: cartesian
 // range of the end-effector point and minimum table / self distances (start states ctlp.py:172-183,1468-1477; ball
 // targets ctlp.py:191-229,1725-1726,2357).  (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is
-// outside the kinematic path.)
+// outside the kinematic path.)  The box first (ctlp.py:2051-2061): one pass down the chain, the same on every lane - about half
+// of the uniformly drawn candidates of a target point end there, before any distance query.
 template <bool EXTRA>
-__device__ inline bool group_pose_valid(const DScene &S, const Group &G, const float q[SMR_NJ], const float box[3][2], float thr,
+__device__ inline bool group_pose_valid(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], const float box[3][2], float thr,
                                         float thr_self) {
-    bool ok = true;
-    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) {
-        const Xf T = body_frame(S, q, b);
-        ok = ok && body_clear<EXTRA>(S, b, q, T, thr);
-        if (b == S.ee_body) {
-            F3 ee = apply(T, F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});            // ctlp.py:2051-2061
-            if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) ok = false;
-        }
-    }
-    if (EXTRA) ok = ok && lane_self_pairs_clear(S, G, q, thr_self);
-    return G.all(ok);
-}
-
-template <bool EXTRA>
-__device__ inline bool group_table_free(const DScene &S, const Group &G, const float q[SMR_NJ]) {
-    bool ok = true;
-    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear<EXTRA>(S, b, q, body_frame(S, q, b), S.start_min_static);
-    if (EXTRA) ok = ok && lane_self_pairs_clear(S, G, q, S.start_min_self);
-    return G.all(ok);
+    const F3 ee = apply(body_frame(S, q, S.ee_body), F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
+    if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) return false;
+    return group_table_free<EXTRA>(S, BP, G, q, thr, thr_self);
 }
 
 // Bullet contact between any planet piece and any robot body (Planet.check_if_object_is_colliding, ctlp.py:4570-4579)
 template <bool EXTRA>
-__device__ inline bool group_planet_contact(const DScene &S, const Group &G, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS]) {
+__device__ inline bool group_planet_contact(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS]) {
     bool contact = false;
     for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) {
-        const int pl = S.link_piece[b];
-        const DPiece LP = load_piece_lane(S.pieces, pl);
-        const Sample r = collide_link(S, b, LP, global_hull(S, pl, LP), body_frame(S, q, b), idx, nullptr, false, false, true);
+        const DPiece LP = load_piece_lane(S.pieces, S.link_piece[b]);
+        const Sample r = collide_link(S, b, LP, BP.hull(b), body_frame(S, q, b), idx, nullptr, false, false, true);
         contact = contact || r.contact;
     }
     return G.any(contact);
@@ -522,13 +570,12 @@ __device__ inline bool group_planet_contact(const DScene &S, const Group &G, con
 
 // is the ball (pose XB) within Bullet's contact distance of any robot body? (Ball.check_if_object_is_colliding, ctlp.py:4186-4194)
 template <bool EXTRA>
-__device__ inline bool group_ball_contact(const DScene &S, const Group &G, const float q[SMR_NJ], const Xf &XB) {
+__device__ inline bool group_ball_contact(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], const Xf &XB) {
     bool contact = false;
     for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8)
         if ((S.contact_mask >> b) & 1u) {
-            const int pl = S.link_piece[b];
-            const DPiece LP = load_piece_lane(S.pieces, pl);
-            float d = piece_distance<false>(S, S.ball_piece, XB, LP, global_hull(S, pl, LP), body_frame(S, q, b), S.contact_dist, S.contact_dist);
+            const DPiece LP = load_piece_lane(S.pieces, S.link_piece[b]);
+            float d = piece_distance<false>(S, S.ball_piece, XB, LP, BP.hull(b), body_frame(S, q, b), S.contact_dist, S.contact_dist);
             contact = contact || d <= S.contact_dist;
         }
     return G.any(contact);
@@ -724,7 +771,7 @@ struct BallSpawn { float p0[3], v0[3], e0[3], omega; int kmax, khit; };
 // _add_moving_object, ctlp.py:1723-1931, by a group of 8 lanes: candidate target poses one after the other, each
 // tested link-parallel; the scalar launch arithmetic is computed redundantly by all lanes, in float64.
 template <bool EXTRA>
-__device__ inline BallSpawn spawn_ball_group(const DScene &S, const DState &st, const Rng &rng, const Group &G) {
+__device__ inline BallSpawn spawn_ball_group(const DScene &S, const BodyPool &BP, const DState &st, const Rng &rng, const Group &G) {
     const int jj = G.g < SMR_NJ ? G.g : 0;
     const double udt = S.dt64 / S.updates_per_step, v = S.ball_speed, grav = 9.81;
     double rel[3] = {0, 0, 0}, vel[3] = {0, 0, 1};
@@ -741,7 +788,7 @@ __device__ inline BallSpawn spawn_ball_group(const DScene &S, const DState &st, 
             float q[SMR_NJ];
             G.gather(rng.uniform(S_BALL_POSE, 7u * pose_attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
             ++pose_attempt;
-            if (group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); have_target = true; break; }
+            if (group_pose_valid<EXTRA>(S, BP, G, q, S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); have_target = true; break; }
         }
         if (!have_target) { if (G.g == 0) sampling_exhausted(st, kSamplingBallTarget); break; }            // ctlp.py:2127-2136 raises
         const double dx = target[0] - rel[0], dy = target[1] - rel[1], dh = target[2] - rel[2];
@@ -843,15 +890,19 @@ __device__ inline void store_ball(const DState &st, int B, int e, const BallSpaw
 // Otherwise the ball is installed - from the staged launch when one with the right tag is there, else drawn on the spot.
 // tags / tag_offset (STAGE): the spawn count the launch is for - tags[i], or the env's current count + tag_offset
 template <bool EXTRA, bool STAGE>
-__global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
+__global__ SMR_SIDE_KERNEL void spawn_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                    const int *__restrict__ count_ptr, int count_fixed, int all_reset, int group_stride,
                                                    float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
+    __shared__ uint32_t pool[kBodyPoolDwords];
+    const int count = count_ptr ? *count_ptr : count_fixed;
+    if (!stage_body_pool(S, pool, count, group_stride)) return;
+    const BodyPool BP{pool};
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t >> 3, g = t & 7;
     if (grp % group_stride) return;
     const int i = grp / group_stride;
-    if (i >= (count_ptr ? *count_ptr : count_fixed)) return;
+    if (i >= count) return;
     const int entry = list ? list[i] : i;
     const bool is_reset = all_reset || entry < 0;
     const int e = entry < 0 ? -(entry + 1) : entry;
@@ -860,8 +911,10 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
     const unsigned spawns = STAGE ? (tags ? tags[i] : (unsigned)st.ball_i[4 * B + e] + (unsigned)tag_offset) : (unsigned)st.ball_i[4 * B + e];
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
     const size_t sl = (size_t)(spawns & 1u);
+    SMR_PHASE_INIT;
     if (STAGE) {
-        const BallSpawn b = spawn_ball_group<EXTRA>(S, st, rng, G);
+        const BallSpawn b = spawn_ball_group<EXTRA>(S, BP, st, rng, G);
+        SMR_PHASE(4);
         if (g == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) { st.next_ball[(sl * 10 + c) * B + e] = b.p0[c]; st.next_ball[(sl * 10 + 3 + c) * B + e] = b.v0[c]; st.next_ball[(sl * 10 + 6 + c) * B + e] = b.e0[c]; }
@@ -880,7 +933,7 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
         b.kmax = st.next_ball_i[(sl * 2) * B + e]; b.khit = st.next_ball_i[(sl * 2 + 1) * B + e];
     }
     if (G.any(!have)) {                                  // nothing matching staged for this group: draw it now
-        const BallSpawn b2 = spawn_ball_group<EXTRA>(S, st, rng, G);
+        const BallSpawn b2 = spawn_ball_group<EXTRA>(S, BP, st, rng, G);
         if (!have) b = b2;
     }
     BallState bs;
@@ -897,7 +950,7 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
         bool free_step = false;
         for (unsigned n = 0; n < 100000u && !free_step; ++n) {
             k0 = rng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
-            free_step = !group_ball_contact<EXTRA>(S, G, q, ball_pose(S, bs, k0, nullptr));
+            free_step = !group_ball_contact<EXTRA>(S, BP, G, q, ball_pose(S, bs, k0, nullptr));
         }
         if (!free_step && g == 0) sampling_exhausted(st, kSamplingBallInitialStep);
     }
@@ -913,15 +966,19 @@ __global__ __launch_bounds__(64) void spawn_kernel(const DScene *__restrict__ Sp
 // STAGED: the point for the env's CURRENT target count goes to next_tp / next_tp_tag and nothing of the live env is touched
 // tags / tag_offset (STAGED): the target count the point is for - tags[i], or the env's current count + tag_offset
 template <bool EXTRA, bool STAGED>
-__global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
+__global__ SMR_SIDE_KERNEL void target_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                     const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                     float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
+    __shared__ uint32_t pool[kBodyPoolDwords];
+    const int n_entries = count_ptr ? *count_ptr : count_fixed;
+    if (!stage_body_pool(S, pool, n_entries, group_stride)) return;
+    const BodyPool BP{pool};
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t >> 3, g = t & 7;
     if (grp % group_stride) return;
     const int i = grp / group_stride;
-    if (i >= (count_ptr ? *count_ptr : count_fixed)) return;
+    if (i >= n_entries) return;
     const int e = list ? list[i] : i;
     const int B = S.B;
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
@@ -930,10 +987,12 @@ __global__ __launch_bounds__(64) void target_kernel(const DScene *__restrict__ S
     const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, count};
     float q[SMR_NJ];
     bool found = false;
+    SMR_PHASE_INIT;
     for (unsigned m = 0; m < 100000u && !found; ++m) {
         G.gather(rng.uniform(S_TARGET, 7u * m + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
-        found = group_pose_valid<EXTRA>(S, G, q, S.ball_target_box, S.target_min_static, S.target_min_self);
+        found = group_pose_valid<EXTRA>(S, BP, G, q, S.ball_target_box, S.target_min_static, S.target_min_self);
     }
+    SMR_PHASE(6);
     if (!found && g == 0) sampling_exhausted(st, kSamplingTargetPoint);                                   // ctlp.py:2127-2136 raises
     if (g == 0 && STAGED) {
         const F3 target = ee_point(S, q);
@@ -973,15 +1032,18 @@ static int reset_group_stride(bool staged = false) {
 // the kernel then runs on the side stream while the main stream steps the envs (scenes without a ball).
 // tags / tag_offset (STAGED): the reset count the state is for - tags[i], or the env's current count + tag_offset
 template <bool STAGED, bool EXTRA>
-__global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
+__global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                    const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                    float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
+    __shared__ uint32_t pool[kBodyPoolDwords];
+    const int count = count_ptr ? *count_ptr : count_fixed;
+    if (!stage_body_pool(S, pool, count, group_stride)) return;
+    const BodyPool BP{pool};
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int grp = t >> 3, g = t & 7;
     if (grp % group_stride) return;
     const int i = grp / group_stride;
-    const int count = count_ptr ? *count_ptr : count_fixed;
     if (i >= count) return;
     const int e = list ? list[i] : i;
     const int B = S.B;
@@ -997,11 +1059,13 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         for (int tries = 0; tries < 100000; ++tries) {
             G.gather(rng.uniform(S_POS, 7u * attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);               // ctlp.py:2035-2037
             ++attempt;
-            if (group_pose_valid<EXTRA>(S, G, q, S.start_box, S.start_min_static, S.start_min_self)) return;
+            if (group_pose_valid<EXTRA>(S, BP, G, q, S.start_box, S.start_min_static, S.start_min_self)) return;
         }
         if (g == 0) sampling_exhausted(st, kSamplingStart);                                               // ctlp.py:2127-2136 raises
     };
+    SMR_PHASE_INIT;
     next_position();
+    SMR_PHASE(0);
 
     // ---- joint velocity / acceleration.  After this block lane j (< 7) holds joint j in (qj, vj, aj).
     float vj = 0.f, aj = 0.f, qj = 0.f;
@@ -1047,7 +1111,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
             const float nv = interp_vel(cv, ca, na, S.dt, S.dt), nq = interp_pos(cq, cv, ca, na, S.dt, S.dt);
             float nqv[SMR_NJ];
             G.gather(nq, nqv);
-            if (group_table_free<EXTRA>(S, G, nqv)) {
+            if (group_table_free<EXTRA>(S, BP, G, nqv, S.start_min_static, S.start_min_self)) {
                 if (nxt == 0) { hq0 = nq; hv0 = nv; ha0 = na; } else if (nxt == 1) { hq1 = nq; hv1 = nv; ha1 = na; } else { hq2 = nq; hv2 = nv; ha2 = na; }
                 ++cnt;
             } else {
@@ -1063,6 +1127,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
         G.gather(qj, q);
     }
 
+    SMR_PHASE(1);
     // ---- planet phase: candidate phases in sequence, first contact-free one wins (ctlp.py:4470-4501)
     int idx[SMR_MAX_PLANETS] = {0, 0};
     int hit = 0;
@@ -1080,7 +1145,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
                 if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % no + no) % no;
                 else idx[p] = rng.randint(S_PLANET, n * (unsigned)n_indep + (unsigned)(k++), no);
             }
-            free_phase = !group_planet_contact<EXTRA>(S, G, q, idx);
+            free_phase = !group_planet_contact<EXTRA>(S, BP, G, q, idx);
         }
         if (!free_phase && g == 0) sampling_exhausted(st, kSamplingPlanetPhase);                          // the reference loops on (ctlp.py:4477-4490)
         // obstacle_wrapper.update(update_after_reset=True): one planet update + contact check,
@@ -1088,9 +1153,10 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (idx[p] + 1) % S.planet[p].n_orbit;
-        if (S.term_moving) hit = group_planet_contact<EXTRA>(S, G, q, idx) ? 1 : 0;
+        if (S.term_moving) hit = group_planet_contact<EXTRA>(S, BP, G, q, idx) ? 1 : 0;
     }
 
+    SMR_PHASE(2);
     if (STAGED) {      // robot part only; the ball of a reset depends on the env's spawn history: spawn_kernel draws it at commit time
         const size_t sl = (size_t)(rng.tag & 1u);
         if (g < SMR_NJ) { st.next_q[(sl * SMR_NJ + g) * B + e] = qj; st.next_v[(sl * SMR_NJ + g) * B + e] = vj; st.next_a[(sl * SMR_NJ + g) * B + e] = aj; }
@@ -1104,7 +1170,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
     if (S.use_ball) {
         ball_spawns = (unsigned)st.ball_i[4 * B + e];
         const Rng brng = {S.seed_lo, S.seed_hi, (unsigned)e, ball_spawns};
-        bsp = spawn_ball_group<EXTRA>(S, st, brng, G);
+        bsp = spawn_ball_group<EXTRA>(S, BP, st, brng, G);
         if (S.ball_random_initial) {
             BallState bs;
             for (int c = 0; c < 3; ++c) { bs.p0[c] = bsp.p0[c]; bs.v0[c] = bsp.v0[c]; bs.e0[c] = bsp.e0[c]; }
@@ -1115,7 +1181,7 @@ __global__ __launch_bounds__(64) void reset_kernel(const DScene *__restrict__ Sp
             bool free_step = false;
             for (unsigned n = 0; n < 100000u && !free_step; ++n) {
                 ball_k0 = brng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
-                free_step = !group_ball_contact<EXTRA>(S, G, q, ball_pose(S, bs, ball_k0, nullptr));
+                free_step = !group_ball_contact<EXTRA>(S, BP, G, q, ball_pose(S, bs, ball_k0, nullptr));
             }
             if (!free_step && g == 0) sampling_exhausted(st, kSamplingBallInitialStep);
         }
@@ -1425,6 +1491,13 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     d.use_ball = s.use_ball; d.dt64 = s.dt;
     planet_tables(G, d);
     if (const char *v = getenv("SMR_LOCKSTEP_PLANETS")) if (atoi(v)) d.planets_auto = 0;     // A/B switch
+    {   // the reset-side kernels' LDS pool with every body's hull tables
+        std::vector<uint32_t> body_pool;
+        if (!body_pool_tables(s, G, body_pool)) { env->err = "the bodies' hull tables exceed the LDS pool of the reset kernels"; return SMR_E_INVALID; }
+        uint32_t *dpool;
+        if ((rc = dev_upload(env, &dpool, body_pool))) return rc;
+        d.body_pool = dpool; d.body_pool_dwords = (int)body_pool.size();
+    }
     {   // dispatch order of the bodies in the collide grid: the bodies with planet queries first, the ones with most work
         // (mounted pieces, then iiwa_link_5, 6, 4, 7, 3: measured) leading, so that the lightest of them start last
         int n = 0;
@@ -1686,43 +1759,46 @@ struct TmpBuf {
 
 static bool scene_extra(const smr_env *env) { return env->hscene.n_bodies > SMR_NLINK || env->hscene.n_self_pairs > 0; }
 
+// grid of a reset-side kernel: a group of 8 lanes per entry, every stride-th group works
+static dim3 side_grid(int entries, int stride) { return dim3((unsigned)(((size_t)entries * 8 * stride + kSideBlock - 1) / kSideBlock)); }
+
 template <bool STAGED>
 static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs,
                          const unsigned *tags = nullptr, int tag_offset = 0) {
-    if (scene_extra(env)) hipLaunchKernelGGL((reset_kernel<STAGED, true>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
-    else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(64), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
+    if (scene_extra(env)) hipLaunchKernelGGL((reset_kernel<STAGED, true>), grid, dim3(kSideBlock), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
+    else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(kSideBlock), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
 }
 
 static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int all_reset, int stride, float *obs) {
-    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
-    else hipLaunchKernelGGL((spawn_kernel<false, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, false>), grid, dim3(kSideBlock), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
+    else hipLaunchKernelGGL((spawn_kernel<false, false>), grid, dim3(kSideBlock), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
 }
 // the staged launch of the NEXT ball of the listed envs (after their current one was installed), on stream s
 static void launch_spawn_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride,
                                 const unsigned *tags = nullptr, int tag_offset = 0) {
-    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
-    else hipLaunchKernelGGL((spawn_kernel<false, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
+    else hipLaunchKernelGGL((spawn_kernel<false, true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
 }
 
 static void launch_target(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {
-    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, (const unsigned *)nullptr, 0);
-    else hipLaunchKernelGGL((target_kernel<false, false>), grid, dim3(64), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, (const unsigned *)nullptr, 0);
+    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, false>), grid, dim3(kSideBlock), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, (const unsigned *)nullptr, 0);
+    else hipLaunchKernelGGL((target_kernel<false, false>), grid, dim3(kSideBlock), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, (const unsigned *)nullptr, 0);
 }
 // the staged next target of the listed envs (after their current one was installed), on stream s
 static void launch_target_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride,
                                  const unsigned *tags = nullptr, int tag_offset = 0) {
-    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
-    else hipLaunchKernelGGL((target_kernel<false, true>), grid, dim3(64), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
+    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
+    else hipLaunchKernelGGL((target_kernel<false, true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
 }
 
 static int launch_reset_list(smr_env *env, float *obs_dev) {
     // entries of done_list[0..*done_count) are reset; the grid covers the worst case B, idle lanes exit at once
     LaunchTimer t(env, SMR_K_RESET);
     const int B = env->B;
-    launch_reset<false>(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->stream, env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
+    launch_reset<false>(env, side_grid(B, reset_group_stride()), env->stream, env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
     SMR_HIP(hipGetLastError());
     if (env->hscene.use_target) {                       // the target points of the new episodes
-        launch_target(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
+        launch_target(env, side_grid(B, reset_group_stride()), env->st.done_list, env->st.done_count, 0, reset_group_stride(), obs_dev);
         SMR_HIP(hipGetLastError());
     }
     return SMR_OK;
@@ -1755,12 +1831,12 @@ static int staged_launch_refill(smr_env *env, int p) {
         if (side2) {                                    // the next target / ball of the envs whose staged one was installed: its own
             SMR_HIP(hipEventRecord(ev_fork, side));                                // stream, beside the start states (all are latency chains)
             SMR_HIP(hipStreamWaitEvent(side2, ev_fork, 0));
-            const dim3 grid(((size_t)B * 8 * reset_group_stride(true) + 63) / 64);
+            const dim3 grid = side_grid(B, reset_group_stride(true));
             if (env->tp_refill_slots) launch_target_staged(env, side2, grid, env->st.tp_refill_list, env->st.tp_refill_count, 0, reset_group_stride(true), env->st.tp_refill_tags, 0);
             if (env->stage_balls) launch_spawn_staged(env, side2, grid, env->st.spawn_list, env->st.spawn_count, 0, reset_group_stride(true), env->st.spawn_tags, 0);
             SMR_HIP(hipEventRecord(ev_join, side2));
         }
-        launch_reset<true>(env, dim3(((size_t)B * 8 * reset_group_stride(true) + 63) / 64), side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(true),
+        launch_reset<true>(env, side_grid(B, reset_group_stride(true)), side, env->st.refill_list, env->st.refill_count, 0, reset_group_stride(true),
                            (float *)nullptr, env->st.refill_tags, 0);
         if (side2) SMR_HIP(hipStreamWaitEvent(side, ev_join, 0));
     }
@@ -1773,7 +1849,7 @@ static int staged_prepare_all(smr_env *env, int tag_offset = 0) {
     int rc;
     if ((rc = staged_wait_refill(env))) return rc;
     LaunchTimer t(env, SMR_K_RESET);
-    launch_reset<true>(env, dim3(((size_t)env->B * 8 + 63) / 64), env->stream, (const int *)nullptr, (const int *)nullptr, env->B, 1, (float *)nullptr, nullptr, tag_offset);
+    launch_reset<true>(env, side_grid(env->B, 1), env->stream, (const int *)nullptr, (const int *)nullptr, env->B, 1, (float *)nullptr, nullptr, tag_offset);
     SMR_HIP(hipGetLastError());
     return SMR_OK;
 }
@@ -1821,7 +1897,7 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
         env->st.refill_zero = nullptr; env->st.tp_refill_zero = nullptr;
         if (env->stage_balls) { env->st.spawn_list = env->spawn_lists + (size_t)env->rot * B; env->st.spawn_tags = env->spawn_tag_lists + (size_t)env->rot * B; env->st.spawn_count = env->spawn_counts + env->rot; }
         const int stride = mask_dev ? reset_group_stride() : 1;
-        const dim3 ggrid(((size_t)B * 8 * stride + 63) / 64);
+        const dim3 ggrid = side_grid(B, stride);
         const int *list = nullptr, *count = nullptr;
         int fixed = B;
         if (mask_dev) {
@@ -1857,10 +1933,10 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     }
     if (!mask_dev) {
         LaunchTimer t(env, SMR_K_RESET);
-        launch_reset<false>(env, dim3(((size_t)B * 8 + 63) / 64), env->stream, (const int *)nullptr, (const int *)nullptr, B, 1, obs_dev);
+        launch_reset<false>(env, side_grid(B, 1), env->stream, (const int *)nullptr, (const int *)nullptr, B, 1, obs_dev);
         SMR_HIP(hipGetLastError());
         if (env->hscene.use_target) {
-            launch_target(env, dim3(((size_t)B * 8 + 63) / 64), nullptr, nullptr, B, 1, obs_dev);
+            launch_target(env, side_grid(B, 1), nullptr, nullptr, B, 1, obs_dev);
             SMR_HIP(hipGetLastError());
         }
         return SMR_OK;
@@ -1944,12 +2020,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     SMR_HIP(hipGetLastError());
     if (env->hscene.use_ball) {
         LaunchTimer t(env, SMR_K_SPAWN);
-        launch_spawn(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.spawn_list, env->st.spawn_count, 0, 0, reset_group_stride(), obs_dev);
+        launch_spawn(env, side_grid(B, reset_group_stride()), env->st.spawn_list, env->st.spawn_count, 0, 0, reset_group_stride(), obs_dev);
         SMR_HIP(hipGetLastError());
     }
     if (env->hscene.use_target) {                       // reached target points, and those of staged resets
         LaunchTimer t(env, SMR_K_SPAWN);
-        launch_target(env, dim3(((size_t)B * 8 * reset_group_stride() + 63) / 64), env->st.tp_list, env->st.tp_list_count, 0, reset_group_stride(), obs_dev);
+        launch_target(env, side_grid(B, reset_group_stride()), env->st.tp_list, env->st.tp_list_count, 0, reset_group_stride(), obs_dev);
         SMR_HIP(hipGetLastError());
     }
     if (staged) {
@@ -2019,15 +2095,15 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
     }
     if (env->stage_balls && h->ball_i) {               // ... the staged balls to the old spawn counters
         if ((rc = staged_wait_refill(env))) return rc;
-        launch_spawn_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1, nullptr, 0);
-        launch_spawn_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1, nullptr, 1);
+        launch_spawn_staged(env, env->stream, side_grid(env->B, 1), nullptr, nullptr, env->B, 1, nullptr, 0);
+        launch_spawn_staged(env, env->stream, side_grid(env->B, 1), nullptr, nullptr, env->B, 1, nullptr, 1);
         SMR_HIP(hipGetLastError());
         SMR_HIP(hipStreamSynchronize(env->stream));
     }
     if (env->tp_refill_slots && h->target_count) {     // ... and the staged target points to the old target counters
         if ((rc = staged_wait_refill(env))) return rc;
-        launch_target_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1, nullptr, 0);
-        launch_target_staged(env, env->stream, dim3(((size_t)env->B * 8 + 63) / 64), nullptr, nullptr, env->B, 1, nullptr, 1);
+        launch_target_staged(env, env->stream, side_grid(env->B, 1), nullptr, nullptr, env->B, 1, nullptr, 0);
+        launch_target_staged(env, env->stream, side_grid(env->B, 1), nullptr, nullptr, env->B, 1, nullptr, 1);
         SMR_HIP(hipGetLastError());
         SMR_HIP(hipStreamSynchronize(env->stream));
     }

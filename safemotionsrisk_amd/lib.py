@@ -47,6 +47,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, srcs[0]]
+    cmd += os.environ.get("SMR_HIPCC_FLAGS", "").split()       # profiling builds (scripts/profile_rows.py: -DSMR_PROFILE_ROWS)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:
     text = open(sys.argv[1]).read()
 else:
-    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-o", "/dev/null",
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-o", "/dev/null"] + os.environ.get("SMR_HIPCC_FLAGS", "").split() + [
                         os.path.join(ROOT, "safemotionsrisk_amd", "csrc", "smr_hip.hip"), "-Rpass-analysis=kernel-resource-usage"],
                        capture_output=True, text=True)
     text = p.stderr

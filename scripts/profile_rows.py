@@ -1,0 +1,59 @@
+"""Where the collide kernel's time goes, per grid row (GPU box; needs a library built with SMR_HIPCC_FLAGS=-DSMR_PROFILE_ROWS):
+shader-clock cycles of the kernel's wavefronts summed per row = per self-collision pair / per body.
+
+    SMR_HIPCC_FLAGS=-DSMR_PROFILE_ROWS python -c "from safemotionsrisk_amd import lib; lib.build(force=True)"   (here)
+    python scripts/profile_rows.py CONFIG [steps]                                                               (GPU box)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import bench  # noqa: E402
+import safemotionsrisk_amd as smr  # noqa: E402
+from safemotionsrisk_amd import lib as _lib  # noqa: E402
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else "space_bm"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    cfg, kw, _, _ = bench._env_config(name)
+    kw = {k: v for k, v in kw.items() if k != "risk_networks"}
+    env = smr.VecSafeMotionsEnv(65536, seed=0, auto_reset=True, **kw, **cfg)
+    L = _lib.load()
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = [torch.rand((65536, 7), device="cuda", generator=g) * 2 - 1 for _ in range(8)]
+    for i in range(20):
+        env.step(acts[i % 8])
+    env.synchronize()
+    out = (C.c_ulonglong * 128)()
+    assert L.smr_debug_row_cycles(out, 1) == 0
+    for i in range(steps):
+        env.step(acts[i % 8])
+    env.synchronize()
+    assert L.smr_debug_row_cycles(out, 0) == 0
+    cyc = np.array(out[:64], dtype=np.float64) / steps
+    waves = np.array(out[64:], dtype=np.float64) / steps
+    s = env.scene.struct
+    n_pairs = s.n_self_pairs
+    total = cyc[:32].sum()
+    print("config %s: %.1f M wave-cycles per step over %d rows" % (name, total / 1e6, int((waves > 0).sum())))
+    phases = {32: "reset: start position", 33: "reset: velocity / acceleration", 34: "reset: planet phase", 36: "staged spawn: launch",
+              38: "target point"}
+    total = cyc[:32].sum()
+    for r in range(64):
+        if waves[r] == 0:
+            continue
+        if r >= 32:
+            print("  %-32s %8.2f M cycles  %8.0f cycles per wave, %6.0f waves per step" % (phases.get(r, "phase %d" % r), cyc[r] / 1e6, cyc[r] / waves[r], waves[r]))
+            continue
+        what = "pair %d (%d, %d)" % (r, s.self_pair[r][0], s.self_pair[r][1]) if r < n_pairs else "body row %d" % (r - n_pairs)
+        print("  row %2d %-18s %8.2f M cycles %5.1f%%  %6.0f cycles per wave" % (r, what, cyc[r] / 1e6, 100 * cyc[r] / total, cyc[r] / waves[r]))
+
+
+if __name__ == "__main__":
+    main()
