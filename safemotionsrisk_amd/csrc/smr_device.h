@@ -58,8 +58,8 @@ constexpr int kStartBins = 8;                                // cube-map resolut
 constexpr int kStartCells = 6 * kStartBins * kStartBins;     // entries per piece
 // the reset-side kernels (reset, spawn, target: smr_hip.hip) climb over the hulls of ALL bodies, a different one per lane: one LDS
 // pool per block with every body's tables (body_pool_tables, smr_tables.h), kBodyPoolHead dwords of offsets per body in front
-constexpr int kBodyPoolHead = 4;                             // vertices, id groups, start map (dword offsets into the pool), unused
-constexpr int kBodyPoolDwords = 14848;                       // 58 KB: two 256-lane blocks per CU
+constexpr int kBodyPoolHead = 4;                             // dword offsets into the pool: vertices, id groups, start map, DPiece
+constexpr int kBodyPoolDwords = 15360;                       // 60 KB: two 256-lane blocks per CU
 
 struct DPlanet {
     int piece_begin, piece_count, n_orbit, index_shift, coupled;
@@ -242,7 +242,7 @@ enum { S_POS = 0, S_JOINT = 1, S_WALK = 8, S_PLANET = 9, S_MODE = 10, S_BALL_REL
 
 struct Rng {
     unsigned k0, k1, env, tag;
-    __device__ unsigned u32(unsigned stream, unsigned draw) const {
+    __device__ __forceinline__ unsigned u32(unsigned stream, unsigned draw) const {
         unsigned c0 = draw >> 2, c1 = env, c2 = stream, c3 = tag, a = k0, b = k1;
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
@@ -255,11 +255,11 @@ struct Rng {
         unsigned sel = draw & 3u;
         return sel == 0 ? c0 : sel == 1 ? c1 : sel == 2 ? c2 : c3;
     }
-    __device__ float uniform01(unsigned stream, unsigned draw) const { return (float)(u32(stream, draw) >> 8) * (1.0f / 16777216.0f); }
-    __device__ float uniform(unsigned stream, unsigned draw, float lo, float hi) const { return fmaf(uniform01(stream, draw), hi - lo, lo); }
-    __device__ double uniform01d(unsigned stream, unsigned draw) const { return (double)(u32(stream, draw) >> 8) * (1.0 / 16777216.0); }
-    __device__ double uniformd(unsigned stream, unsigned draw, double lo, double hi) const { return lo + uniform01d(stream, draw) * (hi - lo); }
-    __device__ int randint(unsigned stream, unsigned draw, int n) const {
+    __device__ __forceinline__ float uniform01(unsigned stream, unsigned draw) const { return (float)(u32(stream, draw) >> 8) * (1.0f / 16777216.0f); }
+    __device__ __forceinline__ float uniform(unsigned stream, unsigned draw, float lo, float hi) const { return fmaf(uniform01(stream, draw), hi - lo, lo); }
+    __device__ __forceinline__ double uniform01d(unsigned stream, unsigned draw) const { return (double)(u32(stream, draw) >> 8) * (1.0 / 16777216.0); }
+    __device__ __forceinline__ double uniformd(unsigned stream, unsigned draw, double lo, double hi) const { return lo + uniform01d(stream, draw) * (hi - lo); }
+    __device__ __forceinline__ int randint(unsigned stream, unsigned draw, int n) const {
         return (int)(((unsigned long long)(u32(stream, draw) >> 8) * (unsigned long long)n) >> 24);
     }
 };
@@ -550,11 +550,10 @@ __device__ __forceinline__ Xf fk_base(const DScene &S) {
 }
 
 // T <- T * Trans(joint_xyz[k]) * Rot(joint_axis[k], qk): frame of iiwa_link_(k+1)
-__device__ __forceinline__ void fk_advance(const DScene &S, int k, float qk, Xf &T) {
+// ... with the joint's sine and cosine given (a lane that builds several frames of one configuration computes them once)
+__device__ __forceinline__ void fk_advance_sc(const DScene &S, int k, float s, float c, Xf &T) {
     T.t = apply(T, F3{S.joint_xyz[k][0], S.joint_xyz[k][1], S.joint_xyz[k][2]});
     float ax = S.joint_axis[k][0], ay = S.joint_axis[k][1], az = S.joint_axis[k][2];
-    float s, c;
-    sincosf(qk, &s, &c);
     float C = 1.f - c;
     float j0 = c + ax * ax * C, j1 = ax * ay * C - az * s, j2 = ax * az * C + ay * s;
     float j3 = ay * ax * C + az * s, j4 = c + ay * ay * C, j5 = ay * az * C - ax * s;
@@ -569,6 +568,11 @@ __device__ __forceinline__ void fk_advance(const DScene &S, int k, float qk, Xf 
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) T.r[i] = n[i];
+}
+__device__ __forceinline__ void fk_advance(const DScene &S, int k, float qk, Xf &T) {
+    float s, c;
+    sincosf(qk, &s, &c);
+    fk_advance_sc(S, k, s, c, T);
 }
 
 // the same with the hardware sine / cosine (v_sin_f32 / v_cos_f32, absolute error ~1e-6): for BOUNDS only - link frames that feed
@@ -738,6 +742,7 @@ struct BodyPool {
         const uint32_t *h = pool + kBodyPoolHead * b;
         return LocalHull{(const float *)pool + h[0], pool + h[1], (const uint8_t *)(pool + h[2])};
     }
+    __device__ __forceinline__ DPiece piece(int b) const { return piece_from_words((const int *)(pool + pool[kBodyPoolHead * b + 3])); }
 };
 
 // closest point of segment (a,b) to the origin; mask: bit0 a, bit1 b support it
@@ -1069,14 +1074,26 @@ __device__ inline Xf body_frame(const DScene &S, const float q[SMR_NJ], int b) {
     return b < SMR_NLINK ? T : mounted_frame(S, b, T);
 }
 
+// sines and cosines of a configuration's joint angles: the reset-side kernels build many frames of one candidate
+struct Trig { float sn[SMR_NJ], cs[SMR_NJ]; };
+__device__ inline Xf body_frame_sc(const DScene &S, const Trig &P, int b) {
+    const int link = b < SMR_NLINK ? b : SMR_NLINK - 1;
+    Xf T = fk_base(S);
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j)
+        if (j < link) fk_advance_sc(S, j, P.sn[j], P.cs[j], T);
+    return b < SMR_NLINK ? T : mounted_frame(S, b, T);
+}
+
 // A7 self: distance of self-collision pair i = (body a with hull (LP, hull) under T, partner): the partner is another
 // chain link (its hull climbed from the global tables, per lane) or the base adapter's cylinder in the world frame
 // (btCylinderShapeZ::localGetSupportingVertexWithoutMargin).  Margins subtracted; > cutoff means "farther than cutoff".
 // LANE: the pair index differs between lanes (reset groups deal the pairs to their lanes), so nothing is wave uniform.
-// bodies: when given, the partner link's hull comes from that LDS pool instead of the global tables.
+// bodies / trig (the reset-side kernels): the partner link's hull comes from that LDS pool instead of the global tables, its frame
+// from the configuration's sines and cosines.
 template <bool LANE = false, class HB>
 __device__ inline float self_pair_distance(const DScene &S, int i, const float q[SMR_NJ], const DPiece &LP, const HB &hull,
-                                           const Xf &T, float cutoff, float stop_below, const BodyPool *bodies = nullptr) {
+                                           const Xf &T, float cutoff, float stop_below, const BodyPool *bodies = nullptr, const Trig *trig = nullptr) {
     const int partner = S.self_pair[i][1];
     const int pa = partner >= 0 ? S.link_piece[partner] : -(partner + 1);
     const DPiece A = LANE ? load_piece_lane(S.pieces, pa) : load_piece(S.pieces, pa);
@@ -1084,10 +1101,16 @@ __device__ inline float self_pair_distance(const DScene &S, int i, const float q
     const F3 cb = apply(T, F3{LP.cx, LP.cy, LP.cz});
     const auto sb = [&](F3 d, int &hint, bool first) { return apply(T, hull.support(rot_t(T, d), hint, first)); };
     if (partner >= 0) {
-        const Xf XA = body_frame(S, q, partner);
+        const Xf XA = trig ? body_frame_sc(S, *trig, partner) : body_frame(S, q, partner);
         const F3 d = apply(XA, F3{A.cx, A.cy, A.cz}) - cb;
-        const float lb = sqrtf(dot(d, d)) - A.radius - LP.radius - margins;
+        float lb = sqrtf(dot(d, d)) - A.radius - LP.radius - margins;
         if (lb > cutoff) return lb;
+        {   // bounding capsules (both bodies are elongated: the spheres above overlap for every neighbour of a link)
+            const F3 a0 = apply(XA, F3{A.cap_a[0], A.cap_a[1], A.cap_a[2]}), a1 = apply(XA, F3{A.cap_b[0], A.cap_b[1], A.cap_b[2]});
+            const F3 b0 = apply(T, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), b1 = apply(T, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
+            lb = sqrtf(seg_seg_dist2(a0, a1, b0, b1)) * 0.99999f - 1e-6f - A.cap_r - LP.cap_r - margins;
+            if (lb > cutoff) return lb;
+        }
         if (bodies) {
             const LocalHull ha = bodies->hull(partner);
             const auto sa = [&](F3 dd, int &hint, bool first) { return apply(XA, ha.support(rot_t(XA, dd), hint, first)); };

@@ -490,6 +490,15 @@ struct Group {
 #pragma unroll
         for (int j = 0; j < SMR_NJ; ++j) q[j] = __shfl(x, gbase + j);
     }
+    // ... the joint angles: every lane gets the sines and cosines of all 7 (each computed once, by the joint's lane)
+    __device__ __forceinline__ Trig trig(float x) const {
+        float s, c;
+        sincosf(x, &s, &c);
+        Trig P;
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) { P.sn[j] = __shfl(s, gbase + j); P.cs[j] = __shfl(c, gbase + j); }
+        return P;
+    }
 };
 
 // Lane g of a group works the bodies g, g + 8, ... (8 chain links; the ball machine's pieces fold onto lanes 0, 1).
@@ -508,7 +517,7 @@ __device__ inline bool stage_body_pool(const DScene &S, uint32_t *pool, int coun
 
 // table clearance of ONE body (ctlp.py:2140-2208)
 __device__ inline bool body_clear(const DScene &S, const BodyPool &BP, int b, const Xf &T, float thr) {
-    const DPiece LP = load_piece_lane(S.pieces, S.link_piece[b]);
+    const DPiece LP = BP.piece(b);
     const LocalHull hull = BP.hull(b);
     bool ok = true;
     if ((S.static_mask >> b) & 1u)
@@ -520,12 +529,11 @@ __device__ inline bool body_clear(const DScene &S, const BodyPool &BP, int b, co
 }
 
 // the self-collision pairs dealt round-robin to the lanes of a group: lane g tests pairs g, g + 8, ... (ctlp.py:2170-2208, 1605-1619)
-__device__ inline bool lane_self_pairs_clear(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], float thr_self) {
+__device__ inline bool lane_self_pairs_clear(const DScene &S, const BodyPool &BP, const Group &G, const Trig &P, float thr_self) {
     bool ok = true;
     for (int i = G.g; i < S.n_self_pairs; i += 8) {
         const int a = S.self_pair[i][0];
-        const DPiece LP = load_piece_lane(S.pieces, S.link_piece[a]);
-        float d = self_pair_distance<true>(S, i, q, LP, BP.hull(a), body_frame(S, q, a), thr_self + 0.005f, 0.f, &BP);
+        float d = self_pair_distance<true>(S, i, nullptr, BP.piece(a), BP.hull(a), body_frame_sc(S, P, a), thr_self + 0.005f, 0.f, &BP, &P);
         if (d <= thr_self + 0.005f && d < thr_self) ok = false;
     }
     return ok;
@@ -535,34 +543,33 @@ __device__ inline bool lane_self_pairs_clear(const DScene &S, const BodyPool &BP
 // capsule / lowest-point shortcuts of piece_distance), then - only if all are clear - the self-collision pairs
 // EXTRA: the scene has bodies beyond the chain and self-collision pairs (ball machine); false compiles that code out
 template <bool EXTRA>
-__device__ inline bool group_table_free(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], float thr, float thr_self) {
+__device__ inline bool group_table_free(const DScene &S, const BodyPool &BP, const Group &G, const Trig &P, float thr, float thr_self) {
     bool ok = true;
-    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear(S, BP, b, body_frame(S, q, b), thr);
+    for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear(S, BP, b, body_frame_sc(S, P, b), thr);
     if (!G.all(ok)) return false;
-    if (EXTRA) return G.all(lane_self_pairs_clear(S, BP, G, q, thr_self));
+    if (EXTRA) return G.all(lane_self_pairs_clear(S, BP, G, P, thr_self));
     return true;
 }
 
-// A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138, for one candidate q.  box / thr: cartesian
+// A17 part 1: _get_collision_free_robot_position, ctlp.py:1980-2138, for one candidate.  box / thr: cartesian
 // range of the end-effector point and minimum table / self distances (start states ctlp.py:172-183,1468-1477; ball
 // targets ctlp.py:191-229,1725-1726,2357).  (The one-physics-step gravity-torque check of ctlp.py:2091-2111 is
 // outside the kinematic path.)  The box first (ctlp.py:2051-2061): one pass down the chain, the same on every lane - about half
 // of the uniformly drawn candidates of a target point end there, before any distance query.
 template <bool EXTRA>
-__device__ inline bool group_pose_valid(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], const float box[3][2], float thr,
+__device__ inline bool group_pose_valid(const DScene &S, const BodyPool &BP, const Group &G, const Trig &P, const float box[3][2], float thr,
                                         float thr_self) {
-    const F3 ee = apply(body_frame(S, q, S.ee_body), F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
+    const F3 ee = apply(body_frame_sc(S, P, S.ee_body), F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
     if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) return false;
-    return group_table_free<EXTRA>(S, BP, G, q, thr, thr_self);
+    return group_table_free<EXTRA>(S, BP, G, P, thr, thr_self);
 }
 
 // Bullet contact between any planet piece and any robot body (Planet.check_if_object_is_colliding, ctlp.py:4570-4579)
 template <bool EXTRA>
-__device__ inline bool group_planet_contact(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS]) {
+__device__ inline bool group_planet_contact(const DScene &S, const BodyPool &BP, const Group &G, const Trig &P, const int idx[SMR_MAX_PLANETS]) {
     bool contact = false;
     for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) {
-        const DPiece LP = load_piece_lane(S.pieces, S.link_piece[b]);
-        const Sample r = collide_link(S, b, LP, BP.hull(b), body_frame(S, q, b), idx, nullptr, false, false, true);
+        const Sample r = collide_link(S, b, BP.piece(b), BP.hull(b), body_frame_sc(S, P, b), idx, nullptr, false, false, true);
         contact = contact || r.contact;
     }
     return G.any(contact);
@@ -570,12 +577,11 @@ __device__ inline bool group_planet_contact(const DScene &S, const BodyPool &BP,
 
 // is the ball (pose XB) within Bullet's contact distance of any robot body? (Ball.check_if_object_is_colliding, ctlp.py:4186-4194)
 template <bool EXTRA>
-__device__ inline bool group_ball_contact(const DScene &S, const BodyPool &BP, const Group &G, const float q[SMR_NJ], const Xf &XB) {
+__device__ inline bool group_ball_contact(const DScene &S, const BodyPool &BP, const Group &G, const Trig &P, const Xf &XB) {
     bool contact = false;
     for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8)
         if ((S.contact_mask >> b) & 1u) {
-            const DPiece LP = load_piece_lane(S.pieces, S.link_piece[b]);
-            float d = piece_distance<false>(S, S.ball_piece, XB, LP, BP.hull(b), body_frame(S, q, b), S.contact_dist, S.contact_dist);
+            float d = piece_distance<false>(S, S.ball_piece, XB, BP.piece(b), BP.hull(b), body_frame_sc(S, P, b), S.contact_dist, S.contact_dist);
             contact = contact || d <= S.contact_dist;
         }
     return G.any(contact);
@@ -770,8 +776,10 @@ struct BallSpawn { float p0[3], v0[3], e0[3], omega; int kmax, khit; };
 
 // _add_moving_object, ctlp.py:1723-1931, by a group of 8 lanes: candidate target poses one after the other, each
 // tested link-parallel; the scalar launch arithmetic is computed redundantly by all lanes, in float64.
+// (forced inline: as a function of its own it would not know that the scene sits in constant memory and the hulls in LDS - every
+// read of either became a per-lane flat load)
 template <bool EXTRA>
-__device__ inline BallSpawn spawn_ball_group(const DScene &S, const BodyPool &BP, const DState &st, const Rng &rng, const Group &G) {
+__device__ __forceinline__ BallSpawn spawn_ball_group(const DScene &S, const BodyPool &BP, const DState &st, const Rng &rng, const Group &G) {
     const int jj = G.g < SMR_NJ ? G.g : 0;
     const double udt = S.dt64 / S.updates_per_step, v = S.ball_speed, grav = 9.81;
     double rel[3] = {0, 0, 0}, vel[3] = {0, 0, 1};
@@ -786,9 +794,10 @@ __device__ inline BallSpawn spawn_ball_group(const DScene &S, const BodyPool &BP
         bool have_target = false;
         for (int tries = 0; tries < 25000; ++tries) {                                                       // ctlp.py:1782-1790
             float q[SMR_NJ];
-            G.gather(rng.uniform(S_BALL_POSE, 7u * pose_attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
+            const float qme = rng.uniform(S_BALL_POSE, 7u * pose_attempt + jj, S.pos_lo[jj], S.pos_hi[jj]);
+            G.gather(qme, q);
             ++pose_attempt;
-            if (group_pose_valid<EXTRA>(S, BP, G, q, S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); have_target = true; break; }
+            if (group_pose_valid<EXTRA>(S, BP, G, G.trig(qme), S.ball_target_box, S.ball_target_min_static, S.ball_target_min_self)) { ee_point_f64(S, q, target); have_target = true; break; }
         }
         if (!have_target) { if (G.g == 0) sampling_exhausted(st, kSamplingBallTarget); break; }            // ctlp.py:2127-2136 raises
         const double dx = target[0] - rel[0], dy = target[1] - rel[1], dh = target[2] - rel[2];
@@ -941,16 +950,14 @@ __global__ SMR_SIDE_KERNEL void spawn_kernel(const DScene *__restrict__ Sp, DSta
     bs.omega = b.omega;
     int k0 = 0;
     if (is_reset && S.ball_random_initial) {
-        float q[SMR_NJ];
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) q[j] = st.q[j * B + e];
+        const Trig P = G.trig(st.q[(g < SMR_NJ ? g : 0) * B + e]);
         int kcap = b.kmax < b.khit ? b.kmax : b.khit;
         int max_ts = kcap / S.updates_per_step;
         if (max_ts < 0) max_ts = 0;
         bool free_step = false;
         for (unsigned n = 0; n < 100000u && !free_step; ++n) {
             k0 = rng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
-            free_step = !group_ball_contact<EXTRA>(S, BP, G, q, ball_pose(S, bs, k0, nullptr));
+            free_step = !group_ball_contact<EXTRA>(S, BP, G, P, ball_pose(S, bs, k0, nullptr));
         }
         if (!free_step && g == 0) sampling_exhausted(st, kSamplingBallInitialStep);
     }
@@ -989,8 +996,9 @@ __global__ SMR_SIDE_KERNEL void target_kernel(const DScene *__restrict__ Sp, DSt
     bool found = false;
     SMR_PHASE_INIT;
     for (unsigned m = 0; m < 100000u && !found; ++m) {
-        G.gather(rng.uniform(S_TARGET, 7u * m + jj, S.pos_lo[jj], S.pos_hi[jj]), q);
-        found = group_pose_valid<EXTRA>(S, BP, G, q, S.ball_target_box, S.target_min_static, S.target_min_self);
+        const float qme = rng.uniform(S_TARGET, 7u * m + jj, S.pos_lo[jj], S.pos_hi[jj]);
+        G.gather(qme, q);
+        found = group_pose_valid<EXTRA>(S, BP, G, G.trig(qme), S.ball_target_box, S.target_min_static, S.target_min_self);
     }
     SMR_PHASE(6);
     if (!found && g == 0) sampling_exhausted(st, kSamplingTargetPoint);                                   // ctlp.py:2127-2136 raises
@@ -1057,9 +1065,10 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
     unsigned attempt = 0;
     auto next_position = [&]() {
         for (int tries = 0; tries < 100000; ++tries) {
-            G.gather(rng.uniform(S_POS, 7u * attempt + jj, S.pos_lo[jj], S.pos_hi[jj]), q);               // ctlp.py:2035-2037
+            const float qme = rng.uniform(S_POS, 7u * attempt + jj, S.pos_lo[jj], S.pos_hi[jj]);          // ctlp.py:2035-2037
+            G.gather(qme, q);
             ++attempt;
-            if (group_pose_valid<EXTRA>(S, BP, G, q, S.start_box, S.start_min_static, S.start_min_self)) return;
+            if (group_pose_valid<EXTRA>(S, BP, G, G.trig(qme), S.start_box, S.start_min_static, S.start_min_self)) return;
         }
         if (g == 0) sampling_exhausted(st, kSamplingStart);                                               // ctlp.py:2127-2136 raises
     };
@@ -1109,9 +1118,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
             w += SMR_NJ;
             const float na = lo + 0.5f * (u + 1.f) * (hi - lo);
             const float nv = interp_vel(cv, ca, na, S.dt, S.dt), nq = interp_pos(cq, cv, ca, na, S.dt, S.dt);
-            float nqv[SMR_NJ];
-            G.gather(nq, nqv);
-            if (group_table_free<EXTRA>(S, BP, G, nqv, S.start_min_static, S.start_min_self)) {
+            if (group_table_free<EXTRA>(S, BP, G, G.trig(nq), S.start_min_static, S.start_min_self)) {
                 if (nxt == 0) { hq0 = nq; hv0 = nv; ha0 = na; } else if (nxt == 1) { hq1 = nq; hv1 = nv; ha1 = na; } else { hq2 = nq; hv2 = nv; ha2 = na; }
                 ++cnt;
             } else {
@@ -1128,6 +1135,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
     }
 
     SMR_PHASE(1);
+    const Trig P = G.trig(qj);            // the start configuration
     // ---- planet phase: candidate phases in sequence, first contact-free one wins (ctlp.py:4470-4501)
     int idx[SMR_MAX_PLANETS] = {0, 0};
     int hit = 0;
@@ -1145,7 +1153,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
                 if (S.planet[p].coupled) idx[p] = ((idx[0] + S.planet[p].index_shift) % no + no) % no;
                 else idx[p] = rng.randint(S_PLANET, n * (unsigned)n_indep + (unsigned)(k++), no);
             }
-            free_phase = !group_planet_contact<EXTRA>(S, BP, G, q, idx);
+            free_phase = !group_planet_contact<EXTRA>(S, BP, G, P, idx);
         }
         if (!free_phase && g == 0) sampling_exhausted(st, kSamplingPlanetPhase);                          // the reference loops on (ctlp.py:4477-4490)
         // obstacle_wrapper.update(update_after_reset=True): one planet update + contact check,
@@ -1153,7 +1161,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (idx[p] + 1) % S.planet[p].n_orbit;
-        if (S.term_moving) hit = group_planet_contact<EXTRA>(S, BP, G, q, idx) ? 1 : 0;
+        if (S.term_moving) hit = group_planet_contact<EXTRA>(S, BP, G, P, idx) ? 1 : 0;
     }
 
     SMR_PHASE(2);
@@ -1181,7 +1189,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
             bool free_step = false;
             for (unsigned n = 0; n < 100000u && !free_step; ++n) {
                 ball_k0 = brng.randint(S_BALL_MISC, 1u + n, max_ts + 1) * S.updates_per_step;
-                free_step = !group_ball_contact<EXTRA>(S, BP, G, q, ball_pose(S, bs, ball_k0, nullptr));
+                free_step = !group_ball_contact<EXTRA>(S, BP, G, P, ball_pose(S, bs, ball_k0, nullptr));
             }
             if (!free_step && g == 0) sampling_exhausted(st, kSamplingBallInitialStep);
         }

@@ -25,16 +25,19 @@ struct HostGeometry {
     std::vector<float> auto_desc;   // ... and their descriptors
 };
 
-// image of the LDS pool of the reset-side kernels: kBodyPoolHead dwords per body (offsets of its vertices / id groups / start map),
-// then every body's tables as the global ones hold them.  Returns false when they do not fit.
+// image of the LDS pool of the reset-side kernels: kBodyPoolHead dwords per body (offsets of its vertices / id groups / start map /
+// DPiece), then every body's tables as the global ones hold them.  Returns false when they do not fit.
 inline bool body_pool_tables(const smr_scene_t &s, const HostGeometry &G, std::vector<uint32_t> &pool) {
     pool.assign((size_t)kBodyPoolHead * SMR_MAX_BODIES, 0u);
     for (int b = 0; b < s.n_bodies; ++b) {
         const int piece = s.link_piece[b];
         const DPiece &P = G.pieces[piece];
         const uint32_t v_off = (uint32_t)pool.size(), ids_off = v_off + 4u * (uint32_t)P.count, start_off = ids_off + (uint32_t)P.ids_count;
+        const uint32_t piece_off = start_off + kStartCells / 4;
         pool[(size_t)kBodyPoolHead * b] = v_off; pool[(size_t)kBodyPoolHead * b + 1] = ids_off; pool[(size_t)kBodyPoolHead * b + 2] = start_off;
-        pool.resize((size_t)start_off + kStartCells / 4);
+        pool[(size_t)kBodyPoolHead * b + 3] = piece_off;
+        pool.resize((size_t)piece_off + kPieceDwords);
+        std::memcpy(pool.data() + piece_off, &P, 4 * kPieceDwords);
         std::memcpy(pool.data() + v_off, G.verts.data() + P.begin, 16 * (size_t)P.count);
         std::memcpy(pool.data() + ids_off, G.ids4.data() + P.ids_begin, 4 * (size_t)P.ids_count);
         std::memcpy(pool.data() + start_off, G.start.data() + (size_t)kStartCells * piece, kStartCells);
