@@ -19,6 +19,11 @@
 #define SMR_CNT(i)            // work counters of the host emulation build (tests/host_emul)
 #define SMR_CNT_SLOT(i)
 #endif
+#ifndef SMR_DEV_COUNT         // cycle / count slots of the profiling build (smr_hip.hip, SMR_PROFILE_ROWS)
+#define SMR_DEV_CLOCK() 0ull
+#define SMR_DEV_COUNT(i, n)
+#define SMR_WAVE_REC(f, n)
+#endif
 
 namespace smr {
 
@@ -1425,7 +1430,9 @@ __device__ inline void planet_gjk(const DScene &S, const float *pv, const float 
         bp = {av[4 * bi], av[4 * bi + 1], av[4 * bi + 2]};
         return apply(XA, bp);
     };
+    int prof_trips = 0;
     for (int trip = 0; trip < 33 * kMaxPlanetPieces; ++trip) {
+        ++prof_trips;
         if (!active && !finished) {
             con_cur = want_contact && !out.contact;
             float cutoff = mov ? fminf(out.d_moving, moving_max) : S.contact_dist;
@@ -1466,6 +1473,7 @@ __device__ inline void planet_gjk(const DScene &S, const float *pv, const float 
             }
         }
     }
+    SMR_WAVE_REC(3, prof_trips); (void)prof_trips;
 }
 
 
@@ -1609,12 +1617,17 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
 #pragma unroll
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (in.planet_idx[p] + N * upd) % S.planet[p].n_orbit;
+        const unsigned long long c0 = SMR_DEV_CLOCK();
         r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, nullptr, AUTO);
         if (AUTO) {
             float cutoff_max = want_moving ? S.moving_max : S.contact_dist;
             if (want_contact) cutoff_max = fmaxf(cutoff_max, S.contact_dist);
+            const unsigned long long c1 = SMR_DEV_CLOCK();
             lb = planet_keys(S, keys, kstride, LP, T, idx, want_moving || want_contact, cutoff_max);
+            const unsigned long long c2 = SMR_DEV_CLOCK();
             planet_gjk(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, want_contact, S.moving_max, r);
+            SMR_DEV_COUNT(16, c1 - c0); SMR_DEV_COUNT(17, c2 - c1); SMR_DEV_COUNT(18, SMR_DEV_CLOCK() - c2);
+            SMR_WAVE_REC(0, (c1 - c0) >> 4); SMR_WAVE_REC(1, (c2 - c1) >> 4); SMR_WAVE_REC(2, (SMR_DEV_CLOCK() - c2) >> 4);
             if (!(want_moving || want_contact)) lb = -1.f;
         } else if (sweep_contact && N > 1) {
             lb = planets_lower_bound(S, LP, T, idx, S.moving_max);

@@ -19,6 +19,18 @@
 #include <string>
 #include <vector>
 
+#ifdef SMR_PROFILE_ROWS
+// profiling build (scripts/profile_rows.py, profile_blocks.py): cycle / count slots the device code adds to - [i]: sum, [64 + i]:
+// number of additions; slots 0..31: wavefront cycles per grid row of the collide kernel, 32..63: phases and counts (the first
+// active lane of a wavefront adds) - and a record per wavefront of the collide kernel (g_wave_rec)
+__device__ unsigned long long g_row_cycles[128];
+__device__ unsigned g_wave_rec[8 * 65536];
+#define SMR_DEV_CLOCK() __builtin_readcyclecounter()
+#define SMR_DEV_COUNT(i, n) do { if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) { atomicAdd(&g_row_cycles[32 + (i)], (unsigned long long)(n)); atomicAdd(&g_row_cycles[96 + (i)], 1ull); } } while (0)
+// field f (0..7) of this wavefront's record
+#define SMR_WAVE_REC(f, n) do { const unsigned w_ = ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
+                                if (w_ < 65536u && (int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) g_wave_rec[8 * w_ + (f)] += (unsigned)(n); } while (0)
+#endif
 #include "smr_device.h"
 #include "smr_tables.h"
 #include "smr_mlp.h"
@@ -47,7 +59,6 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
 
 #ifdef SMR_PROFILE_ROWS
 // profiling build (scripts/profile_rows.py): shader-clock cycles of the collide kernel's wavefronts, summed per grid row
-__device__ unsigned long long g_row_cycles[128];       // [row]: cycles, [64 + row]: wavefronts
 struct RowClock {
     unsigned long long t0;
     int row;
@@ -61,7 +72,23 @@ extern "C" int smr_debug_row_cycles(unsigned long long *out, int reset) {
     if (reset) { unsigned long long z[128] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_row_cycles), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
-#define SMR_ROW_CLOCK(r) RowClock row_clock_(r)
+// ... and the schedule of the collide kernel's blocks: real-time clock (100 MHz, the same on every XCD) at the start and the end
+__device__ unsigned long long g_block_times[2 * 16384];
+struct BlockClock {
+    unsigned long long t0;
+    __device__ BlockClock() : t0(wall_clock64()) {}
+    __device__ ~BlockClock() {
+        const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+        if (threadIdx.x == 0 && id < 16384u) { g_block_times[2 * id] = t0; g_block_times[2 * id + 1] = wall_clock64(); }
+    }
+};
+extern "C" int smr_debug_block_times(unsigned long long *out, unsigned *wave_rec, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_times), sizeof(unsigned long long) * 2 * 16384) != hipSuccess) return -1;
+    if (wave_rec && hipMemcpyFromSymbol(wave_rec, HIP_SYMBOL(g_wave_rec), sizeof(unsigned) * 8 * 65536) != hipSuccess) return -1;
+    if (reset) { void *p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wave_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * 8 * 65536) != hipSuccess) return -1; }
+    return 0;
+}
+#define SMR_ROW_CLOCK(r) RowClock row_clock_(r); BlockClock block_clock_
 // ... and of the phases of the reset-side kernels: slots 32 + phase (first active lane of the wavefront)
 struct PhaseClock {
     unsigned long long t;
@@ -196,6 +223,9 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
         if (N > 1) st.lb_moving[(size_t)l * B + e] = r.lb_end;
     }
     bool contact = r.contact;
+#ifdef SMR_PROFILE_ROWS
+    const unsigned long long items_t0 = SMR_DEV_CLOCK();
+#endif
     if (N > 1) {
         // The samples k_first .. k_need of every lane become work items of its WAVEFRONT: a queue in LDS (source lane, sample),
         // worked off 64 items at a time by all lanes - dense rounds, however unevenly the items are spread over the lanes.
@@ -237,6 +267,9 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
             contact = contact || lds_hit[threadIdx.x] != 0u;
         }
     }
+#ifdef SMR_PROFILE_ROWS
+    SMR_WAVE_REC(4, (SMR_DEV_CLOCK() - items_t0) >> 4);
+#endif
     if (valid) st.res[(size_t)l * B + e] = contact ? 1.f : 0.f;
 }
 
@@ -1022,12 +1055,14 @@ __global__ SMR_SIDE_KERNEL void target_kernel(const DScene *__restrict__ Sp, DSt
     }
 }
 
-// every n-th 8-lane group works (tuning knob SMR_RESET_GROUP_STRIDE: 1, 2, 4 or 8).  On the critical path (synchronous reset)
-// sparse wavefronts finish soonest: 4.  The staged refill runs beside the step kernels and competes with them for vector
-// issue, where denser wavefronts cost fewer instructions: 2 (measured: 74.7M -> 76.1M env-steps/s).
+// every n-th 8-lane group works (tuning knob SMR_RESET_GROUP_STRIDE: 1, 2, 4 or 8).  Sparse wavefronts end sooner (a wavefront
+// runs as long as the group with the most rejected candidates), dense ones are fewer: since every block stages the bodies' hulls
+// in LDS and a wavefront holds half a SIMD's registers, fewer wins - measured at 65 536 envs with stride 1 / 2 / 4: space 82.0 /
+// 79.3 / 75.6, reaching task 75.9 / 68.6 / 62.7, ball + ball machine 65.7 / 56.9 / 45.7 M env-steps/s.
 static int reset_group_stride(bool staged = false) {
     static const int v = [] { const char *e = std::getenv("SMR_RESET_GROUP_STRIDE"); int x = e ? std::atoi(e) : 0; return (x == 1 || x == 2 || x == 4 || x == 8) ? x : 0; }();
-    return v ? v : (staged ? 2 : 4);
+    (void)staged;
+    return v ? v : 1;
 }
 
 // env.reset() for the envs in list[0..count): obs.py:144-149 -> base.py:913-1022.
