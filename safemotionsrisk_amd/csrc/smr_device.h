@@ -103,6 +103,7 @@ struct DScene {
     // in LDS for the lane-autonomous planet queries (planets_auto = 0: does not fit, wave-lockstep queries)
     int planets_auto, planet_p0, planet_pn, planet_vn;   // planet_vn: vertex slots of auto_verts (4 floats each)
     int body_order[SMR_MAX_BODIES];   // dispatch order of the bodies in the collide grid (longest-running first)
+    int pair_order[SMR_MAX_SELF_PAIRS];   // ... and of the self-collision pairs behind them
     // conservative advancement over the intermediate contact samples (contact sweep, below): no point of body b moves faster than
     // sum_j |qdot_j| sweep_R[b][j]; no point of planet p moves farther than planet_step[p] per orbit index; the ball stays inside
     // the sphere of radius ball_bound_radius (margin included) about its frame origin

@@ -128,15 +128,14 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     const DScene &S = *Sp;
     constexpr int kBlock = AUTO ? 256 : 64;
     SMR_ROW_CLOCK((int)blockIdx.y);
-    // grid y: first the self-collision pairs (SELF; they only work at the end-of-step sample), then the bodies, outer ones
-    // (most planet work) first
-    const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
-    const bool pair_block = SELF && (int)blockIdx.y < n_pair_blocks;
-    const int pair = pair_block ? (int)blockIdx.y : 0;
+    // grid y: first the bodies, outer ones (most planet work, the longest blocks) leading, then the self-collision pairs (SELF; they
+    // only work at the end-of-step sample), the ones with the nearest partners first: short blocks that fill the gaps at the end
+    const bool pair_block = SELF && (int)blockIdx.y >= S.n_bodies;
+    const int pair = pair_block ? S.pair_order[(int)blockIdx.y - S.n_bodies] : 0;
     // the body whose hull this block climbs over: its own body, or for a pair block the partner link (the ball machine
     // piece is then the scanned A side; with the base adapter as partner the piece itself is staged)
     const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0])
-                             : S.body_order[(int)blockIdx.y - n_pair_blocks];
+                             : S.body_order[(int)blockIdx.y];
     const int B = S.B, N = S.checks_per_step, NB = S.n_bodies;
     if (!pair_block) {                                   // nothing to do for this body: leave before anything is staged
         const bool any = (((S.static_mask | S.moving_mask | S.contact_mask) >> l) & 1u) || SELF;
@@ -679,7 +678,7 @@ __global__ __launch_bounds__(256) void brake_check_kernel(const DScene *__restri
     constexpr int kBlock = 256;
     const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
     const bool pair_block = SELF && (int)blockIdx.y < n_pair_blocks;
-    const int pair = pair_block ? (int)blockIdx.y : 0;
+    const int pair = pair_block ? S.pair_order[(int)blockIdx.y] : 0;                       // the pairs with the nearest partners (longest blocks) first
     const int body = pair_block ? S.self_pair[pair][0] : S.body_order[(int)blockIdx.y - n_pair_blocks];
     const int partner = pair_block ? S.self_pair[pair][1] : -1;
     const int l = pair_block ? (partner >= 0 ? partner : body) : body;                    // the body whose hull is staged (see collide_kernel)
@@ -1550,6 +1549,12 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
             const int chain[SMR_NLINK] = {5, 6, 4, 7, 3, 2, 1, 0};
             for (int i = 0; i < SMR_NLINK; ++i) if ((((d.moving_mask >> chain[i]) & 1u) != 0) == want_moving) d.body_order[n++] = chain[i];
         }
+    }
+    {   // ... and of the self-collision pairs: highest partner link (nearest to the mounted bodies) first, the world-fixed piece last
+        std::vector<int> order(d.n_self_pairs);
+        for (int i = 0; i < d.n_self_pairs; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d.self_pair[a][1] > d.self_pair[b][1]; });
+        for (int i = 0; i < d.n_self_pairs; ++i) d.pair_order[i] = order[i];
     }
     if (const char *v = getenv("SMR_BODY_ORDER")) {                                          // experiment: e.g. 54367210
         int n = 0;

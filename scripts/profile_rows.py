@@ -51,7 +51,7 @@ def main():
         if r >= 32:
             print("  %-32s %8.2f M cycles  %8.0f cycles per wave, %6.0f waves per step" % (phases.get(r, "phase %d" % r), cyc[r] / 1e6, cyc[r] / waves[r], waves[r]))
             continue
-        what = "pair %d (%d, %d)" % (r, s.self_pair[r][0], s.self_pair[r][1]) if r < n_pairs else "body row %d" % (r - n_pairs)
+        what = "body row %d" % r if r < s.n_bodies else "pair row %d" % (r - s.n_bodies)       # pairs: nearest partner first
         print("  row %2d %-18s %8.2f M cycles %5.1f%%  %6.0f cycles per wave" % (r, what, cyc[r] / 1e6, 100 * cyc[r] / total, cyc[r] / waves[r]))
 
 
