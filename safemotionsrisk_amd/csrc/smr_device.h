@@ -844,10 +844,14 @@ __device__ inline bool simplex_solve(F3 &w0, F3 &w1, F3 &w2, F3 &w3, int &n, F3 
 // sb(dir, hint, first) (hint: a per-run integer the mapping may use as a warm start; first: first call of the run),
 // margins excluded, started from the point v of A - B.  Returns a lower bound > cutoff as soon as one is proven, and
 // the current upper bound as soon as it drops below stop_below (callers only test it against a threshold then).
+// warm (trajectory walks that query the same pair again and again): in - when non-zero - the start direction instead of v (any
+// direction will do: before the first simplex point is in, v only serves as the direction of the first support call), out the
+// vector the run ended with, i.e. the direction of the closest points
 template <class SA, class SB>
-__device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff, float stop_below) {
+__device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff, float stop_below, F3 *warm = nullptr) {
     F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
     int n = 0, hint_a = 0, hint_b = 0, stalls = 0;
+    if (warm && dot(*warm, *warm) > 0.f) v = *warm;
     float vv = dot(v, v);
     const float cutoff2 = cutoff * cutoff, stop2 = stop_below > 0.f ? stop_below * stop_below : 0.f;
     SMR_CNT(2);
@@ -859,7 +863,7 @@ __device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff,
 #ifdef SMR_HOST_EMUL_TRACE
         printf("  it %d n %d vv %.9g vw %.9g v=(%.7g %.7g %.7g) w=(%.7g %.7g %.7g)\n", it, n, vv, vw, v.x, v.y, v.z, w.x, w.y, w.z);
 #endif
-        if (vw > 0.f && vw * vw > cutoff2 * vv) return (vw / sqrtf(vv));     // separating plane farther than cutoff
+        if (vw > 0.f && vw * vw > cutoff2 * vv) { if (warm) *warm = v; return (vw / sqrtf(vv)); }     // separating plane farther than cutoff
         if (n > 0 && (vv - vw) <= 1e-6f * vv) break;                         // converged
         // the support point is already a simplex vertex: v is optimal up to rounding (in exact arithmetic
         // v.w == v.v then; in float32 the test above can miss it and a duplicate vertex would make the
@@ -890,6 +894,7 @@ __device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff,
         if (vv <= stop2) break;
         if (n == 4) return 0.f;
     }
+    if (warm) *warm = v;
     return sqrtf(vv);
 }
 
@@ -971,9 +976,10 @@ __device__ __forceinline__ float seg_seg_dist2(F3 p1, F3 q1, F3 p2, F3 q2) {
 // The same loop as gjk_core, written out: routed through gjk_core's callables the step kernel was 10 % slower (measured).
 template <bool IDENTITY, class HB>
 __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece &A, const Xf &XA, const HB &hb,
-                                     const Xf &XB, F3 v, float cutoff, float stop_below) {
+                                     const Xf &XB, F3 v, float cutoff, float stop_below, F3 *warm = nullptr) {
     F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
     int n = 0, hint = 0, stalls = 0;
+    if (warm && dot(*warm, *warm) > 0.f) v = *warm;      // see gjk_core
     float vv = dot(v, v);
     const float cutoff2 = cutoff * cutoff, stop2 = stop_below > 0.f ? stop_below * stop_below : 0.f;
     SMR_CNT(2);
@@ -982,7 +988,7 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
         SMR_CNT(4);
         F3 w = support<IDENTITY>(verts, A.begin, A.count, XA, neg(v)) - apply(XB, hb.support(rot_t(XB, v), hint, it == 0));
         float vw = dot(v, w);
-        if (vw > 0.f && vw * vw > cutoff2 * vv) return (vw / sqrtf(vv));
+        if (vw > 0.f && vw * vw > cutoff2 * vv) { if (warm) *warm = v; return (vw / sqrtf(vv)); }
         if (n > 0 && (vv - vw) <= 1e-6f * vv) break;
         {
             F3 e0 = w - w0, e1 = w - w1, e2 = w - w2;
@@ -1004,6 +1010,7 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
         if (vv <= stop2) break;
         if (n == 4) return 0.f;
     }
+    if (warm) *warm = v;
     return sqrtf(vv);
 }
 
@@ -1011,7 +1018,7 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
 // > cutoff when they are farther apart than cutoff (ctlp.py:2915-2931: no closest point returned)
 template <bool IDENTITY, class HB>
 __device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, const DPiece &B, const HB &hb, const Xf &XB,
-                                       float cutoff, float stop_below) {
+                                       float cutoff, float stop_below, F3 *warm = nullptr) {
     const DPiece A = load_piece(S.pieces, pa);
     const float margins = A.margin + B.margin;
     F3 cb = apply(XB, F3{B.cx, B.cy, B.cz});
@@ -1044,7 +1051,7 @@ __device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, co
         const F3 low = apply(XB, hb.support(rot_t(XB, F3{0.f, 0.f, -1.f}), hint, true));
         if (low.x >= A.bx0 && low.x <= A.bx1 && low.y >= A.by0 && low.y <= A.by1 && low.z >= A.btop) return (low.z - A.btop) - margins;
     }
-    return gjk_distance<IDENTITY>((const SMR_CONST float *)S.verts, A, XA, hb, XB, d, cutoff + margins, stop_below + margins) - margins;
+    return gjk_distance<IDENTITY>((const SMR_CONST float *)S.verts, A, XA, hb, XB, d, cutoff + margins, stop_below + margins, warm) - margins;
 }
 
 __device__ __forceinline__ Xf planet_pose(const DScene &S, int p, int idx) {
@@ -1099,7 +1106,8 @@ __device__ inline Xf body_frame_sc(const DScene &S, const Trig &P, int b) {
 // from the configuration's sines and cosines.
 template <bool LANE = false, class HB>
 __device__ inline float self_pair_distance(const DScene &S, int i, const float q[SMR_NJ], const DPiece &LP, const HB &hull,
-                                           const Xf &T, float cutoff, float stop_below, const BodyPool *bodies = nullptr, const Trig *trig = nullptr) {
+                                           const Xf &T, float cutoff, float stop_below, const BodyPool *bodies = nullptr, const Trig *trig = nullptr,
+                                           F3 *warm = nullptr) {
     const int partner = S.self_pair[i][1];
     const int pa = partner >= 0 ? S.link_piece[partner] : -(partner + 1);
     const DPiece A = LANE ? load_piece_lane(S.pieces, pa) : load_piece(S.pieces, pa);
@@ -1124,7 +1132,7 @@ __device__ inline float self_pair_distance(const DScene &S, int i, const float q
         }
         const GlobalHull ha = global_hull(S, pa, A);
         const auto sa = [&](F3 dd, int &hint, bool first) { return apply(XA, ha.support(rot_t(XA, dd), hint, first)); };
-        return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins) - margins;
+        return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins, warm) - margins;
     }
     const F3 d = F3{A.cx, A.cy, A.cz} - cb;
     const float lb = sqrtf(dot(d, d)) - A.radius - LP.radius - margins;
@@ -1135,7 +1143,7 @@ __device__ inline float self_pair_distance(const DScene &S, int i, const float q
         p.z += dd.z < 0.f ? -A.cyl_h : A.cyl_h;
         return p;
     };
-    return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins) - margins;
+    return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins, warm) - margins;
 }
 
 __device__ inline Sample collide_sample(const DScene &S, const float q[SMR_NJ], const int idx[SMR_MAX_PLANETS],

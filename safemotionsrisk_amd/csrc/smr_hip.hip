@@ -88,7 +88,13 @@ extern "C" int smr_debug_block_times(unsigned long long *out, unsigned *wave_rec
     if (reset) { void *p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_wave_rec)) != hipSuccess || hipMemset(p, 0, sizeof(unsigned) * 8 * 65536) != hipSuccess) return -1; }
     return 0;
 }
+#ifdef SMR_PROFILE_BRAKE      // the same records for the brake_check kernel instead
+#define SMR_ROW_CLOCK(r)
+#define SMR_BRAKE_ROW_CLOCK(r) RowClock row_clock_(r); BlockClock block_clock_
+#else
 #define SMR_ROW_CLOCK(r) RowClock row_clock_(r); BlockClock block_clock_
+#define SMR_BRAKE_ROW_CLOCK(r)
+#endif
 // ... and of the phases of the reset-side kernels: slots 32 + phase (first active lane of the wavefront)
 struct PhaseClock {
     unsigned long long t;
@@ -103,6 +109,7 @@ struct PhaseClock {
 #define SMR_PHASE(i) phase_clock_.mark(i)
 #else
 #define SMR_ROW_CLOCK(r)
+#define SMR_BRAKE_ROW_CLOCK(r)
 #define SMR_PHASE_INIT
 #define SMR_PHASE(i)
 #endif
@@ -672,10 +679,14 @@ __global__ __launch_bounds__(256) void brake_plan_kernel(const DScene *__restric
 // (get_minimum_distance with check_safety_distance, ctlp.py:3282-3374) -> braked[env] = 1.  A sample is only evaluated when the joints
 // have moved far enough since the last evaluation to use up the clearance found there (every value piece_distance returns is a
 // lower bound of the distance; joint travel x lever arms bounds the motion of the body's points).
+#ifndef SMR_BRAKE_WAVES
+#define SMR_BRAKE_WAVES 4        // wavefronts per SIMD (512 / SMR_BRAKE_WAVES registers each): the blocks are short and many
+#endif
 template <bool SELF>
-__global__ __launch_bounds__(256) void brake_check_kernel(const DScene *__restrict__ Sp, DState st) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_WAVES, SMR_BRAKE_WAVES))) void brake_check_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = 256;
+    SMR_BRAKE_ROW_CLOCK((int)blockIdx.y);
     const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
     const bool pair_block = SELF && (int)blockIdx.y < n_pair_blocks;
     const int pair = pair_block ? S.pair_order[(int)blockIdx.y] : 0;                       // the pairs with the nearest partners (longest blocks) first
@@ -716,6 +727,9 @@ __global__ __launch_bounds__(256) void brake_check_kernel(const DScene *__restri
     for (int j = 0; j < SMR_NJ; ++j) lever[j] = (partner >= 0 && j < partner) ? 0.f : S.sweep_R[body][j];
     const float thr = S.brake_safety;
     float margin = -1.f;                                 // clearance beyond the safety distance found at q_ref (< 0: nothing evaluated yet)
+    // consecutive evaluations look at nearly the same configuration: each GJK run starts in the direction the last one ended with
+    // (world frame; the first support points then already span the closest feature)
+    F3 warm = {0.f, 0.f, 0.f};
     for (int m = 0; m <= steps; ++m) {
         for (int sidx = 1; sidx <= S.brake_checks; ++sidx) {                              // linspace(dt / Nb, dt, Nb), ctlp.py:3167-3169
             const float t = sidx == S.brake_checks ? S.dt : S.dt * (float)sidx / (float)S.brake_checks;
@@ -734,12 +748,13 @@ __global__ __launch_bounds__(256) void brake_check_kernel(const DScene *__restri
                 }
                 if (partner >= link_a) Tp = body_frame(S, qs, partner);
                 if (body >= SMR_NLINK) Ta = mounted_frame(S, body, Ta);
-                if (partner >= 0) d = piece_distance<false>(S, S.link_piece[body], Ta, LP, hull, Tp, S.static_max, thr);
-                else d = self_pair_distance(S, pair, qs, LP, hull, Ta, S.static_max, thr);
+                if (partner >= 0) d = piece_distance<false>(S, S.link_piece[body], Ta, LP, hull, Tp, S.static_max, thr, &warm);
+                else d = self_pair_distance(S, pair, qs, LP, hull, Ta, S.static_max, thr, nullptr, nullptr, &warm);
             } else {
                 const Xf T = body_frame(S, qs, body);
                 d = 3.0e38f;
-                for (int sp = 0; sp < S.n_static; ++sp) d = fminf(d, piece_distance<true>(S, S.static_piece[sp], T, LP, hull, T, S.static_max, thr));
+                for (int sp = 0; sp < S.n_static; ++sp)
+                    d = fminf(d, piece_distance<true>(S, S.static_piece[sp], T, LP, hull, T, S.static_max, thr, S.n_static == 1 ? &warm : nullptr));
             }
             if (d < thr) { st.braked[e] = 1; return; }                                    // ctlp.py:3307-3312,3364-3368; several lanes of an env may write the same 1
             margin = d - thr - 1e-5f;
