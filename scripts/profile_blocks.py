@@ -53,6 +53,10 @@ def main():
     for a, b in zip(edges[:-1], edges[1:]):
         mid = 0.5 * (a + b)
         print("  t = %7.1f us: %5d blocks running" % (mid, int(((t[:, 0] <= mid) & (t[:, 1] > mid)).sum())))
+    heavy = rec[:4 * 5 * nbx]            # the wavefronts of the first five rows
+    print("  contact items per wavefront (first five rows): mean %.1f, p90 %.0f, max %.0f; of them past the bound test: mean %.1f, max %.0f"
+          % (heavy[:, 5].mean(), np.percentile(heavy[:, 5], 90), heavy[:, 5].max(), heavy[:, 6].mean(), heavy[:, 6].max()))
+    print("  per wavefront of those rows, mean us: static %.1f, keys %.1f, planet runs %.1f, items %.1f" % tuple(heavy[:, i].mean() * 16 / 2400.0 for i in (0, 1, 2, 4)))
     k = 16 / 2400.0                      # record unit (16 cycles) -> microseconds at 2.4 GHz
     print("  wavefront records (us at 2.4 GHz: static, planet keys, planet runs, contact items; trips of the planet-run loop):")
     order = np.argsort(-dur)
