@@ -261,6 +261,7 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+            SMR_WAVE_REC(5, total); SMR_WAVE_REC(6, pending);
             // ... and get the real test, again 64 at a time
             for (int base = 0; base < pending; base += 64) {
                 const bool live = base + lane < pending;
