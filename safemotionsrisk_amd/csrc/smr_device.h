@@ -495,6 +495,39 @@ __device__ inline void safe_acc_range_joint(const JointLim &L, float p, float v,
     }
 }
 
+// Only the violation code of safe_acc_range_joint (0: the state is feasible) - what the kinematic start-state sampling asks for on
+// every one of its velocity / acceleration tries (ctlp.py:1499-1545).  The code needs no range end: whether a position bracket is
+// open (the margin at the far end of the velocity interval), and whether it is infeasible (the margin at its near end - the point
+// the root finder evaluates first), are single margin evaluations.  Only a lane with BOTH brackets open needs the ends themselves
+// (lo > hi), and gets them from the full routine.  Same arithmetic, same code.  All W lanes of a segment must call together.
+template <int W>
+__device__ inline int safe_state_code(const JointLim &L, float p, float v, float a, bool want = true) {
+    const float D = L.J * L.dt;
+    float blo = fmaxf(-L.A, a - D), bhi = fminf(L.A, a + D);
+    if (blo > bhi) blo = bhi = fminf(fmaxf(a, -L.A), L.A);
+    const float vtol = 1e-5f * L.V, vrep = 3e-5f * L.V;
+    const float ptol = 1e-6f * (L.phi - L.plo), prep = 4e-6f * (L.phi - L.plo);
+    int code = 0;
+    float uv = vel_upper_a1max(v, a, L.V, vtol, L), lv = -vel_upper_a1max(-v, -a, L.V, vtol, L);
+    if (uv < blo) { if (vel_upper_a1max(v, a, L.V, vrep, L) < blo) code |= 1; uv = blo; }
+    if (lv > bhi) { if (-vel_upper_a1max(-v, -a, L.V, vrep, L) > bhi) code |= 1; lv = bhi; }
+    float vlo = fmaxf(blo, lv), vhi = fminf(bhi, uv);
+    if (vlo > vhi) { code |= 4; vlo = vhi = 0.5f * (vlo + vhi); }
+    const float gap_hi = (L.phi - p) + L.phi_res, gap_lo = (p - L.plo) - L.plo_res;
+    const bool need_up = want && pos_margin(gap_hi + ptol, v, a, vhi, vtol, L) < 0.f;
+    const bool need_dn = want && pos_margin(gap_lo + ptol, -v, -a, -vlo, vtol, L) < 0.f;
+    const bool both = need_up && need_dn;
+    if (__any(both)) {                                    // rare: the ends decide
+        float lo, hi;
+        int full;
+        safe_acc_range_joint<W>(L, p, v, a, lo, hi, full, both);
+        if (both) return full;
+    }
+    if (need_up && pos_margin(gap_hi + ptol, v, a, vlo, vtol, L) < 0.f && !pos_upper_ok(gap_hi + prep, v, a, vlo, vtol, L)) code |= 2;
+    if (need_dn && pos_margin(gap_lo + ptol, -v, -a, -vhi, vtol, L) < 0.f && !pos_upper_ok(gap_lo + prep, -v, -a, -vhi, vtol, L)) code |= 2;
+    return code;
+}
+
 __device__ __forceinline__ JointLim joint_lim(const DScene &S, int j) {
     JointLim L = {S.pos_lo[j], S.pos_hi[j], S.vel_max[j], S.acc_max[j], S.jerk_max[j], S.dt, S.pos_lo_res[j], S.pos_hi_res[j], S.vel_max_res[j], 0.f, 0.f};
     L.derive();

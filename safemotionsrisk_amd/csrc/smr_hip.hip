@@ -1141,9 +1141,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
                 const float vt = rng.uniform(S_JOINT + jj, round * 55u + tv * 11u, -L.V, L.V);
                 for (unsigned ta = 0; ta < 10 && !G.all(found); ++ta) {
                     const float at = rng.uniform(S_JOINT + jj, round * 55u + tv * 11u + 1u + ta, -L.A, L.A);
-                    float lo, hi;
-                    int code;
-                    safe_acc_range_joint<8>(L, qme, vt, at, lo, hi, code, !found);
+                    const int code = safe_state_code<8>(L, qme, vt, at, !found);        // only feasibility is asked for
                     if (!found && code == 0) { found = true; vj = vt; aj = at; }
                 }
             }
