@@ -58,6 +58,13 @@ float emul_gjk(const float *va, int na, const float *vb, int nb, const float *Rb
     if (identity_a) return gjk_distance<true>((const float *)verts, A, XA, hb, XB, d, cutoff, stop_below);
     return gjk_distance<false>((const float *)verts, A, XA, hb, XB, d, cutoff, stop_below);
 }
+// the violation code alone, as the kinematic start-state sampling asks for it (safe_state_code)
+int emul_state_code(double plo, double phi, double V, double A, double J, double dt, float p, float v, float a) {
+    JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f, 0.f, 0.f};
+    L.derive();
+    L.plo_res = (float)(plo - (double)L.plo); L.phi_res = (float)(phi - (double)L.phi); L.V_res = (float)(V - (double)L.V);
+    return safe_state_code<1>(L, p, v, a);
+}
 void emul_safe_acc_range(double plo, double phi, double V, double A, double J, double dt, float p, float v, float a, float *lo, float *hi, int *code) {
     JointLim L{(float)plo, (float)phi, (float)V, (float)A, (float)J, (float)dt, 0.f, 0.f, 0.f, 0.f, 0.f};
     L.derive();
@@ -111,6 +118,33 @@ extern "C" void emul_distances(void *h, const float *q, const int *idx, int want
     HostScene *H = (HostScene *)h;
     Sample r = collide_sample(H->d, q, idx, want_dist != 0, want_contact != 0);
     out[0] = r.d_static; out[1] = r.d_moving; out[2] = r.contact ? 1.f : 0.f; out[3] = r.d_self;
+}
+
+// the LDS pool image of the reset-side kernels (body_pool_tables): dwords of the image, or -1 when it does not fit; *mismatch counts the
+// support points over `n_dirs` pseudo-random directions per body that differ between a climb over the pool copy and one over the
+// global tables, plus the piece records that differ
+extern "C" int emul_body_pool_check(void *h, const smr_scene_t *sp, int n_dirs, int *mismatch) {
+    HostScene *H = (HostScene *)h;
+    std::vector<uint32_t> pool;
+    if (!body_pool_tables(*sp, H->G, pool)) return -1;
+    const BodyPool BP{pool.data()};
+    *mismatch = 0;
+    unsigned seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (float)(seed >> 8) / 8388608.0f - 1.0f; };
+    for (int b = 0; b < sp->n_bodies; ++b) {
+        const int pi = sp->link_piece[b];
+        const DPiece P = load_piece(H->d.pieces, pi), Q = BP.piece(b);
+        if (std::memcmp(&P, &Q, sizeof(DPiece)) != 0) ++*mismatch;
+        const GlobalHull g = global_hull(H->d, pi, P);
+        const LocalHull l = BP.hull(b);
+        for (int k = 0; k < n_dirs; ++k) {
+            const F3 d{rnd(), rnd(), rnd()};
+            int h1 = 0, h2 = 0;
+            const F3 a = g.support(d, h1, true), c = l.support(d, h2, true);
+            if (a.x != c.x || a.y != c.y || a.z != c.z || h1 != h2) ++*mismatch;
+        }
+    }
+    return (int)pool.size();
 }
 
 // support of piece `pi` along d (piece frame): climbing result vs exhaustive scan; returns the two dot products

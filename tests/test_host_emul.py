@@ -196,6 +196,43 @@ def test_device_acc_range_on_host(emul, space_scene):
     assert worst < 1e-5
 
 
+def test_reset_kernels_lds_pool_is_a_copy_of_the_global_tables(emul, space_scene, bm_scene):
+    """body_pool_tables (smr_tables.h): the image the reset-side kernels stage in LDS holds every body's vertices, id groups, start map
+    and piece record at the offsets of its header - climbs over it return the vertices the climbs over the global tables return -
+    and fits the kernels' static LDS array, with and without the ball machine."""
+    for scene in (space_scene, bm_scene):
+        H = C.c_void_p(emul.emul_scene_create(C.cast(scene.pointer(), C.c_void_p)))
+        mism = C.c_int(-1)
+        size = emul.emul_body_pool_check(H, C.cast(scene.pointer(), C.c_void_p), 200, C.byref(mism))
+        assert 0 < size <= 15360 and mism.value == 0, (size, mism.value)
+
+
+def test_state_code_alone_equals_the_code_of_the_range(emul, space_scene):
+    """safe_state_code (kinematic start-state sampling: only "is this (q, v, a) feasible") returns the violation code of
+    safe_acc_range_joint without finding the range ends - over random states, including the ones next to a position limit where
+    the brackets open, both must agree bit for bit."""
+    s = space_scene.struct
+    rng = np.random.default_rng(5)
+    emul.emul_safe_acc_range.argtypes = [C.c_double] * 6 + [C.c_float] * 3 + [C.c_void_p] * 3
+    emul.emul_state_code.argtypes = [C.c_double] * 6 + [C.c_float] * 3
+    seen = set()
+    for i in range(6000):
+        j = int(rng.integers(7))
+        L = (s.pos_lo[j], s.pos_hi[j], s.vel_max[j], s.acc_max[j], s.jerk_max[j] * float(rng.choice([1.0, 0.5, 0.2])), 0.1)
+        if i % 3 == 0:      # next to a limit, moving towards it: position brackets open / infeasible states
+            side = rng.integers(2)
+            p = np.float32(L[side] + (1 - 2 * side) * rng.uniform(0, 0.08) * (L[1] - L[0]))
+            v = np.float32((2 * side - 1) * rng.uniform(0, 1) * L[2])
+        else:
+            p = np.float32(rng.uniform(L[0], L[1])); v = np.float32(rng.uniform(-L[2], L[2]))
+        a = np.float32(rng.uniform(-L[3], L[3]))
+        lo, hi, code = C.c_float(), C.c_float(), C.c_int()
+        emul.emul_safe_acc_range(*[float(x) for x in L], float(p), float(v), float(a), C.byref(lo), C.byref(hi), C.byref(code))
+        assert emul.emul_state_code(*[float(x) for x in L], float(p), float(v), float(a)) == code.value
+        seen.add(code.value)
+    assert {0, 2}.issubset(seen) and len(seen) >= 3
+
+
 def _cubic(rng, s, n):
     """random start states and end accelerations inside the limits (the sweep only needs kinematically plausible cubics)"""
     lo, hi, V, A = (np.array(x) for x in (s.pos_lo, s.pos_hi, s.vel_max, s.acc_max))
