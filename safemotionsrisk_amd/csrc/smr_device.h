@@ -102,6 +102,9 @@ struct DScene {
     // all planet pieces [planet_p0, +planet_pn) and their vertex slots [planet_v0, +planet_vn): what the step kernel stages
     // in LDS for the lane-autonomous planet queries (planets_auto = 0: does not fit, wave-lockstep queries)
     int planets_auto, planet_p0, planet_pn, planet_vn;   // planet_vn: vertex slots of auto_verts (4 floats each)
+    // behind them in the same tables: the static piece (the table), descriptor auto_static (-1: not there), so that its rare GJK runs
+    // join the lane-autonomous loop of the planet runs; auto_pn / auto_vn: descriptors / vertex slots staged in all
+    int auto_static, auto_pn, auto_vn;
     int body_order[SMR_MAX_BODIES];   // dispatch order of the bodies in the collide grid (longest-running first)
     int pair_order[SMR_MAX_SELF_PAIRS];   // ... and of the self-collision pairs behind them
     // conservative advancement over the intermediate contact samples (contact sweep, below): no point of body b moves faster than
@@ -1049,9 +1052,10 @@ __device__ inline float gjk_distance(const SMR_CONST float *verts, const DPiece 
 
 // signed distance (margins subtracted) between obstacle piece pa and link piece pb, or any value
 // > cutoff when they are farther apart than cutoff (ctlp.py:2915-2931: no closest point returned)
+// defer: when given, the GJK run is not made - *defer is set and 3e38 returned (every bound and shortcut before it still applies)
 template <bool IDENTITY, class HB>
 __device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, const DPiece &B, const HB &hb, const Xf &XB,
-                                       float cutoff, float stop_below, F3 *warm = nullptr) {
+                                       float cutoff, float stop_below, F3 *warm = nullptr, bool *defer = nullptr) {
     const DPiece A = load_piece(S.pieces, pa);
     const float margins = A.margin + B.margin;
     F3 cb = apply(XB, F3{B.cx, B.cy, B.cz});
@@ -1084,6 +1088,7 @@ __device__ inline float piece_distance(const DScene &S, int pa, const Xf &XA, co
         const F3 low = apply(XB, hb.support(rot_t(XB, F3{0.f, 0.f, -1.f}), hint, true));
         if (low.x >= A.bx0 && low.x <= A.bx1 && low.y >= A.by0 && low.y <= A.by1 && low.z >= A.btop) return (low.z - A.btop) - margins;
     }
+    if (defer) { *defer = true; return 3.0e38f; }
     return gjk_distance<IDENTITY>((const SMR_CONST float *)S.verts, A, XA, hb, XB, d, cutoff + margins, stop_below + margins, warm) - margins;
 }
 
@@ -1282,7 +1287,9 @@ __device__ __forceinline__ int ball_retire_update(const DScene &S, int k, int km
 template <class HB>
 __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, const HB &hull, const Xf &T,
                                       const int idx[SMR_MAX_PLANETS], const Xf *XB, bool want_static, bool want_moving,
-                                      bool want_contact, const float *q_self = nullptr, bool skip_planets = false, float moving_cut = -1.f) {
+                                      bool want_contact, const float *q_self = nullptr, bool skip_planets = false, float moving_cut = -1.f,
+                                      bool *static_defer = nullptr) {
+    // static_defer (scenes with auto_static): a GJK run against the static piece is not made here - the caller hands it to planet_gjk
     // moving_cut: moving distances above it are "no closest point" (default: the scene's moving_max; the contact sweep asks for less)
     const float moving_max = moving_cut >= 0.f ? moving_cut : S.moving_max;
     Sample out;
@@ -1292,7 +1299,7 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
     out.contact = false;
     if (want_static && ((S.static_mask >> l) & 1u)) {
         for (int s = 0; s < S.n_static; ++s) {
-            float d = piece_distance<true>(S, S.static_piece[s], T, LP, hull, T, out.d_static, S.collision_dist);
+            float d = piece_distance<true>(S, S.static_piece[s], T, LP, hull, T, out.d_static, S.collision_dist, nullptr, static_defer);
             if (d <= S.static_max && d < out.d_static) out.d_static = d;
         }
     }
@@ -1372,8 +1379,8 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
 // ---------------------------------------------------------------------------------------------
 __device__ inline void stage_planets(const DScene &S, int tid, int nthreads, float *pv, float *pd) {
     const SMR_GLOBAL float *gv = (const SMR_GLOBAL float *)S.auto_verts, *gd = (const SMR_GLOBAL float *)S.auto_desc;
-    for (int i = tid; i < 4 * S.planet_vn; i += nthreads) pv[i] = gv[i];
-    for (int i = tid; i < kPlanetDescDwords * S.planet_pn; i += nthreads) pd[i] = gd[i];
+    for (int i = tid; i < 4 * S.auto_vn; i += nthreads) pv[i] = gv[i];
+    for (int i = tid; i < kPlanetDescDwords * S.auto_pn; i += nthreads) pd[i] = gd[i];
 }
 
 // pass 1 (lockstep, scalar piece loads): the key of every piece for the lanes with `live` set; pieces whose lower bound exceeds
@@ -1439,9 +1446,12 @@ __device__ inline float planet_keys(const DScene &S, uint32_t *keys, int kstride
 template <class HB>
 __device__ inline void planet_gjk(const DScene &S, const float *pv, const float *pd, uint32_t *keys, int kstride,
                                   const DPiece &LP, const HB &hull, const Xf &T, const int idx[SMR_MAX_PLANETS], bool mov,
-                                  bool want_contact, float moving_max, Sample &out) {
+                                  bool want_contact, float moving_max, Sample &out, bool static_pending = false) {
+    // static_pending: the lane's GJK run against the static piece (descriptor S.auto_static; collide_link left it out) is made here,
+    // first - one lane in a hundred has one, and as a phase of its own it held up every second wavefront for its 7 iterations
     const float stop_moving = want_contact ? S.contact_dist : S.collision_dist;
     bool finished = !(mov || want_contact);
+    bool cur_static = false;
     // pass 2: lane-autonomous GJK, best candidate first
     GjkRun g;
     g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);     // defined state for the lanes that never activate
@@ -1453,7 +1463,12 @@ __device__ inline void planet_gjk(const DScene &S, const float *pv, const float 
     // pass 2 works in the LINK frame (XA = the obstacle piece's frame seen from it): the link-side support needs no
     // transform and the link's world frame T leaves the loop's registers
     const F3 lcl = {LP.cx, LP.cy, LP.cz};
-    const auto sb = [&](F3 d, int &hint, bool first) { return hull.support(d, hint, first); };
+    // (the run against the static piece stays in the WORLD frame - the metre-sized table loses three digits when its corners are
+    // carried into the link frame -, so there the link side is the one that is transformed)
+    const auto sb = [&](F3 d, int &hint, bool first) {
+        const F3 p = hull.support(cur_static ? rot_t(T, d) : d, hint, first);
+        return cur_static ? apply(T, p) : p;
+    };
     const auto sa = [&](F3 d, int &, bool) {
         const F3 dl = rot_t(XA, d);
         float best = -3.0e38f;
@@ -1475,6 +1490,18 @@ __device__ inline void planet_gjk(const DScene &S, const float *pv, const float 
     int prof_trips = 0;
     for (int trip = 0; trip < 33 * kMaxPlanetPieces; ++trip) {
         ++prof_trips;
+        if (!active && static_pending) {
+            static_pending = false;
+            const float *d = pd + kPlanetDescDwords * S.auto_static;
+            av = pv + 4 * __float_as_int(d[0]);
+            ac = __float_as_int(d[1]);
+            margins = d[2] + LP.margin;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) XA.r[i] = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+            XA.t = F3{0.f, 0.f, 0.f};
+            g.start(F3{d[4], d[5], d[6]} - apply(T, lcl), out.d_static + margins, S.collision_dist + margins);
+            active = true; cur_static = true;
+        }
         if (!active && !finished) {
             con_cur = want_contact && !out.contact;
             float cutoff = mov ? fminf(out.d_moving, moving_max) : S.contact_dist;
@@ -1509,8 +1536,11 @@ __device__ inline void planet_gjk(const DScene &S, const float *pv, const float 
             float dist;
             if (gjk_iterate(g, sa, sb, dist)) {
                 const float d = dist - margins;
-                if (mov && d <= moving_max && d < out.d_moving) out.d_moving = d;
-                if (con_cur && d <= S.contact_dist) out.contact = true;
+                if (cur_static) { if (d <= S.static_max && d < out.d_static) out.d_static = d; cur_static = false; }
+                else {
+                    if (mov && d <= moving_max && d < out.d_moving) out.d_moving = d;
+                    if (con_cur && d <= S.contact_dist) out.contact = true;
+                }
                 active = false;
             }
         }
@@ -1660,14 +1690,16 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
         for (int p = 0; p < SMR_MAX_PLANETS; ++p)
             if (p < S.n_planets) idx[p] = (in.planet_idx[p] + N * upd) % S.planet[p].n_orbit;
         const unsigned long long c0 = SMR_DEV_CLOCK();
-        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, nullptr, AUTO);
+        bool static_pending = false;
+        r = collide_link(S, l, LP, hull, T, idx, nullptr, want_static, want_moving, want_contact, nullptr, AUTO, -1.f,
+                         (AUTO && S.auto_static >= 0) ? &static_pending : nullptr);
         if (AUTO) {
             float cutoff_max = want_moving ? S.moving_max : S.contact_dist;
             if (want_contact) cutoff_max = fmaxf(cutoff_max, S.contact_dist);
             const unsigned long long c1 = SMR_DEV_CLOCK();
             lb = planet_keys(S, keys, kstride, LP, T, idx, want_moving || want_contact, cutoff_max);
             const unsigned long long c2 = SMR_DEV_CLOCK();
-            planet_gjk(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, want_contact, S.moving_max, r);
+            planet_gjk(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, want_contact, S.moving_max, r, static_pending);
             SMR_DEV_COUNT(16, c1 - c0); SMR_DEV_COUNT(17, c2 - c1); SMR_DEV_COUNT(18, SMR_DEV_CLOCK() - c2);
             SMR_WAVE_REC(0, (c1 - c0) >> 4); SMR_WAVE_REC(1, (c2 - c1) >> 4); SMR_WAVE_REC(2, (SMR_DEV_CLOCK() - c2) >> 4);
             if (!(want_moving || want_contact)) lb = -1.f;

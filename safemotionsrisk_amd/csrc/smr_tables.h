@@ -356,6 +356,7 @@ inline uint32_t reachable_static_mask(const smr_scene_t &s) {
 inline void planet_tables(HostGeometry &G, DScene &d) {
     const std::vector<DPiece> &pieces = G.pieces;
     d.planets_auto = 0; d.planet_p0 = d.planet_pn = d.planet_vn = 0;
+    d.auto_static = -1; d.auto_pn = d.auto_vn = 0;
     G.auto_verts.clear(); G.auto_desc.clear();
     if (d.n_planets <= 0 || d.use_ball) return;
     int p0 = 1 << 30, p1 = 0, covered = 0;
@@ -376,6 +377,13 @@ inline void planet_tables(HostGeometry &G, DScene &d) {
     for (int i = p0; i < p1; ++i) add(i, (d.n_planets > 1 && i >= d.planet[1].piece_begin) ? 1 : 0);
     if ((int)G.auto_verts.size() > kMaxPlanetVerts) { G.auto_verts.clear(); G.auto_desc.clear(); return; }
     d.planets_auto = 1; d.planet_p0 = p0; d.planet_pn = p1 - p0; d.planet_vn = (int)G.auto_verts.size();
+    d.auto_pn = d.planet_pn; d.auto_vn = d.planet_vn;
+    // the static piece behind them (the table: an axis-aligned box), world frame - its GJK runs join the planet runs' loop
+    if (d.n_static == 1 && pieces[d.static_piece[0]].kind == kPieceAlignedBox && d.planet_pn < kMaxPlanetPieces &&
+        d.planet_vn + (pieces[d.static_piece[0]].count + 3) / 4 * 4 <= kMaxPlanetVerts) {
+        add(d.static_piece[0], 2);
+        d.auto_static = d.planet_pn; d.auto_pn = d.planet_pn + 1; d.auto_vn = (int)G.auto_verts.size();
+    }
 }
 
 // Contact sweep constants (smr_device.h, "contact sweep").  sweep_R[b][j]: no point of body b (margin included) is farther from the
