@@ -1660,7 +1660,7 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
     const bool con_link = (S.contact_mask >> l) & 1u;
     bool want_contact, sweep_contact, moving_alive = true;
     int k_last = N - 1;                                 // last intermediate sample that is tested at all
-    if (S.use_ball) {
+    if (!AUTO && S.use_ball) {           // (the lane-autonomous planet queries exist in planet scenes only)
         // the ball is tested at a sample only while it is in flight (ctlp.py:2836-2861): not yet retired by the
         // update counters, and inside the 1.25 m cylinder around the robot
         const int u_end = ball_retire_update(S, in.ball_k0, in.ball_kmax, in.ball_khit);
@@ -1679,7 +1679,7 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
     const Xf T = lane_frame<SELF>(S, l, in, S.dt);
     float lb = -1.f;                                    // lower bound of the distance to every moving piece at t = dt (< 0: none)
     Sample r;
-    if (S.use_ball) {
+    if (!AUTO && S.use_ball) {           // (the lane-autonomous planet queries exist in planet scenes only)
         const Xf XB = ball_pose(S, in.ball, in.ball_k0 + N * upd, nullptr);
         const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
         r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near);
@@ -1714,7 +1714,7 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
         float step = 0.f;
         for (int j = 0; j < chain; ++j) step += cubic_speed_bound(in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], S.dt) * S.sweep_R[l][j];
         step *= S.dt / (float)N;
-        if (S.use_ball) {
+        if (!AUTO && S.use_ball) {           // (the lane-autonomous planet queries exist in planet scenes only)
             const float udt = S.dt / (float)S.updates_per_step, t0 = (float)in.ball_k0 * udt, t1 = t0 + S.dt;
             const float vz = fmaxf(fabsf(in.ball.v0[2] - 9.81f * t0), fabsf(in.ball.v0[2] - 9.81f * t1));
             step += sqrtf(in.ball.v0[0] * in.ball.v0[0] + in.ball.v0[1] * in.ball.v0[1] + vz * vz) * 1.0001f * udt * (float)upd;
@@ -1742,7 +1742,7 @@ __device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, co
     const int N = S.checks_per_step, upd = S.updates_per_step / N;
     const Xf T = lane_frame<SELF, BOUND_ONLY>(S, l, in, S.dt * (float)k / (float)N);      // bounds: hardware sine / cosine, covered by kBoundSlack
     constexpr float kBoundSlack = 1e-4f;
-    if (S.use_ball) {
+    if (!AUTO && S.use_ball) {
         const Xf XB = ball_pose(S, in.ball, in.ball_k0 + k * upd, nullptr);
         const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
         if (BOUND_ONLY) return live && near && ball_lower_bound(S, LP, T, XB) <= S.contact_dist + kBoundSlack;
