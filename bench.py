@@ -160,6 +160,8 @@ def main():
     ap.add_argument("--checks", type=int, default=None, help="contact samples per step (default 24 = the reference's cadence)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the per-step all-gather")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: every step waits for its all-gather (default: the gather of step t "
+                                                               "runs beside the kernels of step t + 1, all of them inside the timed region)")
     ap.add_argument("--no-info", action="store_true", help="do not write the per-step info matrix")
     args = ap.parse_args()
 
@@ -208,7 +210,7 @@ def main():
         r = env.risk_observation_size
         nets = (risk_network(*mk([r + 7, 256, 128, 1]), device=local_rank), backup_policy(*mk([r, 256, 128, 14]), device=local_rank))
         env.set_risk_networks(*nets, risk_threshold=0.5)
-    rollout = ShardedRollout(env) if (distributed and not args.no_gather) else None
+    rollout = ShardedRollout(env, overlap=not args.sync_gather) if (distributed and not args.no_gather) else None
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)
     actions = [torch.rand((B, 7), device="cuda", generator=gen) * 2 - 1 for _ in range(8)]   # resident before timing
@@ -229,6 +231,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
+    if rollout is not None:
+        rollout.wait()                                  # every gather of the timed steps has landed before the clock stops
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -290,7 +294,7 @@ def main():
             "config": {"workload": "%s; %d envs/GPU, dt=%.3g, T=%.3g, %d contact samples/step, auto-reset, uniform(-1,1) actions, info matrix %s"
                                    % (what, B, s.dt, s.dt * s.episode_steps, n_checks, "off" if args.no_info else "on"),
                        "name": args.config, "envs_per_gpu": B, "global_batch": B * world, "collision_checks_per_step": n_checks,
-                       "all_gather": bool(rollout is not None), "parallelism": "env-sharded x%d" % world},
+                       "all_gather": (False if rollout is None else ("every step waits for it" if args.sync_gather else "overlapped with the next step")), "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_step": traffic_step,
                          "binding_resource": "fp32 vector issue + LDS latency (not HBM, SURVEY section 0.5): see vector_issue",

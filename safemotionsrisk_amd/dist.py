@@ -44,10 +44,15 @@ class ShardedRollout:
     (VecSafeMotionsEnv on a GPU).  `group` is a torch.distributed process group (None: default group).
     """
 
-    def __init__(self, env, group=None, equal_shards=True, host_gather=False):
+    def __init__(self, env, group=None, equal_shards=True, host_gather=False, overlap=False):
         """host_gather: the consumer of the rollout lives on the host (a learner that wants numpy batches, or a process group
         without a device backend such as gloo): the packed shard is copied to pinned host memory once per step and the
-        all-gather runs on host buffers; the gathered views are then CPU tensors."""
+        all-gather runs on host buffers; the gathered views are then CPU tensors.
+
+        overlap: the gather of step t runs beside the kernels of step t + 1 (xGMI is point to point: 7 x 6.4 MB arrive per GPU and
+        step at 8 x 65 536 envs - a quarter of the step time if the step waited for it).  Two packed buffers alternate: the env
+        writes slot t & 1 while the collective still reads the other one; step() returns the views of its gathered slot at once,
+        they are complete after wait() (or after the step() after next, which waits for the slot before it is written again)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.env, self.group = torch, dist, env, group
@@ -59,8 +64,14 @@ class ShardedRollout:
         if not equal_shards:
             raise NotImplementedError("all_gather_into_tensor needs equal shards; pad num_envs to a multiple of world")
         self.host_gather = bool(host_gather)
+        self.overlap = bool(overlap) and not self.host_gather
         out_device = "cpu" if self.host_gather else env.obs.device
         self.gathered = torch.zeros(self.world * self.local.nbytes, dtype=torch.uint8, device=out_device)
+        if self.overlap:
+            self._locals = [self.local, PackedRollout(torch, env.num_envs, env.observation_size, env.obs.device)]
+            self._gathereds = [self.gathered, torch.zeros_like(self.gathered)]
+            self._work = [None, None]
+            self._slot = 0
         self._host = None
         if self.host_gather:
             self._host = torch.zeros(self.local.nbytes, dtype=torch.uint8)
@@ -77,13 +88,36 @@ class ShardedRollout:
         return [self.local.views(self.gathered[r * n:(r + 1) * n]) for r in range(self.world)]
 
     def reset(self):
+        if self.overlap:
+            self.wait()
+            self.env.obs, self.env.reward, self.env.done = self.local.obs, self.local.reward, self.local.done
+            self._slot = 1                              # reset() used slot 0 synchronously
+            self._work = [None, None]
         self.env.reset()
         return self._gather()
 
     def step(self, action):
-        """action: float32 [B_g, 7] for the local shard.  Returns [(obs, reward, done)] per rank."""
+        """action: float32 [B_g, 7] for the local shard.  Returns [(obs, reward, done)] per rank (overlap: complete after wait())."""
+        if not self.overlap:
+            self.env.step(action)
+            return self._gather()
+        i = self._slot
+        if self._work[i] is not None:
+            self._work[i].wait()                        # the gather that read this slot two steps ago (long done)
+        loc = self._locals[i]
+        self.env.obs, self.env.reward, self.env.done = loc.obs, loc.reward, loc.done
         self.env.step(action)
-        return self._gather()
+        self._work[i] = self.dist.all_gather_into_tensor(self._gathereds[i], loc.flat, group=self.group, async_op=True)
+        self._slot = i ^ 1
+        n = loc.nbytes
+        return [loc.views(self._gathereds[i][r * n:(r + 1) * n]) for r in range(self.world)]
+
+    def wait(self):
+        """overlap: every gather in flight has landed (device backends: the current stream waits, not the host)"""
+        if self.overlap:
+            for w in self._work:
+                if w is not None:
+                    w.wait()
 
     def concatenated(self, parts):
         t = self.torch

@@ -54,6 +54,23 @@ def _worker(rank, world, port, q):
                 ref.t = t
                 ref._fill()
                 ok &= torch.equal(parts[r][0], ref.obs) and torch.equal(parts[r][1], ref.reward) and torch.equal(parts[r][2], ref.done)
+        # overlapped mode: the gather of a step is still in flight when the next step is issued; two slots alternate
+        env2 = StubEnv(rank, hi - lo, 23)
+        roll2 = ShardedRollout(env2, overlap=True)
+        roll2.reset()
+        held = []
+        for t in range(1, 6):
+            held.append((t, roll2.step(torch.zeros(env2.num_envs, 7))))
+            if len(held) == 2:                          # read a step's batch one step later, as a pipelined learner would
+                roll2.wait()
+                tt, pp = held.pop(0)
+                for r in range(world):
+                    ref = StubEnv(r, env2.num_envs, 23)
+                    ref.t = tt
+                    ref._fill()
+                    ok &= torch.equal(pp[r][0], ref.obs) and torch.equal(pp[r][1], ref.reward) and torch.equal(pp[r][2], ref.done)
+        roll2.wait()
+        ok &= env2.obs.data_ptr() in (roll2._locals[0].flat.data_ptr(), roll2._locals[1].flat.data_ptr())
         obs, rew, done = roll.concatenated(parts)
         ok &= obs.shape == (world * env.num_envs, 23) and rew.shape == (world * env.num_envs,) and done.dtype == torch.uint8
         # the env writes straight into the packed buffer (no staging copy)

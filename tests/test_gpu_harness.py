@@ -155,6 +155,58 @@ def test_two_real_shards_through_one_process_group(built, tmp_path):
     assert sum(a[k][:, -1].sum() for k in a.files[1:]) > 512              # episodes ended in both shards
 
 
+def _overlap_worker(port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
+    from safemotionsrisk_amd.dist import ShardedRollout
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B, T = 1024, 12
+        env = VecSafeMotionsEnv(B, device=0, seed=11, auto_reset=True, **SPACE_ENV_CONFIG)
+        ref = VecSafeMotionsEnv(B, device=0, seed=11, auto_reset=True, **SPACE_ENV_CONFIG)
+        roll = ShardedRollout(env, overlap=True)
+        roll.reset(); ref.reset()
+        gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+        acts = [torch.rand((B, 7), device="cuda", generator=gen) * 2 - 1 for _ in range(T)]
+        ok, held = True, None
+        for t in range(T):
+            parts = roll.step(acts[t])                     # the gather of this step is in flight while the next one is issued
+            o, r, d, _ = ref.step(acts[t])
+            expect = (o.clone(), r.clone(), d.clone())
+            if held is not None:                           # read a step's batch one step later, before its slot is written again
+                roll.wait()
+                torch.cuda.synchronize()
+                (po, pr, pd), (eo, er, ed) = held[0][0], held[1]
+                ok &= bool(torch.equal(po, eo) and torch.equal(pr, er) and torch.equal(pd, ed))
+            held = (parts, expect)
+        roll.wait(); torch.cuda.synchronize()
+        ok &= bool(torch.equal(held[0][0][0], held[1][0]))
+        env.synchronize(); ref.synchronize()
+        env.close(); ref.close()
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_on_the_device(built, tmp_path):
+    """ShardedRollout(overlap=True) through RCCL (a one-rank group: the box has one GPU): the env alternates between two packed
+    buffers, the all-gather of a step runs asynchronously beside the next step's kernels, and what is read one step later equals
+    the batch of an identical env stepped without the rollout wrapper."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "overlap.txt")
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_overlap_worker, args=(port, out))
+    p.start()
+    p.join(timeout=300)
+    assert p.exitcode == 0 and open(out).read() == "ok"
+
+
 def test_bench_refuses_more_ranks_than_gpus(built):
     """`python bench.py --gpus 2` without a launcher starts its own two ranks; on a one-GPU box rank 1 has no device and the
     command must fail loudly instead of printing a one-GPU line."""
