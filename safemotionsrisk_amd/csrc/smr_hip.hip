@@ -947,9 +947,9 @@ __device__ inline void store_ball(const DState &st, int B, int e, const BallSpaw
 // Otherwise the ball is installed - from the staged launch when one with the right tag is there, else drawn on the spot.
 // tags / tag_offset (STAGE): the spawn count the launch is for - tags[i], or the env's current count + tag_offset
 template <bool EXTRA, bool STAGE>
-__global__ SMR_SIDE_KERNEL void spawn_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
-                                                   const int *__restrict__ count_ptr, int count_fixed, int all_reset, int group_stride,
-                                                   float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
+__device__ __forceinline__ void spawn_body(const DScene *__restrict__ Sp, const DState &st, const int *__restrict__ list,
+                                           const int *__restrict__ count_ptr, int count_fixed, int all_reset, int group_stride,
+                                           float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
     __shared__ uint32_t pool[kBodyPoolDwords];
     const int count = count_ptr ? *count_ptr : count_fixed;
@@ -1013,6 +1013,23 @@ __global__ SMR_SIDE_KERNEL void spawn_kernel(const DScene *__restrict__ Sp, DSta
         store_ball(st, B, e, b, k0, spawns + 1u);
         if (obs) write_ball_observation(S, bs, k0, obs + (size_t)e * S.obs_size + 3 * SMR_NJ + S.obs_target_size);
     }
+}
+
+// Two instantiation families with different register budgets: with the ball machine (EXTRA) the kernel is held to 256 registers like
+// the other reset-side kernels (a wavefront with 512 keeps the collide kernel off its SIMD: ball + ball machine 67 against 65 M
+// env-steps/s); on the plain robot its float64 launch arithmetic spills 100-200 registers at 256 and the kernel is short - there it
+// keeps the AGPRs as spill space (ball scene 113 -> 120 M).
+template <bool STAGE>
+__global__ SMR_SIDE_KERNEL void spawn_kernel_extra(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list, const int *__restrict__ count_ptr,
+                                                   int count_fixed, int all_reset, int group_stride, float *__restrict__ obs,
+                                                   const unsigned *__restrict__ tags, int tag_offset) {
+    spawn_body<true, STAGE>(Sp, st, list, count_ptr, count_fixed, all_reset, group_stride, obs, tags, tag_offset);
+}
+template <bool STAGE>
+__global__ __launch_bounds__(256) void spawn_kernel_plain(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list, const int *__restrict__ count_ptr,
+                                                          int count_fixed, int all_reset, int group_stride, float *__restrict__ obs,
+                                                          const unsigned *__restrict__ tags, int tag_offset) {
+    spawn_body<false, STAGE>(Sp, st, list, count_ptr, count_fixed, all_reset, group_stride, obs, tags, tag_offset);
 }
 
 // A14: a new target point for the envs of the list (reached in this step, or reset): _add_target_point, ctlp.py:1658-1721 -
@@ -1832,14 +1849,14 @@ static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int 
 }
 
 static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int all_reset, int stride, float *obs) {
-    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, false>), grid, dim3(kSideBlock), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
-    else hipLaunchKernelGGL((spawn_kernel<false, false>), grid, dim3(kSideBlock), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel_extra<false>), grid, dim3(kSideBlock), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
+    else hipLaunchKernelGGL((spawn_kernel_plain<false>), grid, dim3(kSideBlock), 0, env->stream, env->dscene, env->st, list, count_ptr, count_fixed, all_reset, stride, obs, (const unsigned *)nullptr, 0);
 }
 // the staged launch of the NEXT ball of the listed envs (after their current one was installed), on stream s
 static void launch_spawn_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride,
                                 const unsigned *tags = nullptr, int tag_offset = 0) {
-    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel<true, true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
-    else hipLaunchKernelGGL((spawn_kernel<false, true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel_extra<true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
+    else hipLaunchKernelGGL((spawn_kernel_plain<true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
 }
 
 static void launch_target(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {

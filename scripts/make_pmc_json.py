@@ -9,6 +9,9 @@ out, config, envs, checks, roots = sys.argv[1], sys.argv[2], int(sys.argv[3]), i
 def short(name):
     """template arguments dropped; staged instantiations of reset / spawn / target marked"""
     k = name.split("(")[0].replace("void ", "").strip()
+    m2 = re.match(r"smr::spawn_kernel_(extra|plain)<(.*)>", k)          # two register budgets of one kernel body
+    if m2:
+        return "smr::spawn_kernel<%s>" % ("staged" if m2.group(2).strip() == "true" else "live")
     m = re.match(r"(smr::\w+?)_kernel<(.*)>", k)
     if not m:
         return re.sub(r"<.*", "", k)
