@@ -114,13 +114,18 @@ def _free_port():
 
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: N fresh rank processes (this process has not touched the GPU and does not)."""
-    port = _free_port()
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()    # (the port is free when probed; a launcher that must not race passes its own)
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    # rank 0's stdout is drained while the ranks run (a full pipe would block it for ever)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     # a rank that fails leaves the others waiting in the rendezvous: stop them (our own children, by pid) instead of hanging
     while any(p.poll() is None for p in procs):
         if any(p.poll() not in (None, 0) for p in procs):
@@ -129,8 +134,9 @@ def launch_ranks(args):
                     p.terminate()
             break
         time.sleep(0.2)
-    out = procs[0].stdout.read() if procs[0].stdout else b""
     codes = [p.wait() for p in procs]
+    reader.join(timeout=30)
+    out = b"".join(chunks)
     if any(codes):
         raise SystemExit("bench.py --gpus %d: rank exit codes %s" % (args.gpus, codes))
     sys.stdout.write(out.decode())
@@ -138,10 +144,14 @@ def launch_ranks(args):
 
 
 def load_pmc(config_name, B, n_checks):
-    """profiles/round2_pmc_<config>.json (scripts/make_pmc_json.py from separate rocprofv3 --pmc passes of this command)"""
-    path = os.path.join(ROOT, "profiles", "round2_pmc_%s.json" % config_name)
-    if not os.path.exists(path):
-        return None, "no %s" % os.path.relpath(path, ROOT)
+    """profiles/round<R>_pmc_<config>.json of the latest round that has one (scripts/make_pmc_json.py from separate rocprofv3 --pmc
+    passes of this command)"""
+    for rnd in (3, 2):
+        path = os.path.join(ROOT, "profiles", "round%d_pmc_%s.json" % (rnd, config_name))
+        if os.path.exists(path):
+            break
+    else:
+        return None, "no profiles/round*_pmc_%s.json" % config_name
     pmc = json.load(open(path))
     meta = pmc.get("run", {})
     if meta.get("envs_per_gpu") != B or meta.get("collision_checks_per_step") != n_checks:
@@ -200,7 +210,7 @@ def main():
     if args.checks is not None:
         kw = dict(kw, collision_checks_per_step=args.checks)
     risk_nets = kw.pop("risk_networks", False)
-    env = VecSafeMotionsEnv(B, device=local_rank, seed=0, auto_reset=True, return_info=not args.no_info, env_index_offset=rank, **kw, **cfg)
+    env = VecSafeMotionsEnv(B, device=local_rank, seed=0, auto_reset=True, return_info=not args.no_info, env_index_base=rank * B, **kw, **cfg)
     if risk_nets:                                       # synthetic weights of the shipped architectures (the checkpoints are not loaded)
         import numpy as np
         from safemotionsrisk_amd import backup_policy, risk_network
@@ -261,6 +271,7 @@ def main():
         # measured counters of the same command (separate rocprofv3 --pmc passes, committed under profiles/)
         pmc, pmc_note = load_pmc(args.config, B, n_checks) if world == 1 else (None, "PMC profiles are collected at N = 1")
         traffic = traffic_step = issue = None
+        kk = {}
         if pmc is not None:
             kname = "smr::%s_kernel" % dominant
             kk = pmc["kernels"].get(kname, {})
@@ -278,8 +289,23 @@ def main():
                          "note": "wave-level VALU instructions x 2 cycles (wave64 on a SIMD-32, >= 2 waves per SIMD) / 1024 SIMDs / 2.4 GHz against "
                                  "the kernel's measured time; lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): the share of "
                                  "the issued lanes that are switched on"}
+        # wave-slot occupancy of the dominant kernel: the wavefronts' summed life time against (kernel time x wave slots of the chip)
+        slot = None
+        if pmc is not None and "SQ_WAVE_CYCLES" in kk and kk.get("SQ_WAVES"):
+            waves_per_simd = {"collide": 4, "brake": 4}.get(dominant, 2)
+            slots = N_SIMD * waves_per_simd
+            # SQ_WAVE_CYCLES counts in units of 4 cycles (MI355X_MICROARCH.md, SQ counters "quad-cycles")
+            mean_wave_us = kk["SQ_WAVE_CYCLES"] * 4.0 / kk["SQ_WAVES"] / CLOCK_HZ * 1e6
+            packed_ms = kk["SQ_WAVES"] * mean_wave_us * 1e-3 / slots
+            slot = {"waves_per_launch": kk["SQ_WAVES"], "mean_wave_life_us": mean_wave_us, "wave_slots": slots, "packed_ms": packed_ms,
+                    "slot_utilisation": packed_ms / dom_ms,
+                    "note": "SQ_WAVE_CYCLES x 4 / SQ_WAVES = mean life of a wavefront; packed_ms = all wavefronts' life time spread evenly over the "
+                            "%d wave slots (%d per SIMD at this kernel's register budget); slot_utilisation = packed_ms / measured kernel time: what "
+                            "is lost to the tail of the block schedule (the kernel is as long as its slowest block)" % (slots, waves_per_simd)}
+        label = "env-steps/sec at batch 65 536, 7-DoF space scene" if (args.config == "space" and B == 65536) else \
+                "env-steps/sec, %s, %d envs/GPU" % (args.config, B)
         out = {
-            "metric": "env-steps/sec at batch 65 536, 7-DoF space scene",
+            "metric": label,
             "value": total_env_steps / elapsed,
             "unit": "env-steps/s",
             "n_gpus": world,
@@ -294,11 +320,16 @@ def main():
             "config": {"workload": "%s; %d envs/GPU, dt=%.3g, T=%.3g, %d contact samples/step, auto-reset, uniform(-1,1) actions, info matrix %s"
                                    % (what, B, s.dt, s.dt * s.episode_steps, n_checks, "off" if args.no_info else "on"),
                        "name": args.config, "envs_per_gpu": B, "global_batch": B * world, "collision_checks_per_step": n_checks,
-                       "all_gather": (False if rollout is None else ("every step waits for it" if args.sync_gather else "overlapped with the next step")), "parallelism": "env-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "all_gather": (False if rollout is None else ("every step waits for it" if args.sync_gather else
+                                                                        "overlapped with the next step (all gathers land inside the timed region)")), "parallelism": "env-sharded x%d" % world},
+            # the contract's roofline object prices the kernel against HBM ("achieved" = algorithmic bytes / kernel time); this path is
+            # NOT HBM bound (342 B per env-step), so "bound" names the resource that does bind it and the figures
+            # that matter are vector_issue (share of the chip's VALU issue rate) and slot_utilisation (share of its wave slots)
+            "roofline": {"bound": "valu", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_step": traffic_step,
-                         "binding_resource": "fp32 vector issue + LDS latency (not HBM, SURVEY section 0.5): see vector_issue",
-                         "vector_issue": issue, "pmc": pmc_note,
+                         "binding_resource": "fp32 vector issue + LDS latency of a few long-running wavefronts (not HBM, SURVEY section 0.5): "
+                                             "achieved / peak / frac are the HBM figures the contract asks for, see vector_issue and wave_slots",
+                         "vector_issue": issue, "wave_slots": slot, "pmc": pmc_note,
                          "note": "achieved = %d algorithmic B per env-step x %d envs per launch / mean %s-kernel time (HIP events on the "
                                  "handle's stream); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch" % (algo_bytes, B, dominant)},
             "kernel_ms": kernels,

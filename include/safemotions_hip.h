@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 6
+#define SMR_ABI_VERSION 7
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
@@ -97,8 +97,13 @@ typedef struct smr_host_state {
 int smr_abi_version(void);
 size_t smr_scene_sizeof(void);          /* sizeof(smr_scene_t) as compiled into the library */
 
-/* Env(**env_config) x B.  device: HIP device ordinal.  stream: hipStream_t or NULL. */
-int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint64_t seed, void *stream,
+/* Env(**env_config) x B.  device: HIP device ordinal.  stream: hipStream_t or NULL.
+ * env_index_base: the handle owns the envs [env_index_base, env_index_base + num_envs) of a larger, global batch (one handle per
+ * GPU).  Everything an env draws is a pure function of (seed, GLOBAL env index, its counters): the Philox key
+ * is the seed, the env word of the counter is env_index_base + e.  Shards therefore form a partition of the global batch - the
+ * concatenation of their outputs is bit-identical to one handle over the whole batch, whatever the world size.  0 for a single
+ * handle.  (The reference seeds numpy's global generator per process, base.py:1704-1710.) */
+int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_base, int32_t device, uint64_t seed, void *stream,
                smr_env_t **out);
 int smr_destroy(smr_env_t *env);
 const char *smr_last_error(const smr_env_t *env);

@@ -63,7 +63,7 @@ def _d(x):
 class OracleEnv:
     """Batched float64 oracle env with the same call shape as the product's VecSafeMotionsEnv."""
 
-    def __init__(self, scene_bundle, num_envs, seed=0, num_threads=1):
+    def __init__(self, scene_bundle, num_envs, seed=0, num_threads=1, env_index_base=0):
         self.L = lib()
         assert self.L.smo_scene_sizeof() == C.sizeof(type(scene_bundle.struct)), "smr_scene_t layout mismatch"
         self.bundle = scene_bundle
@@ -73,6 +73,8 @@ class OracleEnv:
         if not self.h:
             raise ValueError("smo_create rejected the scene")
         self.h = C.c_void_p(self.h)
+        if env_index_base:
+            self.L.smo_set_env_index_base(self.h, C.c_uint32(int(env_index_base)))
 
     def close(self):
         if self.h:

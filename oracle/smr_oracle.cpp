@@ -434,6 +434,7 @@ struct Oracle {
     std::vector<double> orbit_pose[SMR_MAX_PLANETS], orbit_local[SMR_MAX_PLANETS];
     int B;
     uint64_t seed;
+    uint32_t env_base = 0;     /* index of this batch's env 0 in the global batch: Philox counter word = env_base + e */
     std::vector<EnvState> st;
     std::string err;
     int num_threads;
@@ -655,7 +656,7 @@ V3 ee_point(const Oracle &O, const double q[SMR_NJ]) {
  * as the next observation sets them (ctlp.py:2229-2243). */
 void sample_target(const Oracle &O, EnvState &st, int e) {
     const smr_scene_t &S = O.S;
-    Rng rng = {O.seed, (uint32_t)e, st.tp_count};
+    Rng rng = {O.seed, O.env_base + (uint32_t)e, st.tp_count};
     st.tp_count += 1;
     V3 target = {0, 0, 0};
     for (uint32_t m = 0; m < 100000; ++m) {
@@ -769,7 +770,7 @@ double ball_min_distance(const Oracle &O, const Xf link[SMR_MAX_BODIES], const X
 void spawn_ball(Oracle &O, int e) {
     const smr_scene_t &S = O.S;
     EnvState &st = O.st[e];
-    Rng rng = {O.seed, (uint32_t)e, st.ball_spawns};
+    Rng rng = {O.seed, O.env_base + (uint32_t)e, st.ball_spawns};
     st.ball_spawns += 1;
     const double udt = S.dt / S.updates_per_step, v = S.ball_speed;
     double rel[3] = {0, 0, 0}, vel[3] = {0, 0, 1};
@@ -942,7 +943,7 @@ bool braking_trajectory_unsafe(const Oracle &O, const double q0[SMR_NJ], const d
 void reset_env(Oracle &O, int e) {
     const smr_scene_t &S = O.S;
     EnvState &st = O.st[e];
-    Rng rng = {O.seed, (uint32_t)e, st.reset_count};
+    Rng rng = {O.seed, O.env_base + (uint32_t)e, st.reset_count};
     st.reset_count += 1;
     double q[SMR_NJ], v[SMR_NJ] = {0}, a[SMR_NJ] = {0};
     uint32_t attempt = 0;
@@ -1011,7 +1012,7 @@ void reset_env(Oracle &O, int e) {
     if (S.use_ball) {                                                                       /* ctlp.py:1052-1111 */
         spawn_ball(O, e);
         if (S.ball_random_initial_position) {
-            Rng brng = {O.seed, (uint32_t)e, st.ball_spawns - 1};
+            Rng brng = {O.seed, O.env_base + (uint32_t)e, st.ball_spawns - 1};
             int kcap = st.ball_kmax;
             if (st.ball_khit < kcap) kcap = st.ball_khit;
             int max_ts = kcap / S.updates_per_step;
@@ -1258,6 +1259,9 @@ void *smo_create(const smr_scene_t *scene, int32_t num_envs, uint64_t seed, int3
 }
 
 void smo_destroy(void *h) { delete (Oracle *)h; }
+
+/* this batch is the block [base, base + B) of a larger one (smr_create's env_index_base) */
+void smo_set_env_index_base(void *h, uint32_t base) { ((Oracle *)h)->env_base = base; }
 
 /* mask: NULL = all envs */
 void smo_reset(void *h, const uint8_t *mask, float *obs) {

@@ -141,6 +141,8 @@ struct DScene {
     int kin_mode;
     float kin_prob, stay_prob;
     unsigned seed_lo, seed_hi;
+    unsigned env_base;          // index of this handle's env 0 in the global batch: Philox counter word of env e = env_base + e, so that
+                                // the shards of a batch draw what one handle over the whole batch draws (smr_create, env_index_base)
 };
 
 // per-env state, struct of arrays ([component][B]) so that lane e of a wave reads consecutive words

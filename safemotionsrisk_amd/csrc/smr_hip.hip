@@ -671,7 +671,12 @@ __global__ __launch_bounds__(256) void brake_plan_kernel(const DScene *__restric
         an = b;
         if (active && joint_lane) st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e] = b;
     }
-    if (valid && g == 7) st.brake_steps[e] = steps;
+    if (valid && g == 7) {
+        st.brake_steps[e] = steps;
+        // no standstill within the braking timeout counts as a collision whatever is observed (ctlp.py:3201-3203): latched here, not in
+        // brake_check_kernel, whose rows of unobserved bodies leave before they look at anything (plan_kernel cleared the flag)
+        if (steps < 0) st.braked[e] = 1;
+    }
 }
 
 // check_braking_trajectory_method (ctlp.py:3026-3053, _check_if_braking_trajectory_is_collision_free :3155-3207) on the grid of the
@@ -717,7 +722,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B) return;
     const int steps = st.brake_steps[e];
-    if (steps < 0) { st.braked[e] = 1; return; }         // no standstill within the braking timeout counts as a collision, ctlp.py:3201-3203
+    if (steps < 0) return;                               // braking timeout: brake_plan_kernel latched braked[e] already (ctlp.py:3201-3203)
     float p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ], q_ref[SMR_NJ];
 #pragma unroll
     for (int j = 0; j < SMR_NJ; ++j) { p[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; ap[j] = st.a[j * B + e]; an[j] = st.a1[j * B + e]; q_ref[j] = p[j]; }
@@ -966,7 +971,7 @@ __device__ __forceinline__ void spawn_body(const DScene *__restrict__ Sp, const 
     const int B = S.B;
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const unsigned spawns = STAGE ? (tags ? tags[i] : (unsigned)st.ball_i[4 * B + e] + (unsigned)tag_offset) : (unsigned)st.ball_i[4 * B + e];
-    const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, spawns};
+    const Rng rng = {S.seed_lo, S.seed_hi, S.env_base + (unsigned)e, spawns};
     const size_t sl = (size_t)(spawns & 1u);
     SMR_PHASE_INIT;
     if (STAGE) {
@@ -1056,7 +1061,7 @@ __global__ SMR_SIDE_KERNEL void target_kernel(const DScene *__restrict__ Sp, DSt
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const int jj = g < SMR_NJ ? g : 0;
     const unsigned count = STAGED ? (tags ? tags[i] : st.tp_count[e] + (unsigned)tag_offset) : st.tp_count[e];
-    const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, count};
+    const Rng rng = {S.seed_lo, S.seed_hi, S.env_base + (unsigned)e, count};
     float q[SMR_NJ];
     bool found = false;
     SMR_PHASE_INIT;
@@ -1124,7 +1129,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
     const int B = S.B;
     const Group G{g, (int)(threadIdx.x & 63) & ~7};
     const int gbase = G.gbase;
-    const Rng rng = {S.seed_lo, S.seed_hi, (unsigned)e, tags ? tags[i] : st.reset_count[e] + (unsigned)tag_offset};
+    const Rng rng = {S.seed_lo, S.seed_hi, S.env_base + (unsigned)e, tags ? tags[i] : st.reset_count[e] + (unsigned)tag_offset};
     const int jj = g < SMR_NJ ? g : 0;
 
     // ---- start position: attempts in sequence, each tested link-parallel (stream S_POS, attempt n = draws 7n..7n+6)
@@ -1242,7 +1247,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
     unsigned ball_spawns = 0;
     if (S.use_ball) {
         ball_spawns = (unsigned)st.ball_i[4 * B + e];
-        const Rng brng = {S.seed_lo, S.seed_hi, (unsigned)e, ball_spawns};
+        const Rng brng = {S.seed_lo, S.seed_hi, S.env_base + (unsigned)e, ball_spawns};
         bsp = spawn_ball_group<EXTRA>(S, BP, st, brng, G);
         if (S.ball_random_initial) {
             BallState bs;
@@ -1504,7 +1509,7 @@ static int dev_upload(smr_env *env, T **out, const std::vector<T> &host) {
 
 static void copy3(float *dst, const double *src, int n = 3) { for (int i = 0; i < n; ++i) dst[i] = (float)src[i]; }
 
-static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed) {
+static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed, uint32_t env_index_base) {
     DScene &d = env->hscene;
     std::memset(&d, 0, sizeof d);
     d.B = env->B; d.obs_size = s.obs_size; d.episode_steps = s.episode_steps; d.updates_per_step = s.updates_per_step;
@@ -1637,7 +1642,7 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed)
     copy3(d.brake_acc_max, s.brake_acc_max, SMR_NJ); copy3(d.brake_jerk_max, s.brake_jerk_max, SMR_NJ);
     d.kin_mode = s.kinematic_state_sampling_mode; d.kin_prob = (float)s.kinematic_state_sampling_probability;
     d.stay_prob = (float)s.stay_in_state_probability;
-    d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32);
+    d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32); d.env_base = env_index_base;
     if ((rc = dev_alloc(env, &env->dscene, 1))) return rc;
     SMR_HIP(hipMemcpy(env->dscene, &d, sizeof d, hipMemcpyHostToDevice));
     return SMR_OK;
@@ -1690,11 +1695,12 @@ int smr_destroy(smr_env_t *env) {
     return SMR_OK;
 }
 
-int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint64_t seed, void *stream, smr_env_t **out) {
+int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_base, int32_t device, uint64_t seed, void *stream, smr_env_t **out) {
     if (!out) { g_create_error = "out is NULL"; return SMR_E_INVALID; }
     *out = nullptr;
     int rc = check_scene(scene, num_envs, g_create_error);
     if (rc) return rc;
+    if ((uint64_t)env_index_base + (uint64_t)num_envs > 0xFFFFFFFFull) { g_create_error = "env_index_base + num_envs must fit 32 bits (the env word of the Philox counter)"; return SMR_E_INVALID; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         g_create_error = "no HIP device: libsmr_hip has no CPU path (the CPU restatement lives in oracle/ and is test-only)";
@@ -1706,7 +1712,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, int32_t device, uint6
     env->N = scene->collision_checks_per_step; env->auto_reset = scene->auto_reset;
     auto fail = [&](int code) { g_create_error = env->err; smr_destroy(env); return code; };
     if (hipSetDevice(device) != hipSuccess) { env->err = "hipSetDevice failed"; return fail(SMR_E_HIP); }
-    if ((rc = build_device_scene(env, *scene, seed))) return fail(rc);
+    if ((rc = build_device_scene(env, *scene, seed, env_index_base))) return fail(rc);
     const size_t B = (size_t)num_envs;
     DState &st = env->st;
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
@@ -2262,6 +2268,10 @@ int smr_mlp_destroy(smr_mlp_t *mlp) {
 
 int smr_mlp_forward(smr_mlp_t *mlp, const float *x_dev, int32_t ldx, float *y_dev, int32_t ldy, int32_t n_rows, void *stream) {
     if (!mlp || !x_dev || !y_dev || n_rows <= 0 || ldx < mlp->d.in_size || ldy < mlp->d.out_size) { g_create_error = "smr_mlp_forward: bad arguments"; return SMR_E_INVALID; }
+    for (int l = 0; l < mlp->d.n_layers; ++l)             // the kernel's contract (smr_mlp.h): what smr_mlp_create pads to
+        if (mlp->d.K[l] % 8 || mlp->d.N[l] % 64 || mlp->d.K[l] > kMlpMaxWidth || mlp->d.N[l] > kMlpMaxWidth || mlp->d.K[l] <= 0 || mlp->d.N[l] <= 0) {
+            g_create_error = "smr_mlp_forward: layer sizes violate the kernel's padding contract (K % 8, N % 64, both <= 256)"; return SMR_E_INVALID;
+        }
     if (hipSetDevice(mlp->device) != hipSuccess) return SMR_E_HIP;
     hipLaunchKernelGGL(mlp_forward_kernel, dim3((n_rows + kMlpRows - 1) / kMlpRows), dim3(64), 0, (hipStream_t)stream, mlp->d, x_dev, ldx, y_dev, ldy, n_rows);
     return hipGetLastError() == hipSuccess ? SMR_OK : SMR_E_HIP;

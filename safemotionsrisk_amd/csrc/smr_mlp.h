@@ -10,7 +10,12 @@
 // k step of 4 the wave reads two A operands from LDS and one B operand per column tile from L2 (weights: <= 256 KB per layer, every
 // wave reads all of them) and issues 2 x N/16 independent v_mfma_f32_16x16x4_f32 (exact f32: A[l&15][k=l>>4], B[k=l>>4][l&15],
 // D col = l&15, row = 4 (l>>4) + reg; 32 cycles each on a SIMD) - enough to cover the L2 latency of the next k step's B operands,
-// which are fetched one step ahead.  Weights are zero-padded on the host to K multiples of 8 and N multiples of 64.
+// which are fetched one step ahead.
+// Contract of mlp_forward_kernel for a DMlp: K[l] % 8 == 0 (the k loop fetches two MFMA k steps together), N[l] % 64 == 0 (four
+// 16-column tiles per pass), K[l], N[l] <= kMlpMaxWidth, K[l + 1] == N[l], weights / biases zero padded up to those sizes.
+// smr_mlp_create pads K[0] to a multiple of 16 and N to multiples of 64; smr_mlp_forward rejects anything else.  The input rows may
+// be wider than in_size (row stride ldx >= in_size: the backup policy reads the first columns of the risk network's rows): only
+// columns < in_size are loaded, the padding columns up to K[0] read as zero.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

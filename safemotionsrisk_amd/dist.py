@@ -1,7 +1,9 @@
 """Rollout sharding over the GPUs of one node (BASELINE config 5).
 
-Environments are independent, so rank g of G owns the contiguous block [g*B_g, (g+1)*B_g) with its own
-handle, stream and Philox key; there is no collective on the data path of step().  The only exchange is
+Environments are independent, so rank g of G owns the contiguous block [g*B_g, (g+1)*B_g) of the global batch with
+its own handle and stream (``VecSafeMotionsEnv(B_g, env_index_base=g * B_g)``: every draw of an env is keyed by
+(seed, global env index, its counters), so the shards are a partition of the global batch and their concatenation does
+not depend on the world size); there is no collective on the data path of step().  The only exchange is
 the concatenation of the rollout batch: ONE all-gather per step of a packed byte buffer
     [ obs float32 [B_g][O] | reward float32 [B_g] | done uint8 [B_g] | pad to 16 B ]
 (backend "nccl" is RCCL on ROCm; 7 xGMI links per GPU, so the gather is per-link bound: one call with
@@ -35,6 +37,30 @@ class PackedRollout:
         rew = flat[self.obs_bytes:self.obs_bytes + self.rew_bytes].view(t.float32)
         done = flat[self.obs_bytes + self.rew_bytes:self.obs_bytes + self.rew_bytes + self.B]
         return obs, rew, done
+
+
+class GatheredBatch:
+    """What ShardedRollout.step() returns in overlap mode: the per-rank (obs, reward, done) views of a gather that may still be in
+    flight.  Any read access (indexing, iteration, len) first makes the current stream wait for the collective, so a consumer
+    cannot see a partly written batch by accident; ``work`` is the collective's handle for callers that schedule the wait themselves."""
+
+    def __init__(self, parts, work):
+        self._parts, self.work = parts, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self._parts
+
+    def __getitem__(self, i):
+        return self.wait()[i]
+
+    def __iter__(self):
+        return iter(self.wait())
+
+    def __len__(self):
+        return len(self._parts)
 
 
 class ShardedRollout:
@@ -97,7 +123,8 @@ class ShardedRollout:
         return self._gather()
 
     def step(self, action):
-        """action: float32 [B_g, 7] for the local shard.  Returns [(obs, reward, done)] per rank (overlap: complete after wait())."""
+        """action: float32 [B_g, 7] for the local shard.  Returns [(obs, reward, done)] per rank (overlap: a GatheredBatch, whose
+        first read access waits for the collective)."""
         if not self.overlap:
             self.env.step(action)
             return self._gather()
@@ -110,7 +137,7 @@ class ShardedRollout:
         self._work[i] = self.dist.all_gather_into_tensor(self._gathereds[i], loc.flat, group=self.group, async_op=True)
         self._slot = i ^ 1
         n = loc.nbytes
-        return [loc.views(self._gathereds[i][r * n:(r + 1) * n]) for r in range(self.world)]
+        return GatheredBatch([loc.views(self._gathereds[i][r * n:(r + 1) * n]) for r in range(self.world)], self._work[i])
 
     def wait(self):
         """overlap: every gather in flight has landed (device backends: the current stream waits, not the host)"""

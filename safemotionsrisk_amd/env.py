@@ -47,7 +47,10 @@ class VecSafeMotionsEnv:
                     "braking_trajectory_executed", "target_point_reached", "moving_object_final_state", "risky_action")
 
     def __init__(self, num_envs, device=0, seed=None, auto_reset=True, collision_checks_per_step=None,
-                 contact_distance=None, return_info=True, env_index_offset=0, **env_config):
+                 contact_distance=None, return_info=True, env_index_base=0, **env_config):
+        """env_index_base: this handle owns the envs [env_index_base, env_index_base + num_envs) of a global batch that is
+        sharded over several handles / GPUs (dist.py): every draw of an env is keyed by (seed, GLOBAL env index, its counters), so
+        the shards together produce bit for bit what one handle over the whole batch produces."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("VecSafeMotionsEnv needs a GPU: the HIP library has no CPU path")
@@ -65,8 +68,11 @@ class VecSafeMotionsEnv:
         self.episode_counter = 0
         self._return_info = bool(return_info)
         self._seed = 0 if seed is None else int(seed)                           # base.py:1704-1710
-        self._device_index, self._env_index_offset = int(device), int(env_index_offset)
+        self._device_index, self._env_index_base = int(device), int(env_index_base)
+        if self._env_index_base < 0 or self._env_index_base + self.num_envs > 0xFFFFFFFF:
+            raise ValueError("env_index_base + num_envs must fit 32 bits")
         self._h = None
+        self._risk_nets, self._risk_threshold, self._profiling = None, 0.05, False
         self._create()
         B, O = self.num_envs, self.observation_size
         self.obs = torch.zeros((B, O), dtype=torch.float32, device=self.device)
@@ -80,8 +86,8 @@ class VecSafeMotionsEnv:
         with torch.cuda.device(self.device):
             self._stream = torch.cuda.current_stream(self.device)
             handle = C.c_void_p()
-            rc = self._L.smr_create(C.cast(self.scene.pointer(), C.c_void_p), self.num_envs, self._device_index,
-                                    C.c_uint64(self._seed + (self._env_index_offset << 32)),
+            rc = self._L.smr_create(C.cast(self.scene.pointer(), C.c_void_p), self.num_envs, C.c_uint32(self._env_index_base),
+                                    self._device_index, C.c_uint64(self._seed & 0xFFFFFFFFFFFFFFFF),
                                     C.c_void_p(self._stream.cuda_stream), C.byref(handle))
             _lib.check(self._L, None, rc, "smr_create")
         self._h = handle
@@ -95,6 +101,11 @@ class VecSafeMotionsEnv:
         self.close()
         self._create()
         self.episode_counter = 0
+        # the fresh handle knows nothing of what was configured on the old one: put it back (risk-aware stepping, profiling)
+        if self._risk_nets is not None and self._risk_nets[0] is not None:
+            self.set_risk_networks(*self._risk_nets, risk_threshold=self._risk_threshold)
+        if self._profiling:
+            self.set_profiling(True)
 
     def reset(self, mask=None):
         """obs = env.reset() for all envs (or those selected by a bool/uint8 mask tensor)."""
@@ -131,7 +142,7 @@ class VecSafeMotionsEnv:
         step(), where risk([risk observation, action]) >= risk_threshold the backup policy's deterministic action replaces the
         action.  risk / backup: policy.Mlp objects on this env's device (None, None switches it off); info column ``risky_action``
         reports it per step."""
-        self._risk_nets = (risk, backup)                # keep them alive
+        self._risk_nets, self._risk_threshold = (risk, backup), float(risk_threshold)   # kept alive, and re-applied by set_seed()
         rc = self._L.smr_set_risk_networks(self._h, None if risk is None else risk._h, None if backup is None else backup._h,
                                            C.c_float(float(risk_threshold)))
         _lib.check(self._L, self._h, rc, "smr_set_risk_networks")
@@ -195,6 +206,7 @@ class VecSafeMotionsEnv:
 
     # ---- profiling ----
     def set_profiling(self, enable):
+        self._profiling = bool(enable)
         _lib.check(self._L, self._h, self._L.smr_set_profiling(self._h, int(bool(enable))), "smr_set_profiling")
 
     def get_profile(self):

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "libsmr_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 INFO_N = 12
 K_COUNT = 7
 KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn", "brake", "risk")
@@ -37,7 +37,7 @@ class HostState(C.Structure):
 
 def _sources():
     return [os.path.join(CSRC, "smr_hip.hip"), os.path.join(CSRC, "smr_device.h"), os.path.join(CSRC, "smr_tables.h"),
-            os.path.join(INCLUDE, "safemotions_hip.h"), os.path.join(INCLUDE, "smr_scene.h")]
+            os.path.join(CSRC, "smr_mlp.h"), os.path.join(INCLUDE, "safemotions_hip.h"), os.path.join(INCLUDE, "smr_scene.h")]
 
 
 def build(force=False, verbose=False):
@@ -73,7 +73,7 @@ def load():
     L.smr_scene_sizeof.restype = C.c_size_t
     L.smr_last_error.restype = C.c_char_p
     L.smr_last_error.argtypes = [C.c_void_p]
-    L.smr_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.smr_create.argtypes = [C.c_void_p, C.c_int32, C.c_uint32, C.c_int32, C.c_uint64, C.c_void_p, C.POINTER(C.c_void_p)]
     L.smr_destroy.argtypes = [C.c_void_p]
     L.smr_num_envs.argtypes = [C.c_void_p]
     L.smr_obs_size.argtypes = [C.c_void_p]

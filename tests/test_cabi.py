@@ -41,7 +41,7 @@ def test_create_without_gpu_fails_loudly(built, space_scene):
         pytest.skip("GPU present")
     L = lib.load()
     h = C.c_void_p()
-    rc = L.smr_create(C.cast(space_scene.pointer(), C.c_void_p), 8, 0, 0, None, C.byref(h))
+    rc = L.smr_create(C.cast(space_scene.pointer(), C.c_void_p), 8, 0, 0, 0, None, C.byref(h))
     assert rc == -3 and not h.value
     assert b"no HIP device" in L.smr_last_error(None)
     from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
@@ -52,11 +52,13 @@ def test_create_without_gpu_fails_loudly(built, space_scene):
 def test_create_rejects_bad_scenes(built, space_scene):
     L = lib.load()
     h = C.c_void_p()
-    assert L.smr_create(None, 8, 0, 0, None, C.byref(h)) == -1
-    assert L.smr_create(C.cast(space_scene.pointer(), C.c_void_p), 0, 0, 0, None, C.byref(h)) == -1
+    assert L.smr_create(None, 8, 0, 0, 0, None, C.byref(h)) == -1
+    assert L.smr_create(C.cast(space_scene.pointer(), C.c_void_p), 0, 0, 0, 0, None, C.byref(h)) == -1
+    assert L.smr_create(C.cast(space_scene.pointer(), C.c_void_p), 8, 0xFFFFFFFC, 0, 0, None, C.byref(h)) == -1     # base + B beyond 32 bits
+    assert b"env_index_base" in L.smr_last_error(None)
     space_scene.struct.version += 1
     try:
-        assert L.smr_create(C.cast(space_scene.pointer(), C.c_void_p), 8, 0, 0, None, C.byref(h)) == -1
+        assert L.smr_create(C.cast(space_scene.pointer(), C.c_void_p), 8, 0, 0, 0, None, C.byref(h)) == -1
         assert b"version" in L.smr_last_error(None)
     finally:
         space_scene.struct.version -= 1

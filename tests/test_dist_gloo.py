@@ -70,6 +70,15 @@ def _worker(rank, world, port, q):
                     ref._fill()
                     ok &= torch.equal(pp[r][0], ref.obs) and torch.equal(pp[r][1], ref.reward) and torch.equal(pp[r][2], ref.done)
         roll2.wait()
+        # a consumer that reads the returned batch at once, without wait(): the first access waits for the collective itself
+        batch = roll2.step(torch.zeros(env2.num_envs, 7))
+        ok &= type(batch).__name__ == "GatheredBatch" and len(batch) == world
+        for r in range(world):
+            ref = StubEnv(r, env2.num_envs, 23)
+            ref.t = 6
+            ref._fill()
+            ok &= torch.equal(batch[r][0], ref.obs) and torch.equal(batch[r][2], ref.done)
+        ok &= batch.work is None                        # consumed by the read
         ok &= env2.obs.data_ptr() in (roll2._locals[0].flat.data_ptr(), roll2._locals[1].flat.data_ptr())
         obs, rew, done = roll.concatenated(parts)
         ok &= obs.shape == (world * env.num_envs, 23) and rew.shape == (world * env.num_envs,) and done.dtype == torch.uint8

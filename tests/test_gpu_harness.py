@@ -106,6 +106,10 @@ def test_step_before_reset_is_an_error_and_set_seed_rekeys(built):
     env.close()
 
 
+def _global_actions(n_envs, steps):
+    return np.random.default_rng(100).uniform(-1, 1, (steps, n_envs, 7)).astype(np.float32)
+
+
 def _shard_worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     import torch
@@ -116,13 +120,13 @@ def _shard_worker(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         B = 512
-        env = VecSafeMotionsEnv(B, device=0, seed=7, auto_reset=True, env_index_offset=rank, **SPACE_ENV_CONFIG)
+        env = VecSafeMotionsEnv(B, device=0, seed=7, auto_reset=True, env_index_base=rank * B, **SPACE_ENV_CONFIG)
         roll = ShardedRollout(env, host_gather=True)          # both ranks share the one GPU of the box: RCCL needs one device per rank
         parts = roll.reset()
         rec = [roll.concatenated(parts)[0].numpy().copy()]
-        gen = torch.Generator(device="cuda"); gen.manual_seed(100 + rank)
+        acts = _global_actions(world * B, 25)                  # this rank's block of the global batch's actions
         for t in range(25):
-            parts = roll.step(torch.rand((B, 7), device="cuda", generator=gen) * 2 - 1)
+            parts = roll.step(torch.from_numpy(acts[t, rank * B:(rank + 1) * B]).cuda())
             obs, rew, done = roll.concatenated(parts)
             rec.append(np.concatenate([obs.numpy(), rew.numpy()[:, None], done.numpy()[:, None].astype(np.float32)], axis=1))
             # this rank's slice of the gathered batch is what its env wrote
@@ -135,8 +139,10 @@ def _shard_worker(rank, world, port, out_path):
 
 
 def test_two_real_shards_through_one_process_group(built, tmp_path):
-    """two ranks, each stepping a real VecSafeMotionsEnv shard (env_index_offset = rank) on the GPU, one packed all-gather per
-    step: both ranks end up with the same concatenated (obs, reward, done) batch, whose halves differ (different Philox keys)."""
+    """two ranks, each stepping a real VecSafeMotionsEnv shard (env_index_base = rank x B) on the GPU, one packed all-gather per
+    step: both ranks end up with the same concatenated (obs, reward, done) batch - and that batch is BIT FOR BIT the one a single
+    handle over all 2 B envs produces (resets, auto-resets and 25 steps): shards are a partition of the global batch, the results do
+    not depend on the world size ("envs shard trivially ... only to concatenate the rollout batch")."""
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "shard%d.npz")
@@ -153,6 +159,18 @@ def test_two_real_shards_through_one_process_group(built, tmp_path):
     last = a[a.files[-1]]
     assert last.shape == (1024, 25) and not np.array_equal(last[:512], last[512:])
     assert sum(a[k][:, -1].sum() for k in a.files[1:]) > 512              # episodes ended in both shards
+    # the same global batch through ONE handle
+    import torch
+    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
+    env = VecSafeMotionsEnv(1024, device=0, seed=7, auto_reset=True, **SPACE_ENV_CONFIG)
+    assert np.array_equal(env.reset().cpu().numpy(), a[a.files[0]])
+    acts = _global_actions(1024, 25)
+    for t in range(25):
+        obs, rew, done, _ = env.step(torch.from_numpy(acts[t]).cuda())
+        one = np.concatenate([obs.cpu().numpy(), rew.cpu().numpy()[:, None], done.cpu().numpy()[:, None].astype(np.float32)], axis=1)
+        assert np.array_equal(one, a[a.files[1 + t]]), "step %d: the shards' batch differs from the single handle's" % t
+    env.synchronize()
+    env.close()
 
 
 def _overlap_worker(port, out_path):

@@ -619,6 +619,53 @@ def test_ragged_batches_give_the_same_envs(built, auto_reset):
     assert (np.abs(o1[same] - outs[63][1][same, :23]) < 1e-4).mean() > 0.99
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["space", "ball_bm", "reach"])
+def test_shards_are_a_partition_of_the_global_batch(built, scene):
+    """env_index_base (smr_create): a handle over the envs [base, base + B) of a global batch draws what ONE handle over the whole
+    batch draws for them - start states, planet phases, ball launches, target points, through resets, auto-resets and a masked
+    reset - so the concatenation of the shards' (obs, reward, done, reason, info) is bit-identical to the single handle's, for an
+    even and an uneven split (block-aligned bases: the wavefronts then hold the same envs; see test_ragged_batches for the rest).
+    North star: "envs shard trivially ... only to concatenate the rollout batch"."""
+    import torch
+    import safemotionsrisk_amd as smr
+    from safemotionsrisk_amd import VecSafeMotionsEnv
+    cfg = {"space": smr.SPACE_ENV_CONFIG, "ball_bm": dict(smr.BALL_ENV_CONFIG, ball_machine_mode=True), "reach": smr.REACH_ENV_CONFIG}[scene]
+    G, T = 1024, 25
+    acts = np.random.default_rng(8).uniform(-1, 1, (T, G, 7)).astype(np.float32)
+    acts[::4] = np.sign(acts[::4])                              # bang-bang steps: collisions and early terminations
+
+    def run(splits):
+        envs = [VecSafeMotionsEnv(hi - lo, device=0, seed=5, auto_reset=True, env_index_base=lo, **cfg) for lo, hi in splits]
+        rec = [np.concatenate([e.reset().cpu().numpy() for e in envs])]
+        for t in range(T):
+            rows = []
+            for e, (lo, hi) in zip(envs, splits):
+                obs, rew, done, info = e.step(torch.from_numpy(acts[t, lo:hi]).cuda())
+                rows.append(np.concatenate([obs.cpu().numpy(), rew.cpu().numpy()[:, None], done.cpu().numpy()[:, None].astype(np.float32),
+                                            info["termination_reason"].cpu().numpy()[:, None].astype(np.float32), info["values"].cpu().numpy()], axis=1))
+            rec.append(np.concatenate(rows))
+            if t == 12:                                         # a masked reset in the middle: every third env of the GLOBAL batch
+                obs_rows = []
+                for e, (lo, hi) in zip(envs, splits):
+                    mask = torch.from_numpy((np.arange(lo, hi) % 3 == 0)).cuda()
+                    obs_rows.append(e.reset(mask=mask).cpu().numpy())
+                rec.append(np.concatenate(obs_rows))
+        states = [e.get_state() for e in envs]
+        for e in envs:
+            e.close()
+        return rec, {k: np.concatenate([st[k] for st in states]) for k in states[0]}
+
+    one, st_one = run([(0, G)])
+    for splits in ([(0, 512), (512, 1024)], [(0, 256), (256, 768), (768, 1024)]):
+        rec, st = run(splits)
+        for t, (a, b) in enumerate(zip(one, rec)):
+            assert np.array_equal(a, b), (scene, splits, t, int((a != b).any(axis=1).sum()))
+        assert all(np.array_equal(st_one[k], st[k]) for k in st_one)
+    dones = sum(r[:, one[0].shape[1] + 1].sum() for r in one[1:] if r.shape[1] > one[0].shape[1])
+    assert dones > 100                                          # auto-resets happened inside the compared window
+
+
 def _scene_of(auto_reset):
     from safemotionsrisk_amd import SPACE_ENV_CONFIG, build_scene
     return build_scene(SPACE_ENV_CONFIG, auto_reset=auto_reset)
