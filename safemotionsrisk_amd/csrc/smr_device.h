@@ -22,6 +22,7 @@
 #ifndef SMR_DEV_COUNT         // cycle / count slots of the profiling build (smr_hip.hip, SMR_PROFILE_ROWS)
 #define SMR_DEV_CLOCK() 0ull
 #define SMR_DEV_COUNT(i, n)
+#define SMR_DEV_MAX(i, n)
 #define SMR_WAVE_REC(f, n)
 #endif
 
@@ -92,6 +93,10 @@ struct DScene {
     int n_self_pairs, self_pair[SMR_MAX_SELF_PAIRS][2];               // (body, partner body | -(world piece + 1))
     const uint32_t *body_pool;            // image of the reset-side kernels' LDS pool (body_pool_tables)
     int body_pool_dwords;
+    // pair-job path of the collide stage ("Pair jobs" below): on / off, and the LDS pool of its first / jobs kernels - like body_pool,
+    // with the hull tables of the bodies that take part in moving / contact / static queries only
+    int planets_jobs, job_pool_dwords;
+    const uint32_t *job_pool;
     int n_static, static_piece[SMR_MAX_STATIC];
     unsigned static_mask;
     float static_max;
@@ -201,6 +206,17 @@ struct DState {
     int *stale_commits;                // [1]  commits that found no matching staged state (must stay 0)
     int *error_flags;                  // [1]  kSampling* bits: a bounded rejection-sampling loop ran out of attempts (the reference raises
                                        //      ValueError there, ctlp.py:2127-2136); reported by the next synchronising call
+    // pair jobs (planet scenes, "Pair jobs" below): the step's GJK runs as independent (env, body, piece, sample) jobs in global lists
+    uint32_t *keyw;                    // [7][n_bodies][B] candidate key words of (env, body) at the end-of-step sample: keys -> first kernel
+    unsigned *env_best;                // [B] smallest (key << 16 | body << 8 | piece) over the env's bodies (atomicMin; ~0u: no candidate)
+    unsigned *env_min;                 // [B] float bits of the env's moving-obstacle distance: atomicMin over its jobs (non-negative floats
+                                       //     order like their bits); plan_kernel starts it at moving_max + 0.002
+    unsigned *env_dstatic;             // [B] ... of the static distance found by deferred table runs (starts at static_max)
+    unsigned long long *items;         // intermediate contact samples still to be tested: job words (env, body, k) of kind kJobItem
+    unsigned long long *jobs;          // GJK runs to make: job words (env, body, piece, k, kind)
+    int *item_count, *job_count;       // [1] each, cleared by plan_kernel
+    int job_cap;                       // capacity of jobs[]
+    int *overflow_env;                 // [B] 1: a job of this env found the list full - the overflow kernel works the env in the lane form
 };
 
 enum { kSamplingStart = 1, kSamplingPlanetPhase = 2, kSamplingBallLaunch = 4, kSamplingBallTarget = 8, kSamplingTargetPoint = 16,
@@ -724,15 +740,32 @@ struct ClimbHull {
         for (int guard = 0; guard < 256; ++guard) {
             const int g0 = (int)(sp & 0xffffu), g1 = g0 + (int)(sp >> 16);
             int nb = cur;
-            for (int g = g0; g < g1; ++g) {
+            // The first two id groups (a hull vertex has six neighbours on average) are fetched together and their eight vertices are
+            // all in flight at once: two dependent LDS round trips per step of the climb instead of four - the step is a latency chain.
+            // (The second word is read even when the vertex has one group - it lies inside the tables - but then not used.)
+            const uint32_t fa = ids4[g0], fb_raw = ids4[g0 + 1];
+            const uint32_t fb = g1 - g0 > 1 ? fb_raw : fa;
+            int id8[8];
+            float qx[8], qy[8], qz[8], qw[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                id8[k] = (int)(((k < 4 ? fa : fb) >> (8 * (k & 3))) & 255u);
+                qx[k] = v[4 * id8[k]]; qy[k] = v[4 * id8[k] + 1]; qz[k] = v[4 * id8[k] + 2]; qw[k] = v[4 * id8[k] + 3];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float sq = fmaf(qz[k], dl.z, fmaf(qy[k], dl.y, qx[k] * dl.x));
+                if (sq > best) { best = sq; nb = id8[k]; pv = F3{qx[k], qy[k], qz[k]}; sp = (uint32_t)__float_as_int(qw[k]); }
+            }
+            for (int g = g0 + 2; g < g1; ++g) {
                 const uint32_t four = ids4[g];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int id = (int)((four >> (8 * k)) & 255u);
                     const F3 q = {v[4 * id], v[4 * id + 1], v[4 * id + 2]};
-                    const float qw = v[4 * id + 3];
+                    const float qw1 = v[4 * id + 3];
                     const float sq = fmaf(q.z, dl.z, fmaf(q.y, dl.y, q.x * dl.x));
-                    if (sq > best) { best = sq; nb = id; pv = q; sp = (uint32_t)__float_as_int(qw); }
+                    if (sq > best) { best = sq; nb = id; pv = q; sp = (uint32_t)__float_as_int(qw1); }
                 }
             }
             if (nb == cur) break;
@@ -1639,7 +1672,8 @@ struct LaneInput {
     float lb_start;                                     // lower bound of the moving-piece distance at t = 0 (the previous step's lb_end; < 0: none)
 };
 // k_first .. k_need: the intermediate samples that still need a test (empty when k_first > k_need); lb_end: the bound at t = dt
-struct LaneResult { bool contact; float d_static, d_moving; int k_first, k_need; float lb_end; };
+struct LaneResult { bool contact; float d_static, d_moving; int k_first, k_need; float lb_end; bool static_pending;
+                    unsigned best; float ub; };   // KEYS_ONLY: the best candidate (key << 5 | piece; ~0u: none) and an upper bound of ITS distance
 
 // frame of body l at time t of the step's cubic
 template <bool SELF, bool FAST = false>
@@ -1654,10 +1688,28 @@ __device__ __forceinline__ Xf lane_frame(const DScene &S, int l, const LaneInput
     return T;
 }
 
-template <bool SELF, bool AUTO, class HB>
+// KEYS_ONLY (the keys kernel of the pair-job path): no GJK run against a moving piece is made - the lane leaves its candidate keys (and
+// the pending table run, static_pending) to the job kernels, and plans its intermediate samples from the key bounds alone
+// the same for a body index that differs between the lanes (job kernels): the 28 state words are loaded up front, all in flight at once
+// (in the loop above a lane-dependent trip count keeps the compiler from hoisting them: seven dependent round trips to HBM), and
+// the chain is walked with the joint loop unrolled under the lane's predicate
+template <bool FAST>
+__device__ inline Xf lane_frame_any(const DScene &S, int b, const LaneInput &in, float t) {
+    float qs[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt);
+    const int link = b < SMR_NLINK ? b : SMR_NLINK - 1;
+    Xf T = fk_base(S);
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j)
+        if (j < link) { if (FAST) fk_advance_fast(S, j, qs[j], T); else fk_advance(S, j, qs[j], T); }
+    return b < SMR_NLINK ? T : mounted_frame(S, b, T);
+}
+
+template <bool SELF, bool AUTO, bool KEYS_ONLY = false, class HB>
 __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &LP, const HB &hull, const LaneInput &in,
                                           const float *lds_pv, const float *lds_pd, uint32_t *keys, int kstride) {
-    LaneResult out = {false, S.static_max, S.moving_max + 0.002f, 1, 0, -1.f};
+    LaneResult out = {false, S.static_max, S.moving_max + 0.002f, 1, 0, -1.f, false, 0xFFFFFFFFu, 3.0e38f};
     const int N = S.checks_per_step, upd = S.updates_per_step / N;
     const bool con_link = (S.contact_mask >> l) & 1u;
     bool want_contact, sweep_contact, moving_alive = true;
@@ -1677,7 +1729,12 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
     if (k_last < 1) sweep_contact = false;
     const bool want_static = (S.static_mask >> l) & 1u;
     const bool want_moving = moving_alive && ((S.moving_mask >> l) & 1u);
-    if (!(want_static || want_moving || want_contact || sweep_contact)) return out;
+    if (!(want_static || want_moving || want_contact || sweep_contact)) {
+        if (KEYS_ONLY)
+#pragma unroll
+            for (int w = 0; w < 7; ++w) keys[w * kstride] = 0xFFFFFFFFu;
+        return out;
+    }
     const Xf T = lane_frame<SELF>(S, l, in, S.dt);
     float lb = -1.f;                                    // lower bound of the distance to every moving piece at t = dt (< 0: none)
     Sample r;
@@ -1701,7 +1758,47 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
             const unsigned long long c1 = SMR_DEV_CLOCK();
             lb = planet_keys(S, keys, kstride, LP, T, idx, want_moving || want_contact, cutoff_max);
             const unsigned long long c2 = SMR_DEV_CLOCK();
-            planet_gjk(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, want_contact, S.moving_max, r, static_pending);
+            if (KEYS_ONLY) {
+                out.static_pending = static_pending;
+                // The best candidate (smallest key) and an UPPER bound of its distance from ONE pair of support points - the vector GJK's
+                // first iteration would produce, a point of the Minkowski difference.  The minimum of these bounds over the env's bodies
+                // prunes the env's pairs nearly as well as the exact distance of its best pair (4.6 pairs per env survive instead of
+                // 3.8, uniformly drawn states) and costs no kernel of its own.
+                uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int w = 0; w < 7; ++w) {
+                    const uint32_t kw = keys[w * kstride];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t cand = (((kw >> (8 * b)) & 0xFFu) << 5) | (uint32_t)(4 * w + b);
+                        best = cand < best ? cand : best;
+                    }
+                }
+                if ((best >> 5) != 255u && want_moving) {
+                    const int c = (int)(best & 31u);
+                    const float *d = lds_pd + kPlanetDescDwords * c;
+                    const float *av = lds_pv + 4 * __float_as_int(d[0]);
+                    const int ac = __float_as_int(d[1]), p = __float_as_int(d[3]);
+                    const Xf XA = inv_compose(T, quat_pose((const SMR_GLOBAL float *)(p ? S.planet[1].orbit_pose : S.planet[0].orbit_pose) + 8 * (size_t)(p ? idx[1] : idx[0])));
+                    const F3 v = apply(XA, F3{d[4], d[5], d[6]}) - F3{LP.cx, LP.cy, LP.cz};      // piece centre - body centre, body frame
+                    const F3 dl = rot_t(XA, neg(v));
+                    float bs = -3.0e38f;
+                    int bi = 0;
+                    for (int i = 0; i < ac; i += 4)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float *q = av + 4 * (i + u);
+                            const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
+                            const bool gt = sq > bs;
+                            bs = gt ? sq : bs;
+                            bi = gt ? i + u : bi;
+                        }
+                    int hint = 0;
+                    const F3 w = apply(XA, F3{av[4 * bi], av[4 * bi + 1], av[4 * bi + 2]}) - hull.support(v, hint, true);
+                    out.ub = (sqrtf(dot(w, w)) - (d[2] + LP.margin)) * 1.00001f + 1e-6f;
+                }
+                out.best = (best >> 5) != 255u ? best : 0xFFFFFFFFu;
+            } else planet_gjk(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, want_contact, S.moving_max, r, static_pending);
             SMR_DEV_COUNT(16, c1 - c0); SMR_DEV_COUNT(17, c2 - c1); SMR_DEV_COUNT(18, SMR_DEV_CLOCK() - c2);
             SMR_WAVE_REC(0, (c1 - c0) >> 4); SMR_WAVE_REC(1, (c2 - c1) >> 4); SMR_WAVE_REC(2, (SMR_DEV_CLOCK() - c2) >> 4);
             if (!(want_moving || want_contact)) lb = -1.f;
@@ -1761,6 +1858,142 @@ __device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, co
     Sample r = collide_link(S, l, LP, hull, T, idx, nullptr, false, false, live, nullptr, AUTO);
     if (AUTO) planet_queries_auto(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, false, live, r);
     return r.contact;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pair jobs (planet scenes).  In the lane-per-(env, body) loop above a wavefront runs as long as its busiest lane - a body next to
+// the station works through ten pieces one after the other while 63 lanes wait - and every body of an env prunes with its OWN
+// running minimum although only the minimum over the bodies is asked for (finish_kernel; ctlp.py:3263-3278).  Here a step's GJK runs
+// are independent jobs (env, body, piece, sample) in a global list, one lane each:
+//   keys kernel   (env, body) lanes: frame at t = dt, table bounds / shortcut, candidate keys of the 25 planet pieces -> keyw, the env's
+//                 best (smallest) key by atomicMin -> env_best, the intermediate contact samples that survive the sweep bounds -> items
+//   first kernel  one lane per env: the GJK run of the env's best pair.  Its distance d1 bounds the env's minimum from above, so only
+//                 the pairs whose key bound does not exceed d1 can matter: they become jobs (2.9 per env on uniformly drawn states,
+//                 8.7 GJK iterations per env in all instead of 19).  One lane per item: the bound test at its sample; the pieces
+//                 that do not clear the contact distance become jobs.
+//   jobs kernel   one lane per job, cutoff = the env's running minimum at that time; results by atomicMin (moving / static distance)
+//                 and plain stores of 1 (contact flags) - both independent of the order the jobs run in, so the step stays
+//                 deterministic and equal to the lane form up to rounding.
+// The critical path of the step is one GJK run, not the longest lane's list of runs.
+// ---------------------------------------------------------------------------------------------
+enum { kJobPlanetEnd = 0, kJobItem = 1, kJobStaticEnd = 2 };
+__device__ __forceinline__ unsigned long long job_word(int env, int body, int piece, int k, int kind) {
+    return (unsigned long long)(unsigned)env | ((unsigned long long)body << 32) | ((unsigned long long)piece << 36) |
+           ((unsigned long long)k << 42) | ((unsigned long long)kind << 47);
+}
+struct Job { int env, body, piece, k, kind; };
+__device__ __forceinline__ Job job_unpack(unsigned long long w) {
+    return {(int)(unsigned)(w & 0xFFFFFFFFull), (int)((w >> 32) & 15ull), (int)((w >> 36) & 63ull), (int)((w >> 42) & 31ull), (int)((w >> 47) & 7ull)};
+}
+__device__ __forceinline__ unsigned dist_bits(float d) { return (unsigned)__float_as_int(fmaxf(d, 0.f)); }   // below 1 mm only "d < 0.001" is defined
+
+// per-lane candidate pieces of the planets for body (LP under T) at orbit indices idx: emit(c) for every piece c (index into the planet
+// descriptors) whose lower bound - the larger of sphere-sphere and capsule-capsule, as planet_keys - does not exceed cutoff.
+// LP / T differ between the lanes; the piece loop is wave uniform (scalar piece loads).
+template <class EMIT>
+__device__ inline void planet_candidates(const DScene &S, const DPiece &LP, const Xf &T, const int idx[SMR_MAX_PLANETS], bool live, float cutoff,
+                                         const EMIT &emit) {
+    const F3 lc = apply(T, F3{LP.cx, LP.cy, LP.cz});
+    const F3 l0 = apply(T, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), l1 = apply(T, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
+    for (int p = 0; p < S.n_planets; ++p) {
+        const Xf X = planet_pose(S, p, idx[p]);
+        const F3 e = apply(X, F3{S.planet[p].bx, S.planet[p].by, S.planet[p].bz}) - lc;
+        const float lbw = __builtin_amdgcn_sqrtf(dot(e, e)) * 0.99999f - 1e-6f - S.planet[p].bradius - LP.radius - LP.margin;
+        const bool near = live && lbw <= cutoff;
+        if (!__any(near)) continue;
+        const int pb = S.planet[p].piece_begin, pc = S.planet[p].piece_count;
+        for (int c = 0; c < pc; ++c) {
+            const DPiece PP = load_piece(S.pieces, pb + c);
+            const float margins = PP.margin + LP.margin;
+            const F3 dc = apply(X, F3{PP.cx, PP.cy, PP.cz}) - lc;
+            const float lb_s = __builtin_amdgcn_sqrtf(dot(dc, dc)) * 0.99999f - 1e-6f - PP.radius - LP.radius - margins;
+            if (near && lb_s <= cutoff) {
+                const F3 a0 = apply(X, F3{PP.cap_a[0], PP.cap_a[1], PP.cap_a[2]}), a1 = apply(X, F3{PP.cap_b[0], PP.cap_b[1], PP.cap_b[2]});
+                const float lb_c = __builtin_amdgcn_sqrtf(seg_seg_dist2(a0, a1, l0, l1)) * 0.99999f - 1e-6f - PP.cap_r - LP.cap_r - margins;
+                if (lb_c <= cutoff) emit(pb + c - S.planet_p0);
+            }
+        }
+    }
+}
+
+// One lane's GJK run of a job: set up from the job word, advanced by one iteration per trip of the wavefront's loop (gjk_iterate: the
+// same tests in the same order as planet_gjk, in the same frames - planet pieces in the LINK frame, the table in the world frame).
+struct JobLane {
+    GjkRun g;
+    Xf XA, T;                    // planet piece seen from the body frame | the body's world frame (table runs)
+    LocalHull hull;
+    const float *av; int ac;
+    float margins;
+    bool is_static;
+};
+
+template <bool SELF>
+__device__ inline void job_setup(const DScene &S, const BodyPool &BP, const float *pv, const float *pd, const LaneInput &in, const Job &jb,
+                                 float cutoff, float stop_below, JobLane &J) {
+    const int N = S.checks_per_step, upd = S.updates_per_step / N;
+    const float t = jb.k >= N ? S.dt : S.dt * (float)jb.k / (float)N;
+    const unsigned long long ps0 = SMR_DEV_CLOCK();
+    J.T = lane_frame_any<false>(S, jb.body, in, t);
+    const unsigned long long ps1 = SMR_DEV_CLOCK();
+    const DPiece LP = BP.piece(jb.body);
+    J.hull = BP.hull(jb.body);
+    const unsigned long long ps2 = SMR_DEV_CLOCK();
+    SMR_DEV_COUNT(8, ps1 - ps0); SMR_DEV_COUNT(9, ps2 - ps1); (void)ps0; (void)ps1;
+    const float *d = pd + kPlanetDescDwords * jb.piece;
+    J.av = pv + 4 * __float_as_int(d[0]);
+    J.ac = __float_as_int(d[1]);
+    J.margins = d[2] + LP.margin;
+    J.is_static = jb.kind == kJobStaticEnd;
+    const F3 lcl = {LP.cx, LP.cy, LP.cz};
+    if (J.is_static) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) J.XA.r[i] = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+        J.XA.t = F3{0.f, 0.f, 0.f};
+        J.g.start(F3{d[4], d[5], d[6]} - apply(J.T, lcl), cutoff + J.margins, stop_below + J.margins);
+    } else {
+        const int p = __float_as_int(d[3]);
+        const int i0 = (in.planet_idx[0] + jb.k * upd) % S.planet[0].n_orbit;
+        const int i1 = S.n_planets > 1 ? (in.planet_idx[1] + jb.k * upd) % S.planet[1].n_orbit : 0;
+        J.XA = inv_compose(J.T, quat_pose((const SMR_GLOBAL float *)(p ? S.planet[1].orbit_pose : S.planet[0].orbit_pose) + 8 * (size_t)(p ? i1 : i0)));
+        J.g.start(apply(J.XA, F3{d[4], d[5], d[6]}) - lcl, cutoff + J.margins, stop_below + J.margins);
+    }
+    SMR_DEV_COUNT(10, SMR_DEV_CLOCK() - ps2); (void)ps2;
+}
+
+// one iteration; true when the run is settled, dist = distance with the margins subtracted
+__device__ __forceinline__ bool job_trip(JobLane &J, float &dist) {
+    const auto sb = [&](F3 d, int &hint, bool first) {
+        const unsigned long long t0 = SMR_DEV_CLOCK();
+        const F3 p = J.hull.support(J.is_static ? rot_t(J.T, d) : d, hint, first);
+        (void)t0;
+        return J.is_static ? apply(J.T, p) : p;
+    };
+    const auto sa = [&](F3 d, int &, bool) {
+        const unsigned long long t0 = SMR_DEV_CLOCK();
+        const F3 dl = rot_t(J.XA, d);
+        float best = -3.0e38f;
+        int bi = 0;
+        for (int i = 0; i < J.ac; i += 8) {                // padded to multiples of 8: eight vertex reads in flight per round trip
+            float sq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float *q = J.av + 4 * (i + u);
+                sq[u] = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool gt = sq[u] > best;
+                best = gt ? sq[u] : best;
+                bi = gt ? i + u : bi;
+            }
+        }
+        (void)t0;
+        return apply(J.XA, F3{J.av[4 * bi], J.av[4 * bi + 1], J.av[4 * bi + 2]});
+    };
+    float d;
+    if (!gjk_iterate(J.g, sa, sb, d)) return false;
+    dist = d - J.margins;
+    return true;
 }
 
 // A15: planet part of the observation (obs.py:262-292)

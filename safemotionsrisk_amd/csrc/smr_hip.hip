@@ -27,6 +27,7 @@ __device__ unsigned long long g_row_cycles[128];
 __device__ unsigned g_wave_rec[8 * 65536];
 #define SMR_DEV_CLOCK() __builtin_readcyclecounter()
 #define SMR_DEV_COUNT(i, n) do { if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) { atomicAdd(&g_row_cycles[32 + (i)], (unsigned long long)(n)); atomicAdd(&g_row_cycles[96 + (i)], 1ull); } } while (0)
+#define SMR_DEV_MAX(i, n) do { if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) { atomicMax(&g_row_cycles[32 + (i)], (unsigned long long)(n)); atomicAdd(&g_row_cycles[96 + (i)], 1ull); } } while (0)
 // field f (0..7) of this wavefront's record
 #define SMR_WAVE_REC(f, n) do { const unsigned w_ = ((blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)); \
                                 if (w_ < 65536u && (int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) g_wave_rec[8 * w_ + (f)] += (unsigned)(n); } while (0)
@@ -53,6 +54,13 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     safe_acc_range_joint<64>(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code, live);
     if (!live) return;
     if (j == 0 && S.check_braking) st.braked[e] = 0;   // set by brake_check_kernel
+    if (j == 0 && S.planets_jobs) {                    // the accumulators and lists of this step's pair jobs (keys / first / jobs kernels)
+        st.env_best[e] = 0xFFFFFFFFu;
+        st.env_min[e] = dist_bits(S.moving_max + 0.002f);
+        st.env_dstatic[e] = dist_bits(S.static_max);
+        st.overflow_env[e] = 0;
+        if (e == 0) { *st.item_count = 0; *st.job_count = 0; }
+    }
     float u = actions[(size_t)e * SMR_NJ + j];
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
 }
@@ -280,6 +288,302 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     if (valid) st.res[(size_t)l * B + e] = contact ? 1.f : 0.f;
 }
 
+// ---- pair-job path of the collide stage (planet scenes; smr_device.h "Pair jobs") ----
+__device__ __forceinline__ LaneInput load_lane_input(const DScene &S, const DState &st, int env) {
+    const int B = S.B;
+    LaneInput in;
+    in.q = st.q + env; in.v = st.v + env; in.a = st.a + env; in.a1 = st.a1 + env; in.stride = B;
+    in.planet_idx[0] = st.planet_idx[env]; in.planet_idx[1] = st.planet_idx[B + env];
+    in.moving_hit = st.moving_hit[env];
+    in.ball_k0 = 0; in.ball_kmax = 0; in.ball_khit = 0; in.ball_active = 0; in.lb_start = -1.f;
+    return in;
+}
+
+// keys kernel: the collide kernel's grid and prologue (one lane per (env, body), the body's hull in LDS for the table shortcut; the
+// self-collision pair rows as there), but no GJK run against a moving piece: keys, best key, items and the pending table run go to
+// the lists the first / jobs kernels work off
+template <bool SELF>
+__global__ __launch_bounds__(256) void keys_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    constexpr int kBlock = 256;
+    const bool pair_block = SELF && (int)blockIdx.y >= S.n_bodies;
+    const int pair = pair_block ? S.pair_order[(int)blockIdx.y - S.n_bodies] : 0;
+    const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0]) : S.body_order[(int)blockIdx.y];
+    const int B = S.B, N = S.checks_per_step, NB = S.n_bodies;
+    if (!pair_block) {
+        const bool any = (((S.static_mask | S.moving_mask | S.contact_mask) >> l) & 1u) || SELF;
+        if (!any) {
+            const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+            if (e0 < B) {
+                st.dist[(size_t)l * B + e0] = S.static_max; st.dist[(size_t)(NB + l) * B + e0] = S.moving_max + 0.002f;
+                st.res[(size_t)l * B + e0] = 0.f;
+                if (N > 1) st.lb_moving[(size_t)l * B + e0] = -1.f;
+            }
+            return;
+        }
+    }
+    __shared__ float lds_v[4 * kMaxPieceVerts];
+    __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
+    __shared__ uint32_t lds_start[kStartCells / 4];
+    __shared__ uint32_t lds_keys[7 * kBlock];
+    __shared__ float lds_pv[4 * kMaxPlanetVerts];
+    __shared__ float lds_pd[kPlanetDescDwords * kMaxPlanetPieces];
+    const int pl = S.link_piece[l];
+    const DPiece LP = load_piece(S.pieces, pl);
+    {                                                                   // the hull: table shortcut, pair rows, upper bound of the best candidate
+        const SMR_GLOBAL float4 *gv = (const SMR_GLOBAL float4 *)S.verts + LP.begin;
+        const SMR_GLOBAL uint32_t *gi = (const SMR_GLOBAL uint32_t *)S.ids4 + LP.ids_begin,
+                                  *gm = (const SMR_GLOBAL uint32_t *)S.start + (kStartCells / 4) * (size_t)pl;
+        for (int i = threadIdx.x; i < LP.count; i += kBlock) {
+            const SMR_GLOBAL float *f = (const SMR_GLOBAL float *)(gv + i);
+            lds_v[4 * i] = f[0]; lds_v[4 * i + 1] = f[1]; lds_v[4 * i + 2] = f[2]; lds_v[4 * i + 3] = f[3];
+        }
+        for (int i = threadIdx.x; i < LP.ids_count; i += kBlock) lds_ids[i] = gi[i];
+        for (int i = threadIdx.x; i < kStartCells / 4; i += kBlock) lds_start[i] = gm[i];
+        if (!pair_block) stage_planets(S, threadIdx.x, kBlock, lds_pv, lds_pd);
+        __syncthreads();
+    }
+    const LocalHull hull{lds_v, lds_ids, (const uint8_t *)lds_start};
+    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = e0 < B;
+    const int e = valid ? e0 : B - 1;
+    if (SELF && pair_block) {
+        if (!valid) return;
+        float qs[SMR_NJ];
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], S.dt, S.dt);
+        const int a = S.self_pair[pair][0], partner = S.self_pair[pair][1];
+        const int link_a = a < SMR_NLINK ? a : SMR_NLINK - 1;
+        Xf Ta = fk_base(S), Tp = Ta;
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) {
+            if (j == partner) Tp = Ta;
+            if (j < link_a) fk_advance(S, j, qs[j], Ta);
+        }
+        if (partner >= link_a) Tp = body_frame(S, qs, partner);
+        if (a >= SMR_NLINK) Ta = mounted_frame(S, a, Ta);
+        float d;
+        if (partner >= 0) d = piece_distance<false>(S, S.link_piece[a], Ta, LP, hull, Tp, S.static_max, S.collision_dist);
+        else d = self_pair_distance(S, pair, qs, LP, hull, Ta, S.static_max, S.collision_dist);
+        st.dist[(size_t)(2 * NB + pair) * B + e] = d <= S.static_max ? d : S.static_max;
+        return;
+    }
+    LaneInput in = load_lane_input(S, st, e);
+    in.lb_start = (N > 1 && st.step_count[e] > 0) ? st.lb_moving[(size_t)l * B + e] : -1.f;
+    const LaneResult r = collide_lane<SELF, true, true>(S, l, LP, hull, in, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock);
+    if (valid) {
+        st.dist[(size_t)l * B + e] = r.d_static; st.dist[(size_t)(NB + l) * B + e] = S.moving_max + 0.002f;
+        st.res[(size_t)l * B + e] = 0.f;
+        if (N > 1) st.lb_moving[(size_t)l * B + e] = r.lb_end;
+        // the candidate keys of this (env, body) for the enumeration, and the upper bound of its best candidate: the env's moving
+        // distance cannot exceed it
+#pragma unroll
+        for (int w = 0; w < 7; ++w) st.keyw[((size_t)w * NB + l) * B + e] = lds_keys[w * kBlock + threadIdx.x];
+        if (r.best != 0xFFFFFFFFu) {
+            st.env_best[e] = 1u;                             // some body of the env has a candidate
+            if (r.ub <= S.moving_max) atomicMin(&st.env_min[e], dist_bits(r.ub));
+        }
+        if (r.static_pending) {                              // the table's GJK run (one lane in a hundred): a job of its own
+            const int slot = atomicAdd(st.job_count, 1);     // never full here: the list holds B x n_bodies entries before the first kernel adds any
+            if (slot < st.job_cap) st.jobs[slot] = job_word(e, l, S.auto_static, N, kJobStaticEnd);
+        }
+    }
+    if (N > 1) {
+        // the samples k_first .. k_need of every lane go to the global item list, one atomic per wavefront
+        const int n = (valid && r.k_need >= r.k_first) ? r.k_need - r.k_first + 1 : 0;
+        if (__any(n > 0)) {
+            const int lane = (int)__lane_id();
+            int incl = n;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            const int total = __shfl(incl, 63);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(st.item_count, total);
+            base = __shfl(base, 0);
+            for (int k = 0; k < n; ++k) st.items[(size_t)base + incl - n + k] = job_word(e, l, 0, r.k_first + k, kJobItem);
+        }
+    }
+}
+
+// tables of the first / jobs kernels in dynamic LDS: the hull pool of the bodies that take part in moving / static queries
+// (DScene::job_pool), the planets' padded vertex lists and descriptors (+ the table's corners)
+extern __shared__ uint32_t job_lds[];
+struct JobTables { BodyPool BP; const float *pv, *pd; };
+__device__ __forceinline__ JobTables stage_job_tables(const DScene &S) {
+    uint32_t *pool = job_lds;
+    float *pv = (float *)(job_lds + S.job_pool_dwords), *pd = pv + 4 * S.auto_vn;
+    const SMR_GLOBAL uint32_t *g = (const SMR_GLOBAL uint32_t *)S.job_pool;
+    for (int i = threadIdx.x; i < S.job_pool_dwords; i += blockDim.x) pool[i] = g[i];
+    stage_planets(S, threadIdx.x, blockDim.x, pv, pd);
+    __syncthreads();
+    return {BodyPool{pool}, pv, pd};
+}
+
+// what a job of (env state `in`, body) looks for: the distance of the reward (mov) and / or the contact latch (con) - collide_lane's rules
+__device__ __forceinline__ void job_flags(const DScene &S, const LaneInput &in, int body, bool &mov, bool &con) {
+    mov = (S.moving_mask >> body) & 1u;
+    con = S.term_moving && S.n_planets > 0 && in.moving_hit == 0 && ((S.contact_mask >> body) & 1u);
+}
+
+// the result of a settled job.  Atomic minima on the bits of non-negative floats and stores of 1: independent of the order of the jobs.
+__device__ __forceinline__ void job_result(const DScene &S, const DState &st, const Job &jb, bool mov, bool con, float d) {
+    const int B = S.B;
+    if (jb.kind == kJobStaticEnd) { if (d <= S.static_max) atomicMin(&st.env_dstatic[jb.env], dist_bits(d)); return; }
+    if (mov && d <= S.moving_max) atomicMin(&st.env_min[jb.env], dist_bits(d));
+    if (con && d <= S.contact_dist) st.res[(size_t)jb.body * B + jb.env] = 1.f;
+}
+
+// cutoff and early-stop distance of a job (planet_gjk's rules; an item only asks "within the contact distance?")
+__device__ __forceinline__ void job_limits(const DScene &S, const Job &jb, bool mov, bool con, float env_min, float &cutoff, float &stop) {
+    if (jb.kind == kJobStaticEnd) { cutoff = S.static_max; stop = S.collision_dist; return; }
+    if (jb.kind == kJobItem) { cutoff = S.contact_dist; stop = S.contact_dist; return; }
+    cutoff = mov ? fminf(env_min, S.moving_max) : S.contact_dist;
+    if (con) cutoff = fmaxf(cutoff, S.contact_dist);
+    stop = con ? S.contact_dist : S.collision_dist;
+}
+
+// Append the jobs (env, body b, piece of every set bit of masks[b], k, kind) of all lanes of the wavefront: ONE atomic on the list
+// counter per call (a counter hit by every lane's every job serialises in the L2: 190 000 atomics per step cost 0.7 ms, measured).
+// All lanes must call together.  A full list is not an error: the env is handed to the overflow kernel, which works ALL its queries
+// in the lane form (a second GJK loop inline here costs the hot kernels 300 - 2400 spilled registers, measured).
+template <int NM>
+__device__ __forceinline__ void push_jobs(const DState &st, int env, const int (&bodies)[NM], const uint32_t (&masks)[NM], int k, int kind) {
+    const int lane = (int)__lane_id();
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) n += __popc(masks[i]);
+    if (!__any(n > 0)) return;
+    int incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+    const int total = __shfl(incl, 63);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(st.job_count, total);
+    base = __shfl(base, 0) + incl - n;
+    if (n > 0 && base + n > st.job_cap) st.overflow_env[env] = 1;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        uint32_t mask = masks[i];
+        while (mask) {
+            const int piece = __ffs((int)mask) - 1;
+            mask &= mask - 1;
+            if (base < st.job_cap) st.jobs[base] = job_word(env, bodies[i], piece, k, kind);
+            ++base;
+        }
+    }
+}
+
+#ifndef SMR_JOB_WAVES
+#define SMR_JOB_WAVES 4
+#endif
+
+// chunk c of 64 tasks is worked by wavefront ((c / gridDim.x) % waves per block) of block (c % gridDim.x): the chunks spread over all
+// blocks of the persistent grid before a block gets its second one
+#define SMR_CHUNK_LOOP(n_chunks) for (int c = (int)blockIdx.x + (int)gridDim.x * (int)(threadIdx.x >> 6); c < (n_chunks); c += (int)gridDim.x * (int)(blockDim.x >> 6))
+
+// enumerate kernel (no GJK, no LDS).  Blocks [0, env_blocks): one lane per env - every pair of the env whose key bound does not exceed
+// the upper bound the keys kernel left in env_min (or, for a body that is tested for contact, the contact distance) becomes a job.
+// The blocks behind them stride over the item list: the bound test of one intermediate contact sample per lane; the pieces it cannot
+// clear become jobs.
+template <bool SELF>
+__global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict__ Sp, DState st, int env_blocks) {
+    const DScene &S = *Sp;
+    const int B = S.B, N = S.checks_per_step, NB = S.n_bodies;
+    if ((int)blockIdx.x < env_blocks) {
+        const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = e0 < B;
+        const int e = valid ? e0 : B - 1;
+        const bool has = valid && st.env_best[e] != 0xFFFFFFFFu;
+        const LaneInput in = load_lane_input(S, st, e);
+        const float cut_first = fminf(__uint_as_float(st.env_min[e]), S.moving_max);
+        int bodies[SMR_MAX_BODIES];
+        uint32_t masks[SMR_MAX_BODIES];
+#pragma unroll
+        for (int b = 0; b < SMR_MAX_BODIES; ++b) {
+            bodies[b] = b; masks[b] = 0u;
+            if (b >= NB || !(((S.moving_mask | S.contact_mask) >> b) & 1u)) continue;
+            bool mov2, con2;
+            job_flags(S, in, b, mov2, con2);
+            float cutoff = mov2 ? cut_first : S.contact_dist;
+            if (con2) cutoff = fmaxf(cutoff, S.contact_dist);
+            if (has && (mov2 || con2)) {
+                uint32_t kws[7];
+#pragma unroll
+                for (int w = 0; w < 7; ++w) kws[w] = st.keyw[((size_t)w * NB + b) * B + e];      // seven loads in flight
+                uint32_t mask = 0u;
+#pragma unroll
+                for (int w = 0; w < 7; ++w)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t key = (kws[w] >> (8 * k)) & 0xFFu;
+                        if (key != 255u && (float)key * kKeyStep <= cutoff) mask |= 1u << (4 * w + k);
+                    }
+                masks[b] = mask;
+            }
+        }
+        push_jobs(st, e, bodies, masks, N, kJobPlanetEnd);
+        return;
+    }
+    const int n_items = N > 1 ? *st.item_count : 0, stride = ((int)gridDim.x - env_blocks) * (int)blockDim.x;
+    const int rounds = (n_items + stride - 1) / stride;                 // block uniform: the lanes of a wavefront append together
+    for (int r = 0; r < rounds; ++r) {
+        const int i = r * stride + ((int)blockIdx.x - env_blocks) * (int)blockDim.x + (int)threadIdx.x;
+        const bool valid = i < n_items;
+        const Job it = job_unpack(st.items[valid ? i : 0]);
+        const LaneInput in = load_lane_input(S, st, it.env);
+        const Xf T = lane_frame_any<true>(S, it.body, in, S.dt * (float)it.k / (float)N);      // bounds: hardware sine / cosine, covered by the slack
+        constexpr float kBoundSlack = 1e-4f;
+        const int upd = S.updates_per_step / N;
+        int idx[SMR_MAX_PLANETS] = {0, 0};
+#pragma unroll
+        for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+            if (p < S.n_planets) idx[p] = (in.planet_idx[p] + it.k * upd) % S.planet[p].n_orbit;
+        const DPiece LP = load_piece_lane(S.pieces, S.link_piece[it.body]);
+        uint32_t masks[1] = {0u};
+        const int bodies[1] = {it.body};
+        planet_candidates(S, LP, T, idx, valid, S.contact_dist + kBoundSlack, [&](int piece) { masks[0] |= 1u << piece; });
+        push_jobs(st, it.env, bodies, masks, it.k, kJobItem);
+    }
+}
+
+// jobs kernel: one lane per job of the list
+template <bool SELF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    const unsigned long long pc0 = SMR_DEV_CLOCK();
+    const JobTables JT = stage_job_tables(S);
+    SMR_DEV_COUNT(26, SMR_DEV_CLOCK() - pc0); (void)pc0;
+    const int lane = (int)__lane_id();
+    const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
+    const int n_chunks = (n_jobs + 63) / 64;
+    SMR_CHUNK_LOOP(n_chunks) {
+        const unsigned long long pc1 = SMR_DEV_CLOCK();
+        int prof_trips = 0;
+        const int j = 64 * c + lane;
+        bool active = j < n_jobs;
+        const Job jb = job_unpack(st.jobs[active ? j : 0]);
+        const LaneInput in = load_lane_input(S, st, jb.env);
+        bool mov, con;
+        job_flags(S, in, jb.body, mov, con);
+        if (jb.kind == kJobItem) { mov = false; con = true; }
+        float cutoff, stop;
+        job_limits(S, jb, mov, con, __uint_as_float(__hip_atomic_load(&st.env_min[jb.env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), cutoff, stop);
+        JobLane J;
+        job_setup<SELF>(S, JT.BP, JT.pv, JT.pd, in, jb, cutoff, stop, J);
+        const unsigned long long pc2 = SMR_DEV_CLOCK();
+        while (__any(active)) {
+            float d;
+            ++prof_trips;
+            if (active && job_trip(J, d)) {
+                active = false;
+                job_result(S, st, jb, mov, con, d);
+            }
+        }
+        SMR_DEV_COUNT(27, pc2 - pc1); SMR_DEV_COUNT(28, SMR_DEV_CLOCK() - pc2); SMR_DEV_COUNT(29, prof_trips); SMR_DEV_MAX(30, prof_trips); SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc1);
+        (void)prof_trips; (void)pc1; (void)pc2;
+    }
+}
+
 // env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
 __device__ inline void commit_staged(const DScene &S, const DState &st, int e, float *row) {
     const int B = S.B;
@@ -352,6 +656,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         d_moving = fminf(d_moving, st.dist[(size_t)(NB + l) * B + e]);
     }
     for (int i = 0; i < S.n_self_pairs; ++i) d_self = fminf(d_self, st.dist[(size_t)(2 * NB + i) * B + e]);
+    if (S.planets_jobs) {                                                     // pair-job path: the minima over the env's jobs
+        d_moving = fminf(d_moving, __uint_as_float(st.env_min[e]));
+        d_static = fminf(d_static, __uint_as_float(st.env_dstatic[e]));
+    }
 
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ], amax = 0.f, vrel = 0.f, arel = 0.f;
     // A14: the target point is reached when the target link point comes within its radius at one of the updates of the
@@ -1458,6 +1766,8 @@ struct smr_env {
     float risk_threshold = 0.05f;
     float *risk_x = nullptr, *risk_y = nullptr, *backup_y = nullptr, *actions_eff = nullptr;
     int *risky_buf = nullptr;
+    size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
+    int job_blocks = 0;               // their persistent grid: two 512-lane blocks per CU
     bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
     DState st;
@@ -1600,6 +1910,18 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed,
         float4 *dav; float *dad;
         if ((rc = dev_upload(env, &dav, G.auto_verts)) || (rc = dev_upload(env, &dad, G.auto_desc))) return rc;
         d.auto_verts = (const float *)dav; d.auto_desc = dad;
+        // pair-job path (the default in planet scenes; SMR_COLLIDE_LANES=1: the lane-per-(env, body) collide kernel, for A/B runs)
+        const char *lanes = getenv("SMR_COLLIDE_LANES");
+        d.planets_jobs = !(lanes && atoi(lanes));
+        if (d.planets_jobs) {
+            std::vector<uint32_t> job_pool;
+            body_pool_tables(s, G, job_pool, d.static_mask | d.moving_mask | d.contact_mask);
+            uint32_t *dpool;
+            if ((rc = dev_upload(env, &dpool, job_pool))) return rc;
+            d.job_pool = dpool; d.job_pool_dwords = (int)job_pool.size();
+            env->job_lds_bytes = 4 * ((size_t)d.job_pool_dwords + 4 * (size_t)d.auto_vn + kPlanetDescDwords * (size_t)d.auto_pn);
+            if (env->job_lds_bytes > 64 * 1024) d.planets_jobs = 0;      // does not fit two blocks per CU: stay with the lane form
+        }
     }
     if (s.use_ball) {
         if (!piece_ok(s.ball_piece)) { env->err = "bad ball_piece"; return SMR_E_INVALID; }
@@ -1729,6 +2051,24 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (env->hscene.planets_jobs) {
+        const size_t NB = (size_t)scene->n_bodies, N = (size_t)scene->collision_checks_per_step;
+        // job list: the table runs the keys kernel defers (at most one per (env, body)) always fit; behind them what the first kernel adds
+        // (2.9 pair jobs per env on uniformly drawn states) - when it finds the list full it makes the run itself
+        size_t cap = B * NB + std::max<size_t>(B * 40, 65536);
+        if (const char *v = getenv("SMR_JOB_CAP")) cap = B * NB + (size_t)std::max(0, atoi(v));       // tests: force the full-list path
+        if (cap > 0x7FFFFFFFull) { env->err = "num_envs too large for the job list"; return fail(SMR_E_INVALID); }
+        st.job_cap = (int)cap;
+        if ((rc = dev_alloc(env, &st.keyw, 7 * NB * B)) || (rc = dev_alloc(env, &st.env_best, B)) || (rc = dev_alloc(env, &st.env_min, B)) ||
+            (rc = dev_alloc(env, &st.env_dstatic, B)) || (rc = dev_alloc(env, &st.items, N > 1 ? B * NB * (N - 1) : 1)) ||
+            (rc = dev_alloc(env, &st.jobs, cap)) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) ||
+            (rc = dev_alloc(env, &st.overflow_env, B))) return fail(rc);
+        if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
+        env->job_blocks = 2 * std::max(prop.multiProcessorCount, 1);
+        if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
+    }
     if ((rc = dev_alloc(env, &st.tp, 5 * B)) || (rc = dev_alloc(env, &st.tp_count, B)) || (rc = dev_alloc(env, &st.tp_list, B)) ||
         (rc = dev_alloc(env, &st.tp_list_count, 1)) || (rc = dev_alloc(env, &st.error_flags, 1))) return fail(rc);
     if (hipMemset(st.tp, 0, 5 * B * 4) || hipMemset(st.tp_count, 0, B * 4) || hipMemset(st.tp_list_count, 0, 4) || hipMemset(st.error_flags, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
@@ -2081,7 +2421,20 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         const bool self = env->hscene.n_self_pairs > 0, autop = env->hscene.planets_auto != 0;
         const int block = autop ? 256 : 64;
         const dim3 grid((B + block - 1) / block, env->hscene.n_bodies + env->hscene.n_self_pairs);
-        if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        if (env->hscene.planets_jobs) {
+            const dim3 jgrid(env->job_blocks);
+            const int env_blocks = (B + 255) / 256;
+            const dim3 egrid(env_blocks + (env->N > 1 ? 4 * env->job_blocks : 0));      // behind the env blocks: a fixed grid striding over the items
+            if (self) {
+                hipLaunchKernelGGL((keys_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+                hipLaunchKernelGGL((enumerate_kernel<true>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
+                hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+            } else {
+                hipLaunchKernelGGL((keys_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+                hipLaunchKernelGGL((enumerate_kernel<false>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
+                hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+            }
+        } else if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);

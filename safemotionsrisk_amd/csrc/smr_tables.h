@@ -27,9 +27,11 @@ struct HostGeometry {
 
 // image of the LDS pool of the reset-side kernels: kBodyPoolHead dwords per body (offsets of its vertices / id groups / start map /
 // DPiece), then every body's tables as the global ones hold them.  Returns false when they do not fit.
-inline bool body_pool_tables(const smr_scene_t &s, const HostGeometry &G, std::vector<uint32_t> &pool) {
+// mask: the bodies whose tables go in (the others keep zero offsets: nobody asks for them)
+inline bool body_pool_tables(const smr_scene_t &s, const HostGeometry &G, std::vector<uint32_t> &pool, uint32_t mask = 0xFFFFFFFFu) {
     pool.assign((size_t)kBodyPoolHead * SMR_MAX_BODIES, 0u);
     for (int b = 0; b < s.n_bodies; ++b) {
+        if (!((mask >> b) & 1u)) continue;
         const int piece = s.link_piece[b];
         const DPiece &P = G.pieces[piece];
         const uint32_t v_off = (uint32_t)pool.size(), ids_off = v_off + 4u * (uint32_t)P.count, start_off = ids_off + (uint32_t)P.ids_count;
@@ -368,7 +370,7 @@ inline void planet_tables(HostGeometry &G, DScene &d) {
     if (d.n_planets > 1 && d.planet[1].piece_begin < d.planet[0].piece_begin) return;
     auto add = [&](int pi, int frame) {
         const DPiece &P = pieces[pi];
-        const int first = (int)G.auto_verts.size(), padded = (P.count + 3) / 4 * 4;
+        const int first = (int)G.auto_verts.size(), padded = (P.count + 7) / 8 * 8;      // the scans read 4 or 8 vertices per round
         for (int k = 0; k < padded; ++k) G.auto_verts.push_back(G.verts[(size_t)P.begin + std::min(k, P.count - 1)]);
         float w[kPlanetDescDwords] = {0, 0, P.margin, 0, P.cx, P.cy, P.cz, 0};
         std::memcpy(&w[0], &first, 4); std::memcpy(&w[1], &padded, 4); std::memcpy(&w[3], &frame, 4);
@@ -380,7 +382,7 @@ inline void planet_tables(HostGeometry &G, DScene &d) {
     d.auto_pn = d.planet_pn; d.auto_vn = d.planet_vn;
     // the static piece behind them (the table: an axis-aligned box), world frame - its GJK runs join the planet runs' loop
     if (d.n_static == 1 && pieces[d.static_piece[0]].kind == kPieceAlignedBox && d.planet_pn < kMaxPlanetPieces &&
-        d.planet_vn + (pieces[d.static_piece[0]].count + 3) / 4 * 4 <= kMaxPlanetVerts) {
+        d.planet_vn + (pieces[d.static_piece[0]].count + 7) / 8 * 8 <= kMaxPlanetVerts) {
         add(d.static_piece[0], 2);
         d.auto_static = d.planet_pn; d.auto_pn = d.planet_pn + 1; d.auto_vn = (int)G.auto_verts.size();
     }

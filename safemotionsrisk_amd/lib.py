@@ -12,7 +12,8 @@ import subprocess
 from .scene import Scene
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libsmr_hip.so")
+#: SMR_LIB: another build of the same library (the profiling build of scripts/profile_rows.py, A/B variants); never a different backend
+LIB_PATH = os.environ.get("SMR_LIB") or os.path.join(_PKG, "libsmr_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 

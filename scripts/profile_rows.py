@@ -22,11 +22,12 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     cfg, kw, _, _ = bench._env_config(name)
     kw = {k: v for k, v in kw.items() if k != "risk_networks"}
-    env = smr.VecSafeMotionsEnv(65536, seed=0, auto_reset=True, **kw, **cfg)
+    nenv = int(os.environ.get('SMR_BENCH_B', '65536'))
+    env = smr.VecSafeMotionsEnv(nenv, seed=0, auto_reset=True, **kw, **cfg)
     L = _lib.load()
     env.reset()
     g = torch.Generator(device="cuda").manual_seed(0)
-    acts = [torch.rand((65536, 7), device="cuda", generator=g) * 2 - 1 for _ in range(8)]
+    acts = [torch.rand((nenv, 7), device="cuda", generator=g) * 2 - 1 for _ in range(8)]
     for i in range(20):
         env.step(acts[i % 8])
     env.synchronize()
@@ -43,10 +44,17 @@ def main():
     total = cyc[:32].sum()
     print("config %s: %.1f M wave-cycles per step over %d rows" % (name, total / 1e6, int((waves > 0).sum())))
     phases = {32: "reset: start position", 33: "reset: velocity / acceleration", 34: "reset: planet phase", 36: "staged spawn: launch",
-              38: "target point"}
+              38: "target point", 40: "job setup: frame of the body", 41: "job setup: piece record + hull pointers", 42: "job setup: planet pose, run start", 52: "first kernel: staging", 53: "first kernel: setup of the first run", 54: "first kernel: trip loop",
+              55: "first kernel: trips per chunk (count, not cycles)", 56: "first kernel: enumeration / job append", 57: "first kernel: item chunk",
+              58: "jobs kernel: staging", 59: "jobs kernel: setup", 60: "jobs kernel: trip loop", 61: "jobs kernel: trips per chunk (count)",
+              62: "jobs kernel: MAX trips of a chunk (x steps)", 63: "jobs kernel: MAX cycles of a chunk (x steps)"}
+    nenv = int(os.environ.get("SMR_BENCH_B", "65536"))
     total = cyc[:32].sum()
     for r in range(64):
         if waves[r] == 0:
+            continue
+        if r in (62, 63):
+            print("  %-32s %d" % (phases.get(r), int(out[r])))
             continue
         if r >= 32:
             print("  %-32s %8.2f M cycles  %8.0f cycles per wave, %6.0f waves per step" % (phases.get(r, "phase %d" % r), cyc[r] / 1e6, cyc[r] / waves[r], waves[r]))
