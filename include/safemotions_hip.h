@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 7
+#define SMR_ABI_VERSION 8
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
@@ -45,7 +45,9 @@ extern "C" {
 /* columns of the optional per-step info matrix (float32 [B][SMR_INFO_N]); the Python shim turns
  * them into the reference's info dict (base.py:1350-1386, rewards.py:490-498) */
 #define SMR_INFO_D_STATIC 0           /* minimum_distance_to_static_obstacles after the 0.001 clamp, rewards.py:115-117 */
-#define SMR_INFO_D_SELF 1             /* minimum_distance_self_collision,          rewards.py:119-121 */
+#define SMR_INFO_D_SELF 1             /* minimum_distance_self_collision,          rewards.py:119-121: exact below the range the
+                                         reference reads - max(self-collision max_reward_distance, 0.001), rewards.py:119-126 -, at or
+                                         beyond it the cut-off value ("no closest point", ctlp.py:354-366) */
 #define SMR_INFO_D_MOVING 2           /* minimum_distance_to_moving_obstacles,     rewards.py:147-155 */
 #define SMR_INFO_ACTION_PUNISHMENT 3  /* rewards.py:164-169 */
 #define SMR_INFO_R_SELF 4             /* self_collision_reward,                     rewards.py:123-126 */
@@ -180,6 +182,10 @@ int smr_test_distances(smr_env_t *env, const float *q_host, const int32_t *plane
  * after k_host[n] updates */
 int smr_test_ball_distances(smr_env_t *env, const float *q_host, const float *ball_host, const int32_t *k_host,
                             int32_t n, float *out);
+
+/* self-collision pairs: the table lower bounds the step's pruning uses (csrc/smr_device.h "Self pairs: bound tables") for n joint
+ * vectors; out [n][SMR_MAX_SELF_PAIRS], -3e38 for a pair without a table.  Each must not exceed the pair's distance (ctlp.py:3345-3372). */
+int smr_test_self_bounds(smr_env_t *env, const float *q_host, int32_t n, float *out);
 
 #ifdef __cplusplus
 }

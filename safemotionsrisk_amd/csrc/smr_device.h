@@ -64,6 +64,8 @@ constexpr int kStartBins = 8;                                // cube-map resolut
 constexpr int kStartCells = 6 * kStartBins * kStartBins;     // entries per piece
 // the reset-side kernels (reset, spawn, target: smr_hip.hip) climb over the hulls of ALL bodies, a different one per lane: one LDS
 // pool per block with every body's tables (body_pool_tables, smr_tables.h), kBodyPoolHead dwords of offsets per body in front
+constexpr float kSelfTabStep = 4.0e-6f;                      // self-pair bound tables: uint16 entries in units of 4 um (0 .. 0.262 m)
+constexpr float kSelfTabMax = 0.262f;
 constexpr int kBodyPoolHead = 4;                             // dword offsets into the pool: vertices, id groups, start map, DPiece
 constexpr int kBodyPoolDwords = 15360;                       // 60 KB: two 256-lane blocks per CU
 
@@ -97,6 +99,18 @@ struct DScene {
     // with the hull tables of the bodies that take part in moving / contact / static queries only
     int planets_jobs, job_pool_dwords;
     const uint32_t *job_pool;
+    // self-collision pairs ("Self pairs" below): jobs_on - the job lists exist (pair jobs and / or self-pair jobs); self_cut - the
+    // distance range the reward and the termination read (rewards.py:119-126): a self distance at or above it is "none"; the bound
+    // tables of the pairs whose relative pose depends on the last two or three joints only
+    int jobs_on;
+    float self_cut;
+    int self_tab_nd[SMR_MAX_SELF_PAIRS];        // 0: the pair has no table; else its axes are the joints 7 - nd .. 6
+    int self_tab_off[SMR_MAX_SELF_PAIRS];       // first entry in self_tab
+    int self_tab_n[SMR_MAX_SELF_PAIRS][3];      // cells per axis
+    float self_tab_h[SMR_MAX_SELF_PAIRS][3], self_tab_ih[SMR_MAX_SELF_PAIRS][3];   // cell width and its inverse
+    float self_tab_lever[SMR_MAX_SELF_PAIRS][3];  // no point of the body moves farther than lever x |dq| relative to the partner link
+    const uint16_t *self_tab;                   // lower bound of the pair's distance at the cell centre, units of kSelfTabStep
+    int self_cyl_slot[SMR_MAX_SELF_PAIRS];      // pairs against a world-fixed cylinder: slot of its parameters in the job kernels' LDS (-1: none)
     int n_static, static_piece[SMR_MAX_STATIC];
     unsigned static_mask;
     float static_max;
@@ -165,6 +179,8 @@ struct DState {
     float *brake_acc;          // [brake_timeout_steps + 1][7][B] end acceleration of braking segment m >= 1 behind the planned step
                                // ([0]: the braking acceleration at the current state, what adapt_action puts in place of the action)
     int *brake_steps;          // [B] braking segments until the robot stands (-1: not within the braking timeout)
+    unsigned long long *brake_jobs;   // [rows x B] (env, row, segment, sample) from which brake_walk takes over a row of brake_scan
+    int *brake_job_count;      // [1] cleared by plan_kernel
     float *lb_moving;          // [n_bodies][B] lower bound of the body's distance to every moving piece at the end of the last step
                                // (< 0: none - new episode, injected state); the next step's lanes rule out their first samples with it
     int *done_list;            // [B]
@@ -212,11 +228,13 @@ struct DState {
     unsigned *env_min;                 // [B] float bits of the env's moving-obstacle distance: atomicMin over its jobs (non-negative floats
                                        //     order like their bits); plan_kernel starts it at moving_max + 0.002
     unsigned *env_dstatic;             // [B] ... of the static distance found by deferred table runs (starts at static_max)
+    unsigned *env_dself;               // [B] ... of the self-collision distance: atomicMin over the env's self-pair jobs (starts at static_max)
     unsigned long long *items;         // intermediate contact samples still to be tested: job words (env, body, k) of kind kJobItem
     unsigned long long *jobs;          // GJK runs to make: job words (env, body, piece, k, kind)
     int *item_count, *job_count;       // [1] each, cleared by plan_kernel
+    int *job_next;                     // [1] the next job of the list nobody has taken yet (jobs_kernel), cleared by plan_kernel
     int job_cap;                       // capacity of jobs[]
-    int *overflow_env;                 // [B] 1: a job of this env found the list full - the overflow kernel works the env in the lane form
+    int *overflow_env;                 // [B] 1: a job of this env found the list full - overflow_kernel evaluates ALL its queries itself
 };
 
 enum { kSamplingStart = 1, kSamplingPlanetPhase = 2, kSamplingBallLaunch = 4, kSamplingBallTarget = 8, kSamplingTargetPoint = 16,
@@ -918,8 +936,10 @@ __device__ inline bool simplex_solve(F3 &w0, F3 &w1, F3 &w2, F3 &w3, int &n, F3 
 // warm (trajectory walks that query the same pair again and again): in - when non-zero - the start direction instead of v (any
 // direction will do: before the first simplex point is in, v only serves as the direction of the first support call), out the
 // vector the run ended with, i.e. the direction of the closest points
+// lower (the builder of the self-pair bound tables): the largest support-plane bound v.w / |v| seen - a rigorous lower bound of the
+// distance however the run ends (the value returned on a stall is an upper bound)
 template <class SA, class SB>
-__device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff, float stop_below, F3 *warm = nullptr) {
+__device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff, float stop_below, F3 *warm = nullptr, float *lower = nullptr) {
     F3 w0 = {0, 0, 0}, w1 = w0, w2 = w0, w3 = w0;
     int n = 0, hint_a = 0, hint_b = 0, stalls = 0;
     if (warm && dot(*warm, *warm) > 0.f) v = *warm;
@@ -931,6 +951,7 @@ __device__ inline float gjk_core(const SA &sa, const SB &sb, F3 v, float cutoff,
         SMR_CNT(4);
         F3 w = sa(neg(v), hint_a, it == 0) - sb(v, hint_b, it == 0);
         float vw = dot(v, w);
+        if (lower && vw > 0.f) *lower = fmaxf(*lower, vw / sqrtf(vv));
 #ifdef SMR_HOST_EMUL_TRACE
         printf("  it %d n %d vv %.9g vw %.9g v=(%.7g %.7g %.7g) w=(%.7g %.7g %.7g)\n", it, n, vv, vw, v.x, v.y, v.z, w.x, w.y, w.z);
 #endif
@@ -1161,7 +1182,7 @@ __device__ inline Xf body_frame(const DScene &S, const float q[SMR_NJ], int b) {
 }
 
 // sines and cosines of a configuration's joint angles: the reset-side kernels build many frames of one candidate
-struct Trig { float sn[SMR_NJ], cs[SMR_NJ]; };
+struct Trig { float sn[SMR_NJ], cs[SMR_NJ]; float q_last[3]; };   // q_last: the angles of joints 4, 5, 6 (axes of the self-pair bound tables)
 __device__ inline Xf body_frame_sc(const DScene &S, const Trig &P, int b) {
     const int link = b < SMR_NLINK ? b : SMR_NLINK - 1;
     Xf T = fk_base(S);
@@ -1171,16 +1192,52 @@ __device__ inline Xf body_frame_sc(const DScene &S, const Trig &P, int b) {
     return b < SMR_NLINK ? T : mounted_frame(S, b, T);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Self pairs: bound tables.  The relative pose of a body mounted on iiwa_link_7 and its partner link k depends on the joints
+// k .. 6 only: two angles for iiwa_link_5, three for iiwa_link_4 - the pairs that are near in most configurations (the ball machine
+// sits 6 - 8 cm from iiwa_link_5 half of the time).  For those pairs smr_create tabulates, with the device GJK itself
+// (self_table_kernel), a rigorous LOWER bound of the distance at every cell centre of a grid over these angles (the largest
+// support-plane bound of the run, rounded down to 4 um).  The distance is 1-Lipschitz in the displacement of the body's points
+// relative to the partner, and joint j moves them by at most lever_j |dq_j|, so  d(q) >= tab[cell(q)] - sum_j lever_j |q_j - centre_j|.
+// Every caller that only asks "closer than x?" - the start-state / target / ball-target sampling (ctlp.py:2170-2208), the braking
+// trajectory checker (ctlp.py:3345-3372), the pruning of the step's pair jobs - is answered by one 2-byte read where the bound clears
+// x; the GJK run is kept for the configurations it cannot clear.  The oracle makes the literal queries, so the parity tests check
+// the argument, and tests/test_gpu_parity.py compares the bounds with the oracle's distances directly.  A bound <= 0 carries no
+// information (overlapping hulls are tabulated as 0).
+// ---------------------------------------------------------------------------------------------
+// q4, q5, q6: the angles of the last three joints.  i may differ between the lanes.
+__device__ inline float self_tab_bound(const DScene &S, int i, float q4, float q5, float q6) {
+    const int nd = S.self_tab_nd[i];
+    if (nd == 0) return -kNoBound;
+    int idx = 0;
+    float slack = 0.f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        if (d >= nd) continue;
+        const int j = SMR_NJ - nd + d;
+        const float qj = (j == 4) ? q4 : (j == 5 ? q5 : q6);
+        const int n = S.self_tab_n[i][d];
+        int c = (int)floorf((qj - S.pos_lo[j]) * S.self_tab_ih[i][d]);
+        c = c < 0 ? 0 : (c > n - 1 ? n - 1 : c);
+        const float centre = S.pos_lo[j] + ((float)c + 0.5f) * S.self_tab_h[i][d];
+        slack += fabsf(qj - centre) * S.self_tab_lever[i][d];
+        idx = idx * n + c;
+    }
+    const float t = (float)((const SMR_GLOBAL uint16_t *)S.self_tab)[S.self_tab_off[i] + idx] * kSelfTabStep;
+    return t - slack * 1.0001f - 2e-5f;
+}
+
 // A7 self: distance of self-collision pair i = (body a with hull (LP, hull) under T, partner): the partner is another
 // chain link (its hull climbed from the global tables, per lane) or the base adapter's cylinder in the world frame
 // (btCylinderShapeZ::localGetSupportingVertexWithoutMargin).  Margins subtracted; > cutoff means "farther than cutoff".
 // LANE: the pair index differs between lanes (reset groups deal the pairs to their lanes), so nothing is wave uniform.
 // bodies / trig (the reset-side kernels): the partner link's hull comes from that LDS pool instead of the global tables, its frame
 // from the configuration's sines and cosines.
-template <bool LANE = false, class HB>
+// TABLE: consult the pair's bound table (above) before the GJK run; lower: see gjk_core (the table builder)
+template <bool LANE = false, bool TABLE = true, class HB>
 __device__ inline float self_pair_distance(const DScene &S, int i, const float q[SMR_NJ], const DPiece &LP, const HB &hull,
                                            const Xf &T, float cutoff, float stop_below, const BodyPool *bodies = nullptr, const Trig *trig = nullptr,
-                                           F3 *warm = nullptr) {
+                                           F3 *warm = nullptr, float *lower = nullptr) {
     const int partner = S.self_pair[i][1];
     const int pa = partner >= 0 ? S.link_piece[partner] : -(partner + 1);
     const DPiece A = LANE ? load_piece_lane(S.pieces, pa) : load_piece(S.pieces, pa);
@@ -1198,14 +1255,20 @@ __device__ inline float self_pair_distance(const DScene &S, int i, const float q
             lb = sqrtf(seg_seg_dist2(a0, a1, b0, b1)) * 0.99999f - 1e-6f - A.cap_r - LP.cap_r - margins;
             if (lb > cutoff) return lb;
         }
+        if (TABLE) {
+            lb = trig ? self_tab_bound(S, i, trig->q_last[0], trig->q_last[1], trig->q_last[2]) : self_tab_bound(S, i, q[4], q[5], q[6]);
+            if (lb > cutoff) return lb;
+        }
         if (bodies) {
             const LocalHull ha = bodies->hull(partner);
             const auto sa = [&](F3 dd, int &hint, bool first) { return apply(XA, ha.support(rot_t(XA, dd), hint, first)); };
-            return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins) - margins;
+            return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins, warm) - margins;
         }
         const GlobalHull ha = global_hull(S, pa, A);
         const auto sa = [&](F3 dd, int &hint, bool first) { return apply(XA, ha.support(rot_t(XA, dd), hint, first)); };
-        return gjk_core(sa, sb, d, cutoff + margins, stop_below + margins, warm) - margins;
+        const float dist = gjk_core(sa, sb, d, cutoff + margins, stop_below + margins, warm, lower) - margins;
+        if (lower) *lower -= margins;
+        return dist;
     }
     const F3 d = F3{A.cx, A.cy, A.cz} - cb;
     const float lb = sqrtf(dot(d, d)) - A.radius - LP.radius - margins;
@@ -1876,7 +1939,8 @@ __device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, co
 //                 deterministic and equal to the lane form up to rounding.
 // The critical path of the step is one GJK run, not the longest lane's list of runs.
 // ---------------------------------------------------------------------------------------------
-enum { kJobPlanetEnd = 0, kJobItem = 1, kJobStaticEnd = 2 };
+// kJobSelf: self-collision pair `piece` of the env at the end of the step (the job word's piece field holds the pair index)
+enum { kJobPlanetEnd = 0, kJobItem = 1, kJobStaticEnd = 2, kJobSelf = 3 };
 __device__ __forceinline__ unsigned long long job_word(int env, int body, int piece, int k, int kind) {
     return (unsigned long long)(unsigned)env | ((unsigned long long)body << 32) | ((unsigned long long)piece << 36) |
            ((unsigned long long)k << 42) | ((unsigned long long)kind << 47);
@@ -1922,16 +1986,120 @@ struct JobLane {
     GjkRun g;
     Xf XA, T;                    // planet piece seen from the body frame | the body's world frame (table runs)
     LocalHull hull;
-    const float *av; int ac;
+    const float *av; int ac;     // the scanned side: padded vertex list in LDS (ac == 0: a world-fixed cylinder, av = centre xyz, radius, half length)
     float margins;
     bool is_static;
 };
 
+// Lower bound of the distance of self-collision pair i (wave uniform) at joint vector q from its bound table, bounding spheres and
+// bounding capsules - no hull is touched.  Frames from the hardware sine / cosine: callers allow kBoundSlack.  One pass down the
+// chain gives both frames, the partner link's is a prefix of the body's.
+// enough: a bound above it is returned as soon as it is known (the table first: two bytes, and it settles nine in ten of the near pairs)
+constexpr float kBoundSlack = 1e-4f;
+__device__ inline float self_pair_lower_bound(const DScene &S, int i, const float q[SMR_NJ], float enough) {
+    const int a = S.self_pair[i][0], partner = S.self_pair[i][1];
+    float lb = partner >= 0 ? self_tab_bound(S, i, q[4], q[5], q[6]) + kBoundSlack : -kNoBound;      // (exact angles: no slack needed there)
+    if (lb > enough) return lb;
+    const DPiece LP = load_piece(S.pieces, S.link_piece[a]);
+    const DPiece A = load_piece(S.pieces, partner >= 0 ? S.link_piece[partner] : -(partner + 1));
+    const float margins = A.margin + LP.margin;
+    const int link_a = a < SMR_NLINK ? a : SMR_NLINK - 1;
+    Xf Ta = fk_base(S), Tp = Ta;
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) {
+        if (j == partner) Tp = Ta;
+        if (j < link_a) fk_advance_fast(S, j, q[j], Ta);
+    }
+    if (partner >= link_a) {                                 // (not the case for bodies mounted on the last link)
+        Tp = fk_base(S);
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) if (j < partner) fk_advance_fast(S, j, q[j], Tp);
+    }
+    if (a >= SMR_NLINK) Ta = mounted_frame(S, a, Ta);
+    const F3 cb = apply(Ta, F3{LP.cx, LP.cy, LP.cz});
+    if (partner < 0) {
+        const F3 d = F3{A.cx, A.cy, A.cz} - cb;
+        return fmaxf(lb, __builtin_amdgcn_sqrtf(dot(d, d)) * 0.99999f - 1e-6f - A.radius - LP.radius - margins);
+    }
+    const F3 d = apply(Tp, F3{A.cx, A.cy, A.cz}) - cb;
+    lb = fmaxf(lb, __builtin_amdgcn_sqrtf(dot(d, d)) * 0.99999f - 1e-6f - A.radius - LP.radius - margins);
+    if (lb > enough) return lb;
+    const F3 a0 = apply(Tp, F3{A.cap_a[0], A.cap_a[1], A.cap_a[2]}), a1 = apply(Tp, F3{A.cap_b[0], A.cap_b[1], A.cap_b[2]});
+    const F3 b0 = apply(Ta, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), b1 = apply(Ta, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
+    return fmaxf(lb, __builtin_amdgcn_sqrtf(seg_seg_dist2(a0, a1, b0, b1)) * 0.99999f - 1e-6f - A.cap_r - LP.cap_r - margins);
+}
+
+// ... and of body b (wave uniform) against the static pieces: the sphere / box and capsule / table-top bounds of piece_distance
+__device__ inline float static_lower_bound(const DScene &S, int b, const float q[SMR_NJ]) {
+    const DPiece B = load_piece(S.pieces, S.link_piece[b]);
+    const int link = b < SMR_NLINK ? b : SMR_NLINK - 1;
+    Xf T = fk_base(S);
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) if (j < link) fk_advance_fast(S, j, q[j], T);
+    if (b >= SMR_NLINK) T = mounted_frame(S, b, T);
+    const F3 cb = apply(T, F3{B.cx, B.cy, B.cz});
+    const F3 b0 = apply(T, F3{B.cap_a[0], B.cap_a[1], B.cap_a[2]}), b1 = apply(T, F3{B.cap_b[0], B.cap_b[1], B.cap_b[2]});
+    float lb = 3.0e38f;
+    for (int s = 0; s < S.n_static; ++s) {
+        const DPiece A = load_piece(S.pieces, S.static_piece[s]);
+        const float margins = A.margin + B.margin;
+        const F3 d = F3{A.cx, A.cy, A.cz} - cb;
+        const float ex = fmaxf(fabsf(d.x) - A.hx, 0.f), ey = fmaxf(fabsf(d.y) - A.hy, 0.f), ez = fmaxf(fabsf(d.z) - A.hz, 0.f);
+        float l = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 0.99999f - 1e-6f - B.radius - margins;
+        if (A.kind == kPieceAlignedBox) l = fmaxf(l, fminf(b0.z, b1.z) - B.cap_r - A.btop - margins - 1e-6f);
+        lb = fminf(lb, l);
+    }
+    return lb;
+}
+
+// cyl: the LDS copy of the world-fixed cylinders' parameters (8 floats per slot: centre xyz, radius, half length; stage_job_tables)
 template <bool SELF>
-__device__ inline void job_setup(const DScene &S, const BodyPool &BP, const float *pv, const float *pd, const LaneInput &in, const Job &jb,
-                                 float cutoff, float stop_below, JobLane &J) {
+__device__ inline void job_setup(const DScene &S, const BodyPool &BP, const float *pv, const float *pd, const float *cyl, const LaneInput &in,
+                                 const Job &jb, float cutoff, float stop_below, JobLane &J) {
     const int N = S.checks_per_step, upd = S.updates_per_step / N;
     const float t = jb.k >= N ? S.dt : S.dt * (float)jb.k / (float)N;
+    if (SELF && jb.kind == kJobSelf) {
+        // pair (a, partner): the partner link's hull is climbed in ITS frame, the body's vertices are scanned under XA = partner^-1 o body
+        // (both frames from one pass down the chain: the partner link's is a prefix of the body's); against the world-fixed cylinder
+        // the body's hull is climbed under its world frame, as in a table run
+        const int a = S.self_pair[jb.piece][0], partner = S.self_pair[jb.piece][1];
+        float qs[SMR_NJ];
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt);
+        const int link_a = a < SMR_NLINK ? a : SMR_NLINK - 1;
+        Xf Ta = fk_base(S), Tp = Ta;
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) {
+            if (j == partner) Tp = Ta;
+            if (j < link_a) fk_advance(S, j, qs[j], Ta);
+        }
+        if (partner >= link_a) Tp = body_frame(S, qs, partner);
+        if (a >= SMR_NLINK) Ta = mounted_frame(S, a, Ta);
+        const DPiece LA = BP.piece(a);
+        if (partner >= 0) {
+            const DPiece LP = BP.piece(partner);
+            J.hull = BP.hull(partner);
+            J.XA = inv_compose(Tp, Ta);
+            J.T = Tp;
+            J.av = (const float *)BP.pool + BP.pool[kBodyPoolHead * a];
+            J.ac = (LA.count + 7) & ~7;                       // the pool pads every vertex list to a multiple of 8 (body_pool_tables)
+            J.margins = LA.margin + LP.margin;
+            J.is_static = false;
+            J.g.start(apply(J.XA, F3{LA.cx, LA.cy, LA.cz}) - F3{LP.cx, LP.cy, LP.cz}, cutoff + J.margins, stop_below + J.margins);
+        } else {
+            const float *c = cyl + 8 * S.self_cyl_slot[jb.piece];
+            J.hull = BP.hull(a);
+            J.T = Ta;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) J.XA.r[i] = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+            J.XA.t = F3{0.f, 0.f, 0.f};
+            J.av = c; J.ac = 0;
+            J.margins = LA.margin + c[5];
+            J.is_static = true;
+            J.g.start(F3{c[0], c[1], c[2]} - apply(Ta, F3{LA.cx, LA.cy, LA.cz}), cutoff + J.margins, stop_below + J.margins);
+        }
+        return;
+    }
     const unsigned long long ps0 = SMR_DEV_CLOCK();
     J.T = lane_frame_any<false>(S, jb.body, in, t);
     const unsigned long long ps1 = SMR_DEV_CLOCK();
@@ -1961,15 +2129,19 @@ __device__ inline void job_setup(const DScene &S, const BodyPool &BP, const floa
 }
 
 // one iteration; true when the run is settled, dist = distance with the margins subtracted
+template <bool SELF>
 __device__ __forceinline__ bool job_trip(JobLane &J, float &dist) {
     const auto sb = [&](F3 d, int &hint, bool first) {
-        const unsigned long long t0 = SMR_DEV_CLOCK();
         const F3 p = J.hull.support(J.is_static ? rot_t(J.T, d) : d, hint, first);
-        (void)t0;
         return J.is_static ? apply(J.T, p) : p;
     };
     const auto sa = [&](F3 d, int &, bool) {
-        const unsigned long long t0 = SMR_DEV_CLOCK();
+        if (SELF && J.ac == 0) {                           // btCylinderShapeZ::localGetSupportingVertexWithoutMargin, world frame
+            const float sxy = sqrtf(d.x * d.x + d.y * d.y), r = J.av[3];
+            F3 p = sxy > 0.f ? F3{J.av[0] + r * d.x / sxy, J.av[1] + r * d.y / sxy, J.av[2]} : F3{J.av[0] + r, J.av[1], J.av[2]};
+            p.z += d.z < 0.f ? -J.av[4] : J.av[4];
+            return p;
+        }
         const F3 dl = rot_t(J.XA, d);
         float best = -3.0e38f;
         int bi = 0;
@@ -1987,7 +2159,6 @@ __device__ __forceinline__ bool job_trip(JobLane &J, float &dist) {
                 bi = gt ? i + u : bi;
             }
         }
-        (void)t0;
         return apply(J.XA, F3{J.av[4 * bi], J.av[4 * bi + 1], J.av[4 * bi + 2]});
     };
     float d;

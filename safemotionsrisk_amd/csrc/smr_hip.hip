@@ -53,13 +53,16 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     int code;
     safe_acc_range_joint<64>(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code, live);
     if (!live) return;
-    if (j == 0 && S.check_braking) st.braked[e] = 0;   // set by brake_check_kernel
-    if (j == 0 && S.planets_jobs) {                    // the accumulators and lists of this step's pair jobs (keys / first / jobs kernels)
-        st.env_best[e] = 0xFFFFFFFFu;
-        st.env_min[e] = dist_bits(S.moving_max + 0.002f);
-        st.env_dstatic[e] = dist_bits(S.static_max);
+    if (j == 0 && S.check_braking) { st.braked[e] = 0; if (e == 0) *st.brake_job_count = 0; }   // set by brake_plan / brake_walk; the scan's job list
+    if (j == 0 && S.jobs_on) {                         // the accumulators and lists of this step's jobs (self_bounds / keys / enumerate / jobs kernels)
+        if (S.planets_jobs) {
+            st.env_best[e] = 0xFFFFFFFFu;
+            st.env_min[e] = dist_bits(S.moving_max + 0.002f);
+            st.env_dstatic[e] = dist_bits(S.static_max);
+        }
+        st.env_dself[e] = dist_bits(S.static_max);
         st.overflow_env[e] = 0;
-        if (e == 0) { *st.item_count = 0; *st.job_count = 0; }
+        if (e == 0) { *st.item_count = 0; *st.job_count = 0; *st.job_next = 0; }
     }
     float u = actions[(size_t)e * SMR_NJ + j];
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
@@ -143,17 +146,12 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
     const DScene &S = *Sp;
     constexpr int kBlock = AUTO ? 256 : 64;
     SMR_ROW_CLOCK((int)blockIdx.y);
-    // grid y: first the bodies, outer ones (most planet work, the longest blocks) leading, then the self-collision pairs (SELF; they
-    // only work at the end-of-step sample), the ones with the nearest partners first: short blocks that fill the gaps at the end
-    const bool pair_block = SELF && (int)blockIdx.y >= S.n_bodies;
-    const int pair = pair_block ? S.pair_order[(int)blockIdx.y - S.n_bodies] : 0;
-    // the body whose hull this block climbs over: its own body, or for a pair block the partner link (the ball machine
-    // piece is then the scanned A side; with the base adapter as partner the piece itself is staged)
-    const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0])
-                             : S.body_order[(int)blockIdx.y];
+    // grid y: the bodies, outer ones (most planet work, the longest blocks) leading.  (The self-collision pairs of a scene with mounted
+    // bodies are not rows of this grid: self_bounds_kernel / jobs_kernel.)
+    const int l = S.body_order[(int)blockIdx.y];
     const int B = S.B, N = S.checks_per_step, NB = S.n_bodies;
-    if (!pair_block) {                                   // nothing to do for this body: leave before anything is staged
-        const bool any = (((S.static_mask | S.moving_mask | S.contact_mask) >> l) & 1u) || SELF;
+    {                                                    // nothing to do for this body: leave before anything is staged
+        const bool any = ((S.static_mask | S.moving_mask | S.contact_mask) >> l) & 1u;
         if (!any) {
             const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
             if (e0 < B) {
@@ -185,36 +183,13 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
         }
         for (int i = threadIdx.x; i < LP.ids_count; i += kBlock) lds_ids[i] = gi[i];
         for (int i = threadIdx.x; i < kStartCells / 4; i += kBlock) lds_start[i] = gm[i];
-        if (AUTO && !pair_block) stage_planets(S, threadIdx.x, kBlock, lds_pv, lds_pd);
+        if (AUTO) stage_planets(S, threadIdx.x, kBlock, lds_pv, lds_pd);
     }
     __syncthreads();
     const LocalHull hull{lds_v, lds_ids, (const uint8_t *)lds_start};
     const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = e0 < B;                           // the wavefront shares out its items: no lane leaves early
     const int e = valid ? e0 : B - 1;
-    if (SELF && pair_block) {
-        if (!valid) return;
-        // A7 self, pair (a, partner) at the end of the step (ctlp.py:3345-3372): distance in dist[2 NB + pair]
-        float qs[SMR_NJ];
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], S.dt, S.dt);
-        const int a = S.self_pair[pair][0], partner = S.self_pair[pair][1];
-        // one pass down the chain gives both frames: the partner link's is a prefix of the body's
-        const int link_a = a < SMR_NLINK ? a : SMR_NLINK - 1;
-        Xf Ta = fk_base(S), Tp = Ta;
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) {
-            if (j == partner) Tp = Ta;
-            if (j < link_a) fk_advance(S, j, qs[j], Ta);
-        }
-        if (partner >= link_a) Tp = body_frame(S, qs, partner);                // not the case for the ball machine (partners are links 0..5)
-        if (a >= SMR_NLINK) Ta = mounted_frame(S, a, Ta);
-        float d;
-        if (partner >= 0) d = piece_distance<false>(S, S.link_piece[a], Ta, LP, hull, Tp, S.static_max, S.collision_dist);
-        else d = self_pair_distance(S, pair, qs, LP, hull, Ta, S.static_max, S.collision_dist);
-        st.dist[(size_t)(2 * NB + pair) * B + e] = d <= S.static_max ? d : S.static_max;
-        return;
-    }
     auto lane_input = [&](int env) {
         LaneInput in;
         in.q = st.q + env; in.v = st.v + env; in.a = st.a + env; in.a1 = st.a1 + env; in.stride = B;
@@ -299,19 +274,17 @@ __device__ __forceinline__ LaneInput load_lane_input(const DScene &S, const DSta
     return in;
 }
 
-// keys kernel: the collide kernel's grid and prologue (one lane per (env, body), the body's hull in LDS for the table shortcut; the
-// self-collision pair rows as there), but no GJK run against a moving piece: keys, best key, items and the pending table run go to
-// the lists the first / jobs kernels work off
+// keys kernel: the collide kernel's grid and prologue (one lane per (env, body), the body's hull in LDS for the table shortcut),
+// but no GJK run against a moving piece: keys, best key, items and the pending table run go to the lists the enumerate / jobs
+// kernels work off
 template <bool SELF>
 __global__ __launch_bounds__(256) void keys_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = 256;
-    const bool pair_block = SELF && (int)blockIdx.y >= S.n_bodies;
-    const int pair = pair_block ? S.pair_order[(int)blockIdx.y - S.n_bodies] : 0;
-    const int l = pair_block ? (S.self_pair[pair][1] >= 0 ? S.self_pair[pair][1] : S.self_pair[pair][0]) : S.body_order[(int)blockIdx.y];
+    const int l = S.body_order[(int)blockIdx.y];
     const int B = S.B, N = S.checks_per_step, NB = S.n_bodies;
-    if (!pair_block) {
-        const bool any = (((S.static_mask | S.moving_mask | S.contact_mask) >> l) & 1u) || SELF;
+    {
+        const bool any = ((S.static_mask | S.moving_mask | S.contact_mask) >> l) & 1u;
         if (!any) {
             const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
             if (e0 < B) {
@@ -340,34 +313,13 @@ __global__ __launch_bounds__(256) void keys_kernel(const DScene *__restrict__ Sp
         }
         for (int i = threadIdx.x; i < LP.ids_count; i += kBlock) lds_ids[i] = gi[i];
         for (int i = threadIdx.x; i < kStartCells / 4; i += kBlock) lds_start[i] = gm[i];
-        if (!pair_block) stage_planets(S, threadIdx.x, kBlock, lds_pv, lds_pd);
+        stage_planets(S, threadIdx.x, kBlock, lds_pv, lds_pd);
         __syncthreads();
     }
     const LocalHull hull{lds_v, lds_ids, (const uint8_t *)lds_start};
     const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = e0 < B;
     const int e = valid ? e0 : B - 1;
-    if (SELF && pair_block) {
-        if (!valid) return;
-        float qs[SMR_NJ];
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], S.dt, S.dt);
-        const int a = S.self_pair[pair][0], partner = S.self_pair[pair][1];
-        const int link_a = a < SMR_NLINK ? a : SMR_NLINK - 1;
-        Xf Ta = fk_base(S), Tp = Ta;
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) {
-            if (j == partner) Tp = Ta;
-            if (j < link_a) fk_advance(S, j, qs[j], Ta);
-        }
-        if (partner >= link_a) Tp = body_frame(S, qs, partner);
-        if (a >= SMR_NLINK) Ta = mounted_frame(S, a, Ta);
-        float d;
-        if (partner >= 0) d = piece_distance<false>(S, S.link_piece[a], Ta, LP, hull, Tp, S.static_max, S.collision_dist);
-        else d = self_pair_distance(S, pair, qs, LP, hull, Ta, S.static_max, S.collision_dist);
-        st.dist[(size_t)(2 * NB + pair) * B + e] = d <= S.static_max ? d : S.static_max;
-        return;
-    }
     LaneInput in = load_lane_input(S, st, e);
     in.lb_start = (N > 1 && st.step_count[e] > 0) ? st.lb_moving[(size_t)l * B + e] : -1.f;
     const LaneResult r = collide_lane<SELF, true, true>(S, l, LP, hull, in, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock);
@@ -384,8 +336,9 @@ __global__ __launch_bounds__(256) void keys_kernel(const DScene *__restrict__ Sp
             if (r.ub <= S.moving_max) atomicMin(&st.env_min[e], dist_bits(r.ub));
         }
         if (r.static_pending) {                              // the table's GJK run (one lane in a hundred): a job of its own
-            const int slot = atomicAdd(st.job_count, 1);     // never full here: the list holds B x n_bodies entries before the first kernel adds any
+            const int slot = atomicAdd(st.job_count, 1);
             if (slot < st.job_cap) st.jobs[slot] = job_word(e, l, S.auto_static, N, kJobStaticEnd);
+            else st.overflow_env[e] = 1;
         }
     }
     if (N > 1) {
@@ -408,15 +361,22 @@ __global__ __launch_bounds__(256) void keys_kernel(const DScene *__restrict__ Sp
 // tables of the first / jobs kernels in dynamic LDS: the hull pool of the bodies that take part in moving / static queries
 // (DScene::job_pool), the planets' padded vertex lists and descriptors (+ the table's corners)
 extern __shared__ uint32_t job_lds[];
-struct JobTables { BodyPool BP; const float *pv, *pd; };
+struct JobTables { BodyPool BP; const float *pv, *pd, *cyl; };
+constexpr int kJobCylDwords = 8 * 4;             // up to four world-fixed cylinders named by self-collision pairs (8 floats each)
 __device__ __forceinline__ JobTables stage_job_tables(const DScene &S) {
     uint32_t *pool = job_lds;
-    float *pv = (float *)(job_lds + S.job_pool_dwords), *pd = pv + 4 * S.auto_vn;
+    const int vn = S.planets_jobs ? S.auto_vn : 0, pn = S.planets_jobs ? S.auto_pn : 0;      // (a scene without pair jobs stages no planets)
+    float *pv = (float *)(job_lds + S.job_pool_dwords), *pd = pv + 4 * vn, *cyl = pd + kPlanetDescDwords * pn;
     const SMR_GLOBAL uint32_t *g = (const SMR_GLOBAL uint32_t *)S.job_pool;
     for (int i = threadIdx.x; i < S.job_pool_dwords; i += blockDim.x) pool[i] = g[i];
-    stage_planets(S, threadIdx.x, blockDim.x, pv, pd);
+    if (S.planets_jobs) stage_planets(S, threadIdx.x, blockDim.x, pv, pd);
+    if ((int)threadIdx.x < S.n_self_pairs && S.self_cyl_slot[threadIdx.x] >= 0) {       // centre, core radius, core half length, margin
+        const DPiece A = load_piece_lane(S.pieces, -(S.self_pair[threadIdx.x][1] + 1));
+        float *c = cyl + 8 * S.self_cyl_slot[threadIdx.x];
+        c[0] = A.cx; c[1] = A.cy; c[2] = A.cz; c[3] = A.cyl_r; c[4] = A.cyl_h; c[5] = A.margin; c[6] = 0.f; c[7] = 0.f;
+    }
     __syncthreads();
-    return {BodyPool{pool}, pv, pd};
+    return {BodyPool{pool}, pv, pd, cyl};
 }
 
 // what a job of (env state `in`, body) looks for: the distance of the reward (mov) and / or the contact latch (con) - collide_lane's rules
@@ -429,6 +389,7 @@ __device__ __forceinline__ void job_flags(const DScene &S, const LaneInput &in, 
 __device__ __forceinline__ void job_result(const DScene &S, const DState &st, const Job &jb, bool mov, bool con, float d) {
     const int B = S.B;
     if (jb.kind == kJobStaticEnd) { if (d <= S.static_max) atomicMin(&st.env_dstatic[jb.env], dist_bits(d)); return; }
+    if (jb.kind == kJobSelf) { if (d < S.self_cut) atomicMin(&st.env_dself[jb.env], dist_bits(d)); return; }
     if (mov && d <= S.moving_max) atomicMin(&st.env_min[jb.env], dist_bits(d));
     if (con && d <= S.contact_dist) st.res[(size_t)jb.body * B + jb.env] = 1.f;
 }
@@ -436,6 +397,7 @@ __device__ __forceinline__ void job_result(const DScene &S, const DState &st, co
 // cutoff and early-stop distance of a job (planet_gjk's rules; an item only asks "within the contact distance?")
 __device__ __forceinline__ void job_limits(const DScene &S, const Job &jb, bool mov, bool con, float env_min, float &cutoff, float &stop) {
     if (jb.kind == kJobStaticEnd) { cutoff = S.static_max; stop = S.collision_dist; return; }
+    if (jb.kind == kJobSelf) { cutoff = fminf(env_min, S.self_cut); stop = S.collision_dist; return; }      // env_min: the env's self distance so far
     if (jb.kind == kJobItem) { cutoff = S.contact_dist; stop = S.contact_dist; return; }
     cutoff = mov ? fminf(env_min, S.moving_max) : S.contact_dist;
     if (con) cutoff = fmaxf(cutoff, S.contact_dist);
@@ -473,13 +435,29 @@ __device__ __forceinline__ void push_jobs(const DState &st, int env, const int (
     }
 }
 
+// self_bounds kernel (scenes with self-collision pairs): one lane per (env, pair), grid y = pair - the lower bounds of the pair at the
+// end of the step (bound table, spheres, capsules: self_pair_cleared); a pair they cannot put beyond the distance range the reward
+// reads (DScene::self_cut) becomes a job of kind kJobSelf: 0.3 per env on uniformly drawn states, where the 14 pairs of the ball
+// machine used to be 14 rows of the collide grid with a GJK run in most lanes of the two rows against iiwa_link_5.
+__global__ __launch_bounds__(256) void self_bounds_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    const int B = S.B, pair = (int)blockIdx.y;
+    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = e0 < B;
+    const int e = valid ? e0 : B - 1;
+    float q[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) q[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], S.dt, S.dt);
+    const bool job = valid && !(self_pair_lower_bound(S, pair, q, S.self_cut + kBoundSlack) > S.self_cut + kBoundSlack);
+    const uint32_t masks[1] = {job ? 1u << pair : 0u};
+    const int bodies[1] = {0};
+    push_jobs(st, e, bodies, masks, S.checks_per_step, kJobSelf);
+}
+
 #ifndef SMR_JOB_WAVES
 #define SMR_JOB_WAVES 4
 #endif
 
-// chunk c of 64 tasks is worked by wavefront ((c / gridDim.x) % waves per block) of block (c % gridDim.x): the chunks spread over all
-// blocks of the persistent grid before a block gets its second one
-#define SMR_CHUNK_LOOP(n_chunks) for (int c = (int)blockIdx.x + (int)gridDim.x * (int)(threadIdx.x >> 6); c < (n_chunks); c += (int)gridDim.x * (int)(blockDim.x >> 6))
 
 // enumerate kernel (no GJK, no LDS).  Blocks [0, env_blocks): one lane per env - every pair of the env whose key bound does not exceed
 // the upper bound the keys kernel left in env_min (or, for a body that is tested for contact, the contact distance) becomes a job.
@@ -546,42 +524,87 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
     }
 }
 
-// jobs kernel: one lane per job of the list
+// jobs kernel: one lane per job of the list.  The wavefronts of the persistent grid draw their jobs from ONE stream (job_next):
+// whenever SMR_JOB_REFILL of a wavefront's lanes have settled their runs (or all have), it takes as many jobs as it has idle lanes
+// with one atomic, and the idle lanes set their new runs up while the others wait one setup; then every lane with a run advances it
+// by one GJK iteration per trip.  A wavefront that worked its jobs in chunks of 64 ran every chunk as long as its slowest run (a
+// third of the lane-trips were useful) and the kernel as long as the unluckiest wavefront's chunks; with the stream no lane waits
+// for more than one setup and the kernel ends within one run's length of the moment the stream runs dry.  The order in which the
+// jobs are worked does not matter: their results are minima and flags (job_result).
+#ifndef SMR_JOB_REFILL
+#define SMR_JOB_REFILL 24
+#endif
 template <bool SELF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
+#ifdef SMR_PROFILE_ROWS
     const unsigned long long pc0 = SMR_DEV_CLOCK();
+    unsigned long long pc_setup = 0, pc_trip = 0;
+    int prof_trips = 0, prof_refills = 0, prof_maxit = 0;
+#endif
     const JobTables JT = stage_job_tables(S);
-    SMR_DEV_COUNT(26, SMR_DEV_CLOCK() - pc0); (void)pc0;
+#ifdef SMR_PROFILE_ROWS
+    SMR_DEV_COUNT(26, SMR_DEV_CLOCK() - pc0);
+#endif
     const int lane = (int)__lane_id();
     const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
-    const int n_chunks = (n_jobs + 63) / 64;
-    SMR_CHUNK_LOOP(n_chunks) {
-        const unsigned long long pc1 = SMR_DEV_CLOCK();
-        int prof_trips = 0;
-        const int j = 64 * c + lane;
-        bool active = j < n_jobs;
-        const Job jb = job_unpack(st.jobs[active ? j : 0]);
-        const LaneInput in = load_lane_input(S, st, jb.env);
-        bool mov, con;
-        job_flags(S, in, jb.body, mov, con);
-        if (jb.kind == kJobItem) { mov = false; con = true; }
-        float cutoff, stop;
-        job_limits(S, jb, mov, con, __uint_as_float(__hip_atomic_load(&st.env_min[jb.env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), cutoff, stop);
-        JobLane J;
-        job_setup<SELF>(S, JT.BP, JT.pv, JT.pd, in, jb, cutoff, stop, J);
-        const unsigned long long pc2 = SMR_DEV_CLOCK();
-        while (__any(active)) {
-            float d;
-            ++prof_trips;
-            if (active && job_trip(J, d)) {
-                active = false;
-                job_result(S, st, jb, mov, con, d);
+    bool active = false, mov = false, con = false, dry = false;
+    Job jb = {0, 0, 0, 0, 0};
+    JobLane J;
+    J.g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);               // defined state for the lanes that never get a job
+    J.XA = Xf{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, F3{0.f, 0.f, 0.f}}; J.T = J.XA;
+    J.hull = JT.BP.hull(0); J.av = JT.pv; J.ac = 0; J.margins = 0.f; J.is_static = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        if (!dry && (n_idle >= SMR_JOB_REFILL || n_idle == 64)) {
+#ifdef SMR_PROFILE_ROWS
+            const unsigned long long t0 = SMR_DEV_CLOCK();
+            ++prof_refills;
+#endif
+            int base = 0;
+            if (lane == 0) base = atomicAdd(st.job_next, n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            dry = base + n_idle >= n_jobs;                 // the stream is exhausted (for every wavefront that asks from now on)
+            const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && j < n_jobs) {
+                jb = job_unpack(st.jobs[j]);
+                const LaneInput in = load_lane_input(S, st, jb.env);
+                job_flags(S, in, jb.body, mov, con);
+                if (jb.kind == kJobItem) { mov = false; con = true; }
+                float cutoff, stop;
+                const unsigned *running = (SELF && jb.kind == kJobSelf) ? st.env_dself : st.env_min;      // the env's minimum so far prunes the run
+                job_limits(S, jb, mov, con, __uint_as_float(__hip_atomic_load(&running[jb.env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), cutoff, stop);
+                job_setup<SELF>(S, JT.BP, JT.pv, JT.pd, JT.cyl, in, jb, cutoff, stop, J);
+                active = true;
             }
+#ifdef SMR_PROFILE_ROWS
+            pc_setup += SMR_DEV_CLOCK() - t0;
+#endif
         }
-        SMR_DEV_COUNT(27, pc2 - pc1); SMR_DEV_COUNT(28, SMR_DEV_CLOCK() - pc2); SMR_DEV_COUNT(29, prof_trips); SMR_DEV_MAX(30, prof_trips); SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc1);
-        (void)prof_trips; (void)pc1; (void)pc2;
+        if (!__any(active)) break;
+#ifdef SMR_PROFILE_ROWS
+        const unsigned long long t1 = SMR_DEV_CLOCK();
+        ++prof_trips;
+#endif
+        float d;
+        if (active && job_trip<SELF>(J, d)) {
+            active = false;
+            job_result(S, st, jb, mov, con, d);
+#ifdef SMR_PROFILE_ROWS
+            prof_maxit = max(prof_maxit, J.g.it + 1);
+#endif
+        }
+#ifdef SMR_PROFILE_ROWS
+        pc_trip += SMR_DEV_CLOCK() - t1;
+#endif
     }
+#ifdef SMR_PROFILE_ROWS
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) prof_maxit = max(prof_maxit, __shfl_xor(prof_maxit, d));
+    SMR_DEV_COUNT(27, pc_setup); SMR_DEV_COUNT(28, pc_trip); SMR_DEV_COUNT(29, prof_trips); SMR_DEV_MAX(30, prof_maxit);
+    SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc0); SMR_DEV_COUNT(25, prof_refills);
+#endif
 }
 
 // env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
@@ -655,7 +678,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         d_static = fminf(d_static, st.dist[(size_t)l * B + e]);
         d_moving = fminf(d_moving, st.dist[(size_t)(NB + l) * B + e]);
     }
-    for (int i = 0; i < S.n_self_pairs; ++i) d_self = fminf(d_self, st.dist[(size_t)(2 * NB + i) * B + e]);
+    if (S.n_self_pairs > 0) {                                                 // the minimum over the env's self-pair jobs; at or beyond the range
+        d_self = fminf(d_self, __uint_as_float(st.env_dself[e]));            // the reward reads (rewards.py:119-126) it is "none"
+        if (d_self >= S.self_cut) d_self = S.static_max;
+    }
     if (S.planets_jobs) {                                                     // pair-job path: the minima over the env's jobs
         d_moving = fminf(d_moving, __uint_as_float(st.env_min[e]));
         d_static = fminf(d_static, __uint_as_float(st.env_dstatic[e]));
@@ -845,6 +871,8 @@ struct Group {
         Trig P;
 #pragma unroll
         for (int j = 0; j < SMR_NJ; ++j) { P.sn[j] = __shfl(s, gbase + j); P.cs[j] = __shfl(c, gbase + j); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) P.q_last[k] = __shfl(x, gbase + 4 + k);
         return P;
     }
 };
@@ -1081,6 +1109,155 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
             p[j] = p1; v[j] = v1; ap[j] = an[j];
             if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
         }
+    }
+}
+
+// ---- the same check in two passes (the default; SMR_BRAKE_ROWS=1: brake_check_kernel above, for A/B runs) ----
+// brake_scan: the grid of brake_check, but a lane only walks its row (env x body against the static pieces, env x self-collision
+// pair) with LOWER BOUNDS - bound table / spheres / capsules, no hull is touched - and the same conservative advancement between
+// evaluations.  The first sample whose bound does not clear the safety distance is handed over as a job (env, row, segment, sample);
+// a row whose whole braking trajectory is cleared by bounds (most rows of most envs) is done.  brake_walk: one lane per job, dense
+// wavefronts - the walk of brake_check from the job's sample on with the real queries (hulls of all bodies in an LDS pool, the row
+// differs between the lanes).  The decision is the one of brake_check: a bound never exceeds the distance, so no sample that
+// brake_check would have found closer than the safety distance is skipped.
+__device__ __forceinline__ unsigned long long brake_job_word(int env, int row, int m, int sidx) {
+    return (unsigned long long)(unsigned)env | ((unsigned long long)row << 32) | ((unsigned long long)m << 40) | ((unsigned long long)sidx << 48);
+}
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void brake_scan_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    const int n_pair_rows = SELF ? S.n_self_pairs : 0;
+    const int row = (int)blockIdx.y;
+    const bool pair_row = SELF && row < n_pair_rows;
+    const int pair = pair_row ? row : 0;
+    const int body = pair_row ? S.self_pair[pair][0] : row - n_pair_rows;
+    const int partner = pair_row ? S.self_pair[pair][1] : -1;
+    if (!pair_row && !((S.static_mask >> body) & 1u)) return;
+    const int B = S.B;
+    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = e0 < B;
+    const int e = valid ? e0 : B - 1;
+    const int steps = valid ? st.brake_steps[e] : -1;      // < 0: braking timeout, latched by brake_plan_kernel already
+    float p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ], q_ref[SMR_NJ], lever[SMR_NJ];
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) {
+        p[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; ap[j] = st.a[j * B + e]; an[j] = st.a1[j * B + e]; q_ref[j] = p[j];
+        lever[j] = (partner >= 0 && j < partner) ? 0.f : S.sweep_R[body][j];
+    }
+    const float thr = S.brake_safety + kBoundSlack;
+    float margin = -1.f;
+    int found = -1;                                        // segment << 8 | sample of the first evaluation the bounds cannot clear
+    int max_steps = steps;                                 // of the wavefront: its lanes walk in step
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) max_steps = max(max_steps, __shfl_xor(max_steps, d));
+    for (int m = 0; m <= max_steps; ++m) {
+        const bool live = found < 0 && m <= steps;
+        for (int sidx = 1; sidx <= S.brake_checks; ++sidx) {
+            const float t = sidx == S.brake_checks ? S.dt : S.dt * (float)sidx / (float)S.brake_checks;
+            float qs[SMR_NJ], moved = 0.f;
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) { qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt); moved += fabsf(qs[j] - q_ref[j]) * lever[j]; }
+            const bool eval = live && found < 0 && !(moved * 1.0001f + 1e-6f < margin);
+            if (!__any(eval)) continue;
+            const float lb = pair_row ? self_pair_lower_bound(S, pair, qs, 3.0e38f) : static_lower_bound(S, body, qs);
+            if (eval) {
+                if (lb <= thr) found = (m << 8) | sidx;
+                else {
+                    margin = lb - thr - 1e-5f;
+#pragma unroll
+                    for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = qs[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) {
+            const float p1 = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt), v1 = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
+            p[j] = p1; v[j] = v1; ap[j] = an[j];
+            if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
+        }
+    }
+    // the jobs of the wavefront: one atomic
+    const unsigned long long has = __ballot(found >= 0);
+    if (has) {
+        const int lane = (int)__lane_id();
+        int base = 0;
+        if (lane == 0) base = atomicAdd(st.brake_job_count, __popcll(has));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (found >= 0) st.brake_jobs[base + __popcll(has & ((1ull << lane) - 1ull))] = brake_job_word(e, row, found >> 8, found & 255);
+    }
+}
+
+template <bool SELF>
+__global__ SMR_SIDE_KERNEL void brake_walk_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    __shared__ uint32_t pool[kBodyPoolDwords];
+    const int n_jobs = *st.brake_job_count;
+    if ((int)blockIdx.x * (int)blockDim.x >= n_jobs) return;           // (block uniform: before the pool is staged)
+    {
+        const SMR_GLOBAL uint32_t *g = (const SMR_GLOBAL uint32_t *)S.body_pool;
+        for (int i = threadIdx.x; i < S.body_pool_dwords; i += blockDim.x) pool[i] = g[i];
+        __syncthreads();
+    }
+    const BodyPool BP{pool};
+    const int B = S.B, n_pair_rows = SELF ? S.n_self_pairs : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_jobs; i += gridDim.x * blockDim.x) {
+        const unsigned long long w = st.brake_jobs[i];
+        const int e = (int)(unsigned)(w & 0xFFFFFFFFull), row = (int)((w >> 32) & 255ull), m0 = (int)((w >> 40) & 255ull), s0 = (int)((w >> 48) & 255ull);
+        const bool pair_row = SELF && row < n_pair_rows;
+        const int pair = pair_row ? row : 0;
+        const int body = pair_row ? S.self_pair[pair][0] : row - n_pair_rows;
+        const int partner = pair_row ? S.self_pair[pair][1] : -1;
+        const int steps = st.brake_steps[e];
+        const DPiece LP = BP.piece(body);
+        const LocalHull hull = BP.hull(body);
+        float p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ], q_ref[SMR_NJ], lever[SMR_NJ];
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) {
+            p[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; ap[j] = st.a[j * B + e]; an[j] = st.a1[j * B + e];
+            lever[j] = (partner >= 0 && j < partner) ? 0.f : S.sweep_R[body][j];
+        }
+        for (int m = 0; m < m0; ++m)                          // the state at the start of the job's segment
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) {
+                const float p1 = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt), v1 = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
+                p[j] = p1; v[j] = v1; ap[j] = an[j];
+                an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
+            }
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = p[j];
+        const float thr = S.brake_safety;
+        float margin = -1.f;
+        F3 warm = {0.f, 0.f, 0.f};
+        bool hit = false;
+        for (int m = m0; m <= steps && !hit; ++m) {
+            for (int sidx = (m == m0 ? s0 : 1); sidx <= S.brake_checks && !hit; ++sidx) {
+                const float t = sidx == S.brake_checks ? S.dt : S.dt * (float)sidx / (float)S.brake_checks;
+                float qs[SMR_NJ], moved = 0.f;
+#pragma unroll
+                for (int j = 0; j < SMR_NJ; ++j) { qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt); moved += fabsf(qs[j] - q_ref[j]) * lever[j]; }
+                if (moved * 1.0001f + 1e-6f < margin) continue;
+                const Xf T = body_frame(S, qs, body);
+                float d;
+                if (pair_row) d = self_pair_distance<true>(S, pair, qs, LP, hull, T, S.static_max, thr, &BP, nullptr, &warm);
+                else {
+                    d = 3.0e38f;
+                    for (int sp = 0; sp < S.n_static; ++sp)
+                        d = fminf(d, piece_distance<true>(S, S.static_piece[sp], T, LP, hull, T, S.static_max, thr, S.n_static == 1 ? &warm : nullptr));
+                }
+                if (d < thr) { hit = true; break; }
+                margin = d - thr - 1e-5f;
+#pragma unroll
+                for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = qs[j];
+            }
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) {
+                const float p1 = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt), v1 = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
+                p[j] = p1; v[j] = v1; ap[j] = an[j];
+                if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
+            }
+        }
+        if (hit) st.braked[e] = 1;                            // ctlp.py:3307-3312,3364-3368
     }
 }
 
@@ -1692,6 +1869,77 @@ __global__ void test_ball_distances_kernel(const DScene *__restrict__ Sp, const 
     out[4 * i] = dst; out[4 * i + 1] = dsf; out[4 * i + 2] = dmv; out[4 * i + 3] = contact ? 1.f : 0.f;
 }
 
+// ---- self-pair bound tables (smr_device.h, "Self pairs: bound tables"): one lane per cell of pair i's grid ----
+// The entry is a rigorous lower bound of the pair's distance at the cell centre: the smaller of the value the run returns and the
+// largest support-plane bound it saw (a stalled run returns an upper bound), margins subtracted, rounded down to kSelfTabStep.
+__global__ __launch_bounds__(256) void self_table_kernel(const DScene *__restrict__ Sp, int i, uint16_t *__restrict__ out, int n_cells) {
+    const DScene &S = *Sp;
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= n_cells) return;
+    const int nd = S.self_tab_nd[i];
+    float q[SMR_NJ] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int rest = cell;
+    for (int d = nd - 1; d >= 0; --d) {
+        const int n = S.self_tab_n[i][d], c = rest % n, j = SMR_NJ - nd + d;
+        rest /= n;
+        const float centre = S.pos_lo[j] + ((float)c + 0.5f) * S.self_tab_h[i][d];
+        if (j == 4) q[4] = centre; else if (j == 5) q[5] = centre; else q[6] = centre;
+    }
+    const int a = S.self_pair[i][0];
+    const DPiece LP = load_piece(S.pieces, S.link_piece[a]);
+    const GlobalHull hull = global_hull(S, S.link_piece[a], LP);
+    float lower = 0.f;
+    const float d = self_pair_distance<false, false>(S, i, q, LP, hull, body_frame(S, q, a), kSelfTabMax, 0.f, nullptr, nullptr, nullptr, &lower);
+    // a value beyond the cutoff is a lower bound already (bounding volumes, or a separating plane farther than the cutoff)
+    float v = d > kSelfTabMax ? kSelfTabMax : fminf(d, lower);
+    v = fminf(fmaxf(v - 2e-6f, 0.f), kSelfTabMax);
+    out[cell] = (uint16_t)floorf(v * (1.0f / kSelfTabStep));
+}
+
+// A step whose job list ran full (push_jobs / keys_kernel set overflow_env): the envs concerned get ALL their queries from this kernel,
+// one lane per env, every body and every sample in sequence with the plain per-sample routine of the component tests (collide_sample) -
+// slow, and exact.  The list holds 64 jobs per env, twelve times the average of uniformly drawn states, so this runs when most of a
+// batch sits inside the planets' bounding volumes at once (or the tests shrink the list with SMR_JOB_CAP); otherwise a block reads
+// one word per lane and leaves.  The results are minima / flags like those of the jobs, so a job that did fit changes nothing.
+__global__ __launch_bounds__(64) void overflow_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    const int B = S.B, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B || !st.overflow_env[e]) return;
+    const int N = S.checks_per_step, upd = S.updates_per_step / N;
+    const bool want_contact = S.term_moving && S.n_planets > 0 && st.moving_hit[e] == 0;
+    bool contact = false;
+    for (int k = N; k >= 1; --k) {
+        if (k < N && !(want_contact && !contact)) break;
+        const float t = k == N ? S.dt : S.dt * (float)k / (float)N;
+        float q[SMR_NJ];
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) q[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
+        int idx[SMR_MAX_PLANETS] = {0, 0};
+#pragma unroll
+        for (int p = 0; p < SMR_MAX_PLANETS; ++p)
+            if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + k * upd) % S.planet[p].n_orbit;
+        if (k == N) {
+            const Sample r = collide_sample(S, q, idx, true, false);
+            atomicMin(&st.env_dself[e], dist_bits(r.d_self));
+            if (S.planets_jobs) {
+                atomicMin(&st.env_dstatic[e], dist_bits(r.d_static));
+                if (r.d_moving <= S.moving_max) atomicMin(&st.env_min[e], dist_bits(r.d_moving));
+            }
+        }
+        if (S.planets_jobs && want_contact) contact = contact || collide_sample(S, q, idx, false, true).contact;
+    }
+    if (contact) st.res[e] = 1.f;                       // finish ORs the bodies' flags: body 0's slot will do
+}
+
+// the lower bounds the step's pruning uses for the self-collision pairs of n joint vectors (component test): out [n][SMR_MAX_SELF_PAIRS]
+__global__ void test_self_bounds_kernel(const DScene *__restrict__ Sp, const float *__restrict__ q, int n, float *__restrict__ out) {
+    const DScene &S = *Sp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int p = 0; p < SMR_MAX_SELF_PAIRS; ++p)
+        out[(size_t)i * SMR_MAX_SELF_PAIRS + p] = p < S.n_self_pairs ? self_tab_bound(S, p, q[i * SMR_NJ + 4], q[i * SMR_NJ + 5], q[i * SMR_NJ + 6]) : -kNoBound;
+}
+
 // ---- risk-aware stepping: actions.py:303-340, base.py:1498-1502,1598-1603 ----
 // row e of x: the risk observation of env e (obs.py:419-431: the observation without its target-point columns) followed by the
 // action the caller asks for
@@ -1768,6 +2016,7 @@ struct smr_env {
     int *risky_buf = nullptr;
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
     int job_blocks = 0;               // their persistent grid: two 512-lane blocks per CU
+    int walk_blocks = 0;              // brake_walk's grid: two 256-lane blocks per CU
     bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
     DState st;
@@ -1913,14 +2162,29 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed,
         // pair-job path (the default in planet scenes; SMR_COLLIDE_LANES=1: the lane-per-(env, body) collide kernel, for A/B runs)
         const char *lanes = getenv("SMR_COLLIDE_LANES");
         d.planets_jobs = !(lanes && atoi(lanes));
-        if (d.planets_jobs) {
-            std::vector<uint32_t> job_pool;
-            body_pool_tables(s, G, job_pool, d.static_mask | d.moving_mask | d.contact_mask);
+    }
+    {   // the job kernels' LDS pool: the hull tables of the bodies that take part in moving / contact / static queries (pair jobs) and
+        // of the bodies the self-collision pairs name; behind it the planets' vertices and descriptors and the pairs' cylinders
+        uint32_t self_mask = 0u;
+        for (int i = 0; i < d.n_self_pairs; ++i) { self_mask |= 1u << d.self_pair[i][0]; if (d.self_pair[i][1] >= 0) self_mask |= 1u << d.self_pair[i][1]; }
+        auto lds_bytes = [&](uint32_t mask, bool planets, std::vector<uint32_t> &pool) {
+            body_pool_tables(s, G, pool, mask);
+            return 4 * (pool.size() + (planets ? 4 * (size_t)d.auto_vn + kPlanetDescDwords * (size_t)d.auto_pn : 0) + kJobCylDwords);
+        };
+        std::vector<uint32_t> job_pool;
+        const uint32_t pair_mask = d.static_mask | d.moving_mask | d.contact_mask;
+        size_t bytes = lds_bytes((d.planets_jobs ? pair_mask : 0u) | self_mask, d.planets_jobs != 0, job_pool);
+        if (d.planets_jobs && bytes > 64 * 1024) {             // does not fit two blocks per CU: the planets stay with the lane form
+            d.planets_jobs = 0;
+            bytes = lds_bytes(self_mask, false, job_pool);
+        }
+        if (d.n_self_pairs > 0 && bytes > 64 * 1024) { env->err = "the hull tables of the self-collision pairs' bodies exceed the LDS pool of the job kernels"; return SMR_E_INVALID; }
+        d.jobs_on = (d.planets_jobs || d.n_self_pairs > 0) ? 1 : 0;
+        if (d.jobs_on) {
             uint32_t *dpool;
             if ((rc = dev_upload(env, &dpool, job_pool))) return rc;
             d.job_pool = dpool; d.job_pool_dwords = (int)job_pool.size();
-            env->job_lds_bytes = 4 * ((size_t)d.job_pool_dwords + 4 * (size_t)d.auto_vn + kPlanetDescDwords * (size_t)d.auto_pn);
-            if (env->job_lds_bytes > 64 * 1024) d.planets_jobs = 0;      // does not fit two blocks per CU: stay with the lane form
+            env->job_lds_bytes = bytes;
         }
     }
     if (s.use_ball) {
@@ -1965,7 +2229,28 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed,
     d.kin_mode = s.kinematic_state_sampling_mode; d.kin_prob = (float)s.kinematic_state_sampling_probability;
     d.stay_prob = (float)s.stay_in_state_probability;
     d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32); d.env_base = env_index_base;
+    // the range of self distances anything reads: the reward's min(1, d / max_reward_distance) and the d < collision_distance flag
+    // (rewards.py:119-126); never beyond the cut-off of the queries (ctlp.py:354-366)
+    d.self_cut = std::min(d.static_max, std::max(d.self_max_reward != 0.f ? d.self_max_dist : 0.f, d.collision_dist));
     if ((rc = dev_alloc(env, &env->dscene, 1))) return rc;
+    // self-pair bound tables: laid out here, filled by the device GJK itself (the scene goes up without them first)
+    const size_t tab_entries = getenv("SMR_NO_SELF_TABLES") ? 0 : self_table_layout(s, G, d);
+    if (tab_entries > 0) {
+        uint16_t *tab;
+        if ((rc = dev_alloc(env, &tab, tab_entries))) return rc;
+        SMR_HIP(hipMemcpy(env->dscene, &d, sizeof d, hipMemcpyHostToDevice));        // layout in, self_tab still null: the builder makes the literal queries
+        for (int i = 0; i < d.n_self_pairs; ++i) {
+            if (d.self_tab_nd[i] == 0) continue;
+            int cells = 1;
+            for (int k = 0; k < d.self_tab_nd[i]; ++k) cells *= d.self_tab_n[i][k];
+            hipLaunchKernelGGL(self_table_kernel, dim3((cells + 255) / 256), dim3(256), 0, nullptr, env->dscene, i, tab + d.self_tab_off[i], cells);
+        }
+        SMR_HIP(hipGetLastError());
+        SMR_HIP(hipDeviceSynchronize());
+        d.self_tab = tab;
+    } else {
+        for (int i = 0; i < SMR_MAX_SELF_PAIRS; ++i) d.self_tab_nd[i] = 0;
+    }
     SMR_HIP(hipMemcpy(env->dscene, &d, sizeof d, hipMemcpyHostToDevice));
     return SMR_OK;
 }
@@ -2040,30 +2325,32 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) || (rc = dev_alloc(env, &st.brake_job_count, 1)) ||
+        (rc = dev_alloc(env, &st.brake_jobs, scene->check_braking_trajectory_collisions ? (size_t)(scene->n_bodies + scene->n_self_pairs) * B : 1)) ||
         (rc = dev_alloc(env, &st.brake_acc, scene->check_braking_trajectory_collisions ? (size_t)(scene->brake_timeout_steps + 1) * SMR_NJ * B : 1)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)) || (rc = dev_alloc(env, &env->spawn_tag_lists, 3 * B)))
         return fail(rc);
-    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12) || hipMemset(st.lb_moving, 0xFF, (size_t)scene->n_bodies * B * 4) || hipMemset(st.braked, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12) || hipMemset(st.lb_moving, 0xFF, (size_t)scene->n_bodies * B * 4) || hipMemset(st.braked, 0, B * 4) || hipMemset(st.brake_job_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts; st.spawn_tags = env->spawn_tag_lists;
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
-    if (env->hscene.planets_jobs) {
+    if (env->hscene.jobs_on) {
         const size_t NB = (size_t)scene->n_bodies, N = (size_t)scene->collision_checks_per_step;
-        // job list: the table runs the keys kernel defers (at most one per (env, body)) always fit; behind them what the first kernel adds
-        // (2.9 pair jobs per env on uniformly drawn states) - when it finds the list full it makes the run itself
-        size_t cap = B * NB + std::max<size_t>(B * 40, 65536);
-        if (const char *v = getenv("SMR_JOB_CAP")) cap = B * NB + (size_t)std::max(0, atoi(v));       // tests: force the full-list path
+        const bool pj = env->hscene.planets_jobs != 0;
+        // job list: 64 entries per env - uniformly drawn states make 4.6 pair jobs, 0.3 self-pair jobs and 0.06 table runs per env.  A
+        // step that needs more hands the envs concerned to overflow_kernel.
+        size_t cap = B * 64 + 65536;
+        if (const char *v = getenv("SMR_JOB_CAP")) cap = (size_t)std::max(0, atoi(v));       // tests: force the full-list path
         if (cap > 0x7FFFFFFFull) { env->err = "num_envs too large for the job list"; return fail(SMR_E_INVALID); }
         st.job_cap = (int)cap;
-        if ((rc = dev_alloc(env, &st.keyw, 7 * NB * B)) || (rc = dev_alloc(env, &st.env_best, B)) || (rc = dev_alloc(env, &st.env_min, B)) ||
-            (rc = dev_alloc(env, &st.env_dstatic, B)) || (rc = dev_alloc(env, &st.items, N > 1 ? B * NB * (N - 1) : 1)) ||
-            (rc = dev_alloc(env, &st.jobs, cap)) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) ||
+        if ((rc = dev_alloc(env, &st.keyw, pj ? 7 * NB * B : 1)) || (rc = dev_alloc(env, &st.env_best, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_min, pj ? B : 1)) ||
+            (rc = dev_alloc(env, &st.env_dstatic, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_dself, B)) || (rc = dev_alloc(env, &st.items, (pj && N > 1) ? B * NB * (N - 1) : 1)) ||
+            (rc = dev_alloc(env, &st.jobs, std::max<size_t>(cap, 1))) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) || (rc = dev_alloc(env, &st.job_next, 1)) ||
             (rc = dev_alloc(env, &st.overflow_env, B))) return fail(rc);
-        if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+        if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4) || hipMemset(st.job_next, 0, 4) || hipMemset(st.overflow_env, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
         env->job_blocks = 2 * std::max(prop.multiProcessorCount, 1);
@@ -2108,6 +2395,11 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if ((env->tp_refill_slots || env->stage_balls) &&
             (hipStreamCreateWithFlags(&env->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess)) { env->err = "could not create the second side stream"; return fail(SMR_E_HIP); }
+    }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
+        env->walk_blocks = 2 * std::max(prop.multiProcessorCount, 1);
     }
     if (hipDeviceSynchronize() != hipSuccess) { env->err = "hipDeviceSynchronize failed"; return fail(SMR_E_HIP); }
     *out = env;
@@ -2411,33 +2703,52 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         LaunchTimer t(env, SMR_K_BRAKE);
         hipLaunchKernelGGL(brake_plan_kernel, dim3(((size_t)B * 8 + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st);
         const dim3 grid((B + 255) / 256, env->hscene.n_bodies + env->hscene.n_self_pairs);
-        if (env->hscene.n_self_pairs > 0) hipLaunchKernelGGL((brake_check_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL((brake_check_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+        static const bool rows = [] { const char *v = getenv("SMR_BRAKE_ROWS"); return !v || atoi(v); }();      // A/B switch (0: the two-pass form, measured slower so far)
+        const bool self = env->hscene.n_self_pairs > 0;
+        if (rows) {
+            if (self) hipLaunchKernelGGL((brake_check_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+            else hipLaunchKernelGGL((brake_check_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+        } else {
+            const dim3 wgrid(std::max(env->walk_blocks, 1));
+            if (self) {
+                hipLaunchKernelGGL((brake_scan_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+                hipLaunchKernelGGL((brake_walk_kernel<true>), wgrid, dim3(256), 0, env->stream, env->dscene, env->st);
+            } else {
+                hipLaunchKernelGGL((brake_scan_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+                hipLaunchKernelGGL((brake_walk_kernel<false>), wgrid, dim3(256), 0, env->stream, env->dscene, env->st);
+            }
+        }
         hipLaunchKernelGGL(brake_apply_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st);
         SMR_HIP(hipGetLastError());
     }
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
-        const bool self = env->hscene.n_self_pairs > 0, autop = env->hscene.planets_auto != 0;
+        const bool self = scene_extra(env), autop = env->hscene.planets_auto != 0, pairs = env->hscene.n_self_pairs > 0;
         const int block = autop ? 256 : 64;
-        const dim3 grid((B + block - 1) / block, env->hscene.n_bodies + env->hscene.n_self_pairs);
+        const dim3 grid((B + block - 1) / block, env->hscene.n_bodies);
+        const dim3 jgrid(env->job_blocks);
+        // the self-collision pairs: bounds per env, the survivors as jobs (worked by the jobs kernel behind the pair jobs of a planet
+        // scene, by a launch of its own otherwise)
+        if (pairs) hipLaunchKernelGGL(self_bounds_kernel, dim3((B + 255) / 256, env->hscene.n_self_pairs), dim3(256), 0, env->stream, env->dscene, env->st);
         if (env->hscene.planets_jobs) {
-            const dim3 jgrid(env->job_blocks);
             const int env_blocks = (B + 255) / 256;
             const dim3 egrid(env_blocks + (env->N > 1 ? 4 * env->job_blocks : 0));      // behind the env blocks: a fixed grid striding over the items
             if (self) {
                 hipLaunchKernelGGL((keys_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
                 hipLaunchKernelGGL((enumerate_kernel<true>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
-                hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
             } else {
                 hipLaunchKernelGGL((keys_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
                 hipLaunchKernelGGL((enumerate_kernel<false>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
-                hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
             }
         } else if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        if (env->hscene.jobs_on) {
+            if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+            else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+            hipLaunchKernelGGL(overflow_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st);
+        }
     }
     SMR_HIP(hipGetLastError());
     const bool staged = env->staged && env->auto_reset;
@@ -2699,6 +3010,19 @@ int smr_test_distances(smr_env_t *env, const float *q_host, const int32_t *plane
     SMR_HIP(hipGetLastError());
     SMR_HIP(hipStreamSynchronize(env->stream));
     SMR_HIP(hipMemcpy(out, o, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_test_self_bounds(smr_env_t *env, const float *q_host, int32_t n, float *out) {
+    if (!env || !q_host || n <= 0 || !out) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    TmpBuf t{env, {}};
+    float *q = t.up(q_host, (size_t)n * 7), *o = t.up<float>(nullptr, (size_t)n * SMR_MAX_SELF_PAIRS);
+    if (!q || !o) { env->err = "smr_test_self_bounds: allocation failed"; return SMR_E_HIP; }
+    hipLaunchKernelGGL(test_self_bounds_kernel, dim3((n + 63) / 64), dim3(64), 0, env->stream, env->dscene, q, n, o);
+    SMR_HIP(hipGetLastError());
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    SMR_HIP(hipMemcpy(out, o, (size_t)n * SMR_MAX_SELF_PAIRS * 4, hipMemcpyDeviceToHost));
     return SMR_OK;
 }
 

@@ -34,13 +34,16 @@ inline bool body_pool_tables(const smr_scene_t &s, const HostGeometry &G, std::v
         if (!((mask >> b) & 1u)) continue;
         const int piece = s.link_piece[b];
         const DPiece &P = G.pieces[piece];
-        const uint32_t v_off = (uint32_t)pool.size(), ids_off = v_off + 4u * (uint32_t)P.count, start_off = ids_off + (uint32_t)P.ids_count;
+        // the vertex list is padded to a multiple of 8 with copies of its last vertex: the job kernels scan it eight at a time
+        const uint32_t padded = ((uint32_t)P.count + 7u) & ~7u;
+        const uint32_t v_off = (uint32_t)pool.size(), ids_off = v_off + 4u * padded, start_off = ids_off + (uint32_t)P.ids_count;
         const uint32_t piece_off = start_off + kStartCells / 4;
         pool[(size_t)kBodyPoolHead * b] = v_off; pool[(size_t)kBodyPoolHead * b + 1] = ids_off; pool[(size_t)kBodyPoolHead * b + 2] = start_off;
         pool[(size_t)kBodyPoolHead * b + 3] = piece_off;
         pool.resize((size_t)piece_off + kPieceDwords);
         std::memcpy(pool.data() + piece_off, &P, 4 * kPieceDwords);
         std::memcpy(pool.data() + v_off, G.verts.data() + P.begin, 16 * (size_t)P.count);
+        for (uint32_t k = (uint32_t)P.count; k < padded; ++k) std::memcpy(pool.data() + v_off + 4u * k, G.verts.data() + P.begin + P.count - 1, 16);
         std::memcpy(pool.data() + ids_off, G.ids4.data() + P.ids_begin, 4 * (size_t)P.ids_count);
         std::memcpy(pool.data() + start_off, G.start.data() + (size_t)kStartCells * piece, kStartCells);
     }
@@ -420,6 +423,55 @@ inline void sweep_tables(const smr_scene_t &s, const HostGeometry &G, DScene &d)
         for (int k = 0; k < P.count; ++k) { const float4 &v = G.verts[(size_t)P.begin + k]; r = std::max(r, std::sqrt((double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z)); }
         d.ball_bound_radius = (float)((r + P.margin) * 1.00001 + 1e-6);
     }
+}
+
+// Layout of the self-pair bound tables (smr_device.h, "Self pairs: bound tables"): a pair (body mounted on iiwa_link_7, partner link k)
+// with k >= 4 gets a grid over the joints k .. 6 - fine for two axes, coarse for three.  Returns the number of uint16 entries in all.
+// lever of joint j: the body's points stay within sweep_R of the joint's axis; the last joint's axis is fixed in the body's parent
+// frame, so there the distance from the axis itself is taken (a third less than the distance from the frame origin).
+// Also the LDS slots of the world-fixed cylinders the pairs name (self_cyl_slot).
+inline size_t self_table_layout(const smr_scene_t &s, const HostGeometry &G, DScene &d) {
+    size_t total = 0;
+    int n_cyl = 0;
+    for (int i = 0; i < SMR_MAX_SELF_PAIRS; ++i) { d.self_tab_nd[i] = 0; d.self_tab_off[i] = 0; d.self_cyl_slot[i] = -1; }
+    for (int i = 0; i < s.n_self_pairs; ++i) {
+        const int a = s.self_pair[i][0], partner = s.self_pair[i][1];
+        if (partner < 0) { d.self_cyl_slot[i] = n_cyl++; continue; }
+        if (a < SMR_NLINK || partner < 4 || partner > 5) continue;
+        const int nd = SMR_NJ - partner;
+        // cells: ~0.016 rad for two axes (98 k entries), ~0.09 rad for three (180 k)
+        const double width = nd == 2 ? 0.016 : 0.092;
+        size_t cells = 1;
+        for (int k = 0; k < nd; ++k) {
+            const int j = SMR_NJ - nd + k;
+            const double range = s.pos_hi[j] - s.pos_lo[j];
+            const int n = std::max(1, (int)std::ceil(range / width));
+            d.self_tab_n[i][k] = n;
+            d.self_tab_h[i][k] = (float)(range / n);
+            d.self_tab_ih[i][k] = (float)(n / range);
+            double lever = d.sweep_R[a][j];
+            if (j == SMR_NJ - 1) {                          // distance from the axis of the last joint (through the parent frame's origin)
+                const DPiece &P = G.pieces[s.link_piece[a]];
+                const double *ax = s.joint_axis[j];
+                double r = 0;
+                for (int v = 0; v < P.count; ++v) {
+                    const float4 &p = G.verts[(size_t)P.begin + v];
+                    double x[3];
+                    for (int c = 0; c < 3; ++c) x[c] = s.body_xyz[a][c] + s.body_rot[a][3 * c] * p.x + s.body_rot[a][3 * c + 1] * p.y + s.body_rot[a][3 * c + 2] * p.z;
+                    const double t = x[0] * ax[0] + x[1] * ax[1] + x[2] * ax[2];
+                    const double e[3] = {x[0] - t * ax[0], x[1] - t * ax[1], x[2] - t * ax[2]};
+                    r = std::max(r, std::sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]));
+                }
+                lever = std::min(lever, (r + P.margin) * 1.00001 + 1e-6);
+            }
+            d.self_tab_lever[i][k] = (float)lever;
+            cells *= (size_t)n;
+        }
+        d.self_tab_nd[i] = nd;
+        d.self_tab_off[i] = (int)total;
+        total += cells;
+    }
+    return total;
 }
 
 // planet_step: the farthest any vertex of the planet's pieces moves from one orbit index to the next (float32 pose table

@@ -244,6 +244,14 @@ class VecSafeMotionsEnv:
         return out
 
 
+    def test_self_bounds(self, q):
+        """[n][n_self_pairs] table lower bounds of the self-collision pairs' distances (-3e38: the pair has no table)"""
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, NJ)
+        out = np.zeros((len(q), 16), np.float32)
+        rc = self._L.smr_test_self_bounds(self._h, q.ctypes.data, len(q), out.ctypes.data)
+        _lib.check(self._L, self._h, rc, "smr_test_self_bounds")
+        return out[:, :int(self.scene.struct.n_self_pairs)]
+
     def test_ball_distances(self, q, ball, k):
         q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, NJ)
         ball = np.ascontiguousarray(ball, dtype=np.float32).reshape(-1, 10)

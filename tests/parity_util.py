@@ -11,6 +11,21 @@ import numpy as np
 TIE = 2e-5
 
 
+def self_cut(scene):
+    """The range of self-collision distances the reference reads: the reward's min(1, d / max_reward_distance) and the flag
+    d < 0.001 (rewards.py:119-126).  The product reports the exact distance below it and the cut-off value ("no closest point")
+    at or beyond it (include/safemotions_hip.h, SMR_INFO_D_SELF); the oracle makes the literal queries up to the cut-off."""
+    s = scene.struct
+    return min(float(s.static_max_distance), max(float(s.self_max_reward_distance) if s.self_max_reward != 0 else 0.0, float(s.collision_distance)))
+
+
+def relevant(d, scene):
+    """distance columns (d_static, d_self, d_moving, ...) with the self distance clipped to the range the reference reads"""
+    d = np.array(d, dtype=np.float64, copy=True)
+    d[..., 1] = np.minimum(d[..., 1], self_cut(scene))
+    return d
+
+
 def cubic(q0, v0, a0, a1, t, dt):
     q0, v0, a0, a1 = (np.asarray(x, dtype=np.float64) for x in (q0, v0, a0, a1))
     return q0 + v0 * t + 0.5 * a0 * t * t + (a1 - a0) / dt * t ** 3 / 6

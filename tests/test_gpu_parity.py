@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from parity_util import TIE, braking_decision_is_tie, explain_mismatches
+from parity_util import TIE, braking_decision_is_tie, explain_mismatches, relevant, self_cut
 
 pytestmark = pytest.mark.gpu
 
@@ -105,7 +105,7 @@ def test_step_against_golden(built, name):
             assert np.array_equal(st["target_count"][ok], g["target_count"][t][ok]) and np.abs(st["target"] - g["target"][t])[ok].max() < 2e-5
         gi = g["info"][t]
         near = (np.abs(gi[:, :3] - 0.001) < TIE).any(axis=1)      # below 1 mm only "d < 0.001" is defined: the clamp to 0 may differ on a tie
-        assert np.abs(vals[ok & ~near, :3] - gi[ok & ~near, :3]).max() < 5e-6
+        assert np.abs(relevant(vals[:, :3], env.scene)[ok & ~near] - relevant(gi[:, :3], env.scene)[ok & ~near]).max() < 5e-6
         gs = g["state"][t]
         A = np.array(env.scene.struct.acc_max)
         assert np.abs(st["q"] - gs[:, :7])[ok].max() < 2e-6 and np.abs(st["v"] - gs[:, 7:14])[ok].max() < 2e-5
@@ -324,7 +324,7 @@ def test_ball_step_against_golden(built):
         ok = ~bad & ~((np.abs(gi[:, 0] - 0.001) < TIE) | (np.abs(gi[:, 2] - 0.001) < TIE))
         assert (np.abs(obs[ok] - g["obs"][t][ok]) < BALL_OBS_TOL).all()
         assert np.abs(rew[ok] - g["reward"][t][ok]).max() < 5e-5
-        assert np.abs(vals[ok, :3] - gi[ok, :3]).max() < 5e-6
+        assert np.abs(relevant(vals[:, :3], env.scene)[ok] - relevant(gi[:, :3], env.scene)[ok]).max() < 5e-6
         assert np.abs(st["ball"] - g["ball"][t])[ok].max() < 2e-5                  # new balls: same launch state
         gs = g["state"][t]
         env.set_state(q=gs[:, :7].astype(np.float32), v=gs[:, 7:14].astype(np.float32), a=gs[:, 14:].astype(np.float32),
@@ -430,6 +430,69 @@ def test_ball_machine_components_against_oracle(built):
 
 
 @pytest.mark.gpu
+def test_self_pair_bound_tables_are_lower_bounds(built):
+    """The bound tables of the near self-collision pairs (csrc/smr_device.h "Self pairs: bound tables"): for random and for
+    near-collision configurations the bound never exceeds the oracle's float64 distance of the literal query (ctlp.py:3345-3372),
+    and it clears the range the reward reads for most configurations - that is what it is for."""
+    from oracle.oracle import OracleEnv
+    env = _bm_env(64, seed=0)
+    s = env.scene.struct
+    ora = OracleEnv(env.scene, 1)
+    rng = np.random.default_rng(3)
+    lo, hi = np.array(s.pos_lo), np.array(s.pos_hi)
+    q = rng.uniform(lo, hi, (1500, 7))
+    q[1000:, 4:] = q[1000:1001, 4:] + rng.normal(size=(500, 3)) * 0.05           # a cluster inside a few cells
+    q = np.clip(q, lo, hi).astype(np.float32)
+    lb = env.test_self_bounds(q)
+    tabled = [i for i in range(s.n_self_pairs) if s.self_pair[i][1] in (4, 5)]
+    assert len(tabled) == 4 and (lb[:, tabled] > -1e30).all() and (lb[:, [i for i in range(s.n_self_pairs) if i not in tabled]] < -1e30).all()
+    cut = self_cut(env.scene)
+    for i in tabled:
+        d = np.array([ora.self_pair_distance(q[n].astype(np.float64), i) for n in range(len(q))])
+        informative = lb[:, i] > 0
+        assert (lb[informative, i] <= d[informative] + 1e-6).all(), (i, float((lb[:, i] - d)[informative].max()))
+        cleared = lb[:1000, i] > cut
+        assert cleared.mean() > (0.75 if s.self_pair[i][1] == 5 else 0.85), (i, float(cleared.mean()))
+        assert (d[:1000][cleared] > cut).all()
+        # tightness where it matters: the two-angle tables lose a few millimetres, the three-angle tables a few centimetres
+        loss = (np.minimum(d, 0.25) - lb[:, i])[d < 0.25]
+        assert np.median(loss) < (0.006 if s.self_pair[i][1] == 5 else 0.05), (i, float(np.median(loss)))
+    env.close()
+
+
+@pytest.mark.gpu
+def test_job_list_overflow_is_worked_by_the_overflow_kernel(built, monkeypatch):
+    """A job list that is far too short (SMR_JOB_CAP): the envs whose jobs did not fit get all their queries from overflow_kernel -
+    same distances, flags and rewards as the run with the full list."""
+    import torch
+    B = 1024
+    full = _bm_env(B, seed=11)
+    full.reset()
+    st = full.get_state()
+    monkeypatch.setenv("SMR_JOB_CAP", "300")
+    short = _bm_env(B, seed=11)
+    monkeypatch.delenv("SMR_JOB_CAP")
+    rng = np.random.default_rng(2)
+    for t in range(3):
+        short.set_state(**{k: st[k] for k in STATE_KEYS})
+        full.set_state(**{k: st[k] for k in STATE_KEYS})
+        act = torch.from_numpy(rng.uniform(-1, 1, (B, 7)).astype(np.float32)).cuda()
+        o1, r1, d1, i1 = full.step(act)
+        o2, r2, d2, i2 = short.step(act)
+        v1, v2 = i1["values"].cpu().numpy(), i2["values"].cpu().numpy()
+        tie = (np.abs(v1[:, :3] - 0.001) < TIE).any(axis=1) | (np.abs(v2[:, :3] - 0.001) < TIE).any(axis=1)
+        assert np.abs(v1[~tie, :3] - v2[~tie, :3]).max() < 2e-6
+        flags = (d1 != d2).cpu().numpy() | (i1["termination_reason"] != i2["termination_reason"]).cpu().numpy()
+        assert int((flags & ~tie).sum()) <= 2                                  # (a contact distance on its 0.02 m threshold)
+        assert np.abs((r1 - r2).cpu().numpy()[~tie & ~flags]).max() < 2e-5
+        st = full.get_state()
+        if d1.any():
+            full.reset(mask=d1)
+            st = full.get_state()
+    full.close(); short.close()
+
+
+@pytest.mark.gpu
 def test_ball_machine_rollout_and_reset_against_oracle(built):
     import torch
     from oracle.oracle import OracleEnv
@@ -457,7 +520,7 @@ def test_ball_machine_rollout_and_reset_against_oracle(built):
         good = ~bad
         assert (np.abs(obs[good] - o_obs[good]) < OBS_TOL).all()
         assert np.abs(rew[good] - o_rew[good]).max() < 5e-5
-        assert np.abs(info["values"].cpu().numpy()[good, 1] - o_info[good, 1]).max() < 5e-6      # self distance
+        assert np.abs(relevant(info["values"].cpu().numpy()[:, :3], env.scene)[good, 1] - relevant(o_info[:, :3], env.scene)[good, 1]).max() < 5e-6      # self distance
         reasons += o_reason[o_done.astype(bool)].tolist()
         if done.any():
             env.reset(mask=torch.from_numpy(done).cuda())
@@ -713,7 +776,7 @@ def test_planet_scene_variants_against_oracle(built, variant):
         good = ~bad
         assert np.abs(obs[good] - o_obs[good]).max() < 2e-5 and np.abs(rew[good] - o_rew[good]).max() < 5e-5
         ok = good & ~tie
-        assert np.abs(vals[ok, :3] - o_info[ok, :3]).max() < 5e-6
+        assert np.abs(relevant(vals[:, :3], env.scene)[ok] - relevant(o_info[:, :3], env.scene)[ok]).max() < 5e-6
         n_done += int(o_done.sum())
         if done.any():
             env.reset(mask=torch.from_numpy(done).cuda())
