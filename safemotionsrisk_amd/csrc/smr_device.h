@@ -179,8 +179,6 @@ struct DState {
     float *brake_acc;          // [brake_timeout_steps + 1][7][B] end acceleration of braking segment m >= 1 behind the planned step
                                // ([0]: the braking acceleration at the current state, what adapt_action puts in place of the action)
     int *brake_steps;          // [B] braking segments until the robot stands (-1: not within the braking timeout)
-    unsigned long long *brake_jobs;   // [rows x B] (env, row, segment, sample) from which brake_walk takes over a row of brake_scan
-    int *brake_job_count;      // [1] cleared by plan_kernel
     float *lb_moving;          // [n_bodies][B] lower bound of the body's distance to every moving piece at the end of the last step
                                // (< 0: none - new episode, injected state); the next step's lanes rule out their first samples with it
     int *done_list;            // [B]
@@ -228,6 +226,7 @@ struct DState {
     unsigned *env_min;                 // [B] float bits of the env's moving-obstacle distance: atomicMin over its jobs (non-negative floats
                                        //     order like their bits); plan_kernel starts it at moving_max + 0.002
     unsigned *env_dstatic;             // [B] ... of the static distance found by deferred table runs (starts at static_max)
+    float *frames;                     // [n_bodies][B][12] frame of (body, env) at t = dt: keys kernel -> the end-of-step jobs (job_setup)
     unsigned *env_dself;               // [B] ... of the self-collision distance: atomicMin over the env's self-pair jobs (starts at static_max)
     unsigned long long *items;         // intermediate contact samples still to be tested: job words (env, body, k) of kind kJobItem
     unsigned long long *jobs;          // GJK runs to make: job words (env, body, piece, k, kind)
@@ -247,6 +246,7 @@ __device__ __forceinline__ void sampling_exhausted(const DState &st, int bit) { 
 // small vector algebra
 // ---------------------------------------------------------------------------------------------
 struct F3 { float x, y, z; };
+typedef float V4 __attribute__((vector_size(16)));       // a plain 16-byte vector: loads / stores through address-space pointers (dwordx4)
 __device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ F3 operator*(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
@@ -840,6 +840,11 @@ struct BodyPool {
     __device__ __forceinline__ DPiece piece(int b) const { return piece_from_words((const int *)(pool + pool[kBodyPoolHead * b + 3])); }
 };
 
+// quotient to 1 ulp of the reciprocal (v_rcp_f32 + a multiplication instead of the ten instructions of an IEEE division): for the
+// barycentric parameters of the sub-simplex solves - a relative error of 1e-7 in a parameter moves the closest point by less than
+// 1e-7 of an edge length
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
 // closest point of segment (a,b) to the origin; mask: bit0 a, bit1 b support it
 __device__ __forceinline__ F3 seg_closest(F3 a, F3 b, int &mask) {
     F3 e = b - a;
@@ -847,7 +852,7 @@ __device__ __forceinline__ F3 seg_closest(F3 a, F3 b, int &mask) {
     if (t <= 0.f) { mask = 1; return a; }
     if (t >= den) { mask = 2; return b; }
     mask = 3;
-    return a + (t / den) * e;
+    return a + fast_div(t, den) * e;
 }
 
 // Closest point of triangle (a,b,c) to the origin; mask: bit0 a, bit1 b, bit2 c support it.
@@ -862,7 +867,7 @@ __device__ __forceinline__ F3 tri_closest(F3 a, F3 b, F3 c, int &mask) {
     float la = dot(n, cross(b, c)), lb = dot(n, cross(c, a)), lc = dot(n, cross(a, b));   // la + lb + lc = nn
     if (nn > 0.f && la >= 0.f && lb >= 0.f && lc >= 0.f) {
         mask = 7;
-        return (dot(a, n) / nn) * n;                      // foot of the perpendicular
+        return fast_div(dot(a, n), nn) * n;               // foot of the perpendicular
     }
     // outside (or degenerate): the closest point lies on an edge opposite to a negative coordinate
     float best = 3.0e38f;
@@ -1736,7 +1741,8 @@ struct LaneInput {
 };
 // k_first .. k_need: the intermediate samples that still need a test (empty when k_first > k_need); lb_end: the bound at t = dt
 struct LaneResult { bool contact; float d_static, d_moving; int k_first, k_need; float lb_end; bool static_pending;
-                    unsigned best; float ub; };   // KEYS_ONLY: the best candidate (key << 5 | piece; ~0u: none) and an upper bound of ITS distance
+                    unsigned best; float ub;      // KEYS_ONLY: the best candidate (key << 5 | piece; ~0u: none) and an upper bound of ITS distance
+                    Xf frame; };                  // KEYS_ONLY: the body's frame at t = dt, handed on to the jobs of this (env, body)
 
 // frame of body l at time t of the step's cubic
 template <bool SELF, bool FAST = false>
@@ -1799,6 +1805,7 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
         return out;
     }
     const Xf T = lane_frame<SELF>(S, l, in, S.dt);
+    if (KEYS_ONLY) out.frame = T;
     float lb = -1.f;                                    // lower bound of the distance to every moving piece at t = dt (< 0: none)
     Sample r;
     if (!AUTO && S.use_ball) {           // (the lane-autonomous planet queries exist in planet scenes only)
@@ -2029,43 +2036,13 @@ __device__ inline float self_pair_lower_bound(const DScene &S, int i, const floa
     return fmaxf(lb, __builtin_amdgcn_sqrtf(seg_seg_dist2(a0, a1, b0, b1)) * 0.99999f - 1e-6f - A.cap_r - LP.cap_r - margins);
 }
 
-// ... and of body b (wave uniform) against the static pieces: the sphere / box and capsule / table-top bounds of piece_distance
-__device__ inline float static_lower_bound(const DScene &S, int b, const float q[SMR_NJ]) {
-    const DPiece B = load_piece(S.pieces, S.link_piece[b]);
-    const int link = b < SMR_NLINK ? b : SMR_NLINK - 1;
-    Xf T = fk_base(S);
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) if (j < link) fk_advance_fast(S, j, q[j], T);
-    if (b >= SMR_NLINK) T = mounted_frame(S, b, T);
-    const F3 cb = apply(T, F3{B.cx, B.cy, B.cz});
-    const F3 b0 = apply(T, F3{B.cap_a[0], B.cap_a[1], B.cap_a[2]}), b1 = apply(T, F3{B.cap_b[0], B.cap_b[1], B.cap_b[2]});
-    float lb = 3.0e38f;
-    for (int s = 0; s < S.n_static; ++s) {
-        const DPiece A = load_piece(S.pieces, S.static_piece[s]);
-        const float margins = A.margin + B.margin;
-        const F3 d = F3{A.cx, A.cy, A.cz} - cb;
-        const float ex = fmaxf(fabsf(d.x) - A.hx, 0.f), ey = fmaxf(fabsf(d.y) - A.hy, 0.f), ez = fmaxf(fabsf(d.z) - A.hz, 0.f);
-        float l = __builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) * 0.99999f - 1e-6f - B.radius - margins;
-        if (A.kind == kPieceAlignedBox) l = fmaxf(l, fminf(b0.z, b1.z) - B.cap_r - A.btop - margins - 1e-6f);
-        lb = fminf(lb, l);
-    }
-    return lb;
-}
-
-// cyl: the LDS copy of the world-fixed cylinders' parameters (8 floats per slot: centre xyz, radius, half length; stage_job_tables)
-template <bool SELF>
-__device__ inline void job_setup(const DScene &S, const BodyPool &BP, const float *pv, const float *pd, const float *cyl, const LaneInput &in,
-                                 const Job &jb, float cutoff, float stop_below, JobLane &J) {
-    const int N = S.checks_per_step, upd = S.updates_per_step / N;
-    const float t = jb.k >= N ? S.dt : S.dt * (float)jb.k / (float)N;
-    if (SELF && jb.kind == kJobSelf) {
+// the GJK run of self-collision pair `pair` at joint vector qs
+__device__ inline void self_job_setup(const DScene &S, const BodyPool &BP, const float *cyl, const float qs[SMR_NJ], int pair, float cutoff,
+                                      float stop_below, JobLane &J) {
         // pair (a, partner): the partner link's hull is climbed in ITS frame, the body's vertices are scanned under XA = partner^-1 o body
         // (both frames from one pass down the chain: the partner link's is a prefix of the body's); against the world-fixed cylinder
         // the body's hull is climbed under its world frame, as in a table run
-        const int a = S.self_pair[jb.piece][0], partner = S.self_pair[jb.piece][1];
-        float qs[SMR_NJ];
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt);
+        const int a = S.self_pair[pair][0], partner = S.self_pair[pair][1];
         const int link_a = a < SMR_NLINK ? a : SMR_NLINK - 1;
         Xf Ta = fk_base(S), Tp = Ta;
 #pragma unroll
@@ -2087,7 +2064,7 @@ __device__ inline void job_setup(const DScene &S, const BodyPool &BP, const floa
             J.is_static = false;
             J.g.start(apply(J.XA, F3{LA.cx, LA.cy, LA.cz}) - F3{LP.cx, LP.cy, LP.cz}, cutoff + J.margins, stop_below + J.margins);
         } else {
-            const float *c = cyl + 8 * S.self_cyl_slot[jb.piece];
+            const float *c = cyl + 8 * S.self_cyl_slot[pair];
             J.hull = BP.hull(a);
             J.T = Ta;
 #pragma unroll
@@ -2098,15 +2075,33 @@ __device__ inline void job_setup(const DScene &S, const BodyPool &BP, const floa
             J.is_static = true;
             J.g.start(F3{c[0], c[1], c[2]} - apply(Ta, F3{LA.cx, LA.cy, LA.cz}), cutoff + J.margins, stop_below + J.margins);
         }
+}
+
+// cyl: the LDS copy of the world-fixed cylinders' parameters (8 floats per slot: centre xyz, radius, half length; stage_job_tables)
+// frames: the bodies' frames at t = dt the keys kernel left behind ([body][env][12]: rotation rows, translation) - an end-of-step
+// job reads its body's frame instead of the 28 state words, seven sines / cosines and the chain (measured: the setups took 44 % of
+// the jobs kernel); the jobs of intermediate samples and of the self-collision pairs compute theirs
+template <bool SELF>
+__device__ inline void job_setup(const DScene &S, const BodyPool &BP, const float *pv, const float *pd, const float *cyl, const LaneInput &in,
+                                 const float *frames, const Job &jb, float cutoff, float stop_below, JobLane &J) {
+    const int N = S.checks_per_step, upd = S.updates_per_step / N;
+    const float t = jb.k >= N ? S.dt : S.dt * (float)jb.k / (float)N;
+    if (SELF && jb.kind == kJobSelf) {
+        float qs[SMR_NJ];
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt);
+        self_job_setup(S, BP, cyl, qs, jb.piece, cutoff, stop_below, J);
         return;
     }
-    const unsigned long long ps0 = SMR_DEV_CLOCK();
-    J.T = lane_frame_any<false>(S, jb.body, in, t);
-    const unsigned long long ps1 = SMR_DEV_CLOCK();
+    if (jb.kind == kJobItem) J.T = lane_frame_any<false>(S, jb.body, in, t);
+    else {
+        const SMR_GLOBAL V4 *f = (const SMR_GLOBAL V4 *)frames + 3 * ((size_t)jb.body * S.B + jb.env);
+        const V4 f0 = f[0], f1 = f[1], f2 = f[2];
+        J.T.r[0] = f0[0]; J.T.r[1] = f0[1]; J.T.r[2] = f0[2]; J.T.r[3] = f0[3]; J.T.r[4] = f1[0]; J.T.r[5] = f1[1]; J.T.r[6] = f1[2]; J.T.r[7] = f1[3];
+        J.T.r[8] = f2[0]; J.T.t = F3{f2[1], f2[2], f2[3]};
+    }
     const DPiece LP = BP.piece(jb.body);
     J.hull = BP.hull(jb.body);
-    const unsigned long long ps2 = SMR_DEV_CLOCK();
-    SMR_DEV_COUNT(8, ps1 - ps0); SMR_DEV_COUNT(9, ps2 - ps1); (void)ps0; (void)ps1;
     const float *d = pd + kPlanetDescDwords * jb.piece;
     J.av = pv + 4 * __float_as_int(d[0]);
     J.ac = __float_as_int(d[1]);
@@ -2125,7 +2120,6 @@ __device__ inline void job_setup(const DScene &S, const BodyPool &BP, const floa
         J.XA = inv_compose(J.T, quat_pose((const SMR_GLOBAL float *)(p ? S.planet[1].orbit_pose : S.planet[0].orbit_pose) + 8 * (size_t)(p ? i1 : i0)));
         J.g.start(apply(J.XA, F3{d[4], d[5], d[6]}) - lcl, cutoff + J.margins, stop_below + J.margins);
     }
-    SMR_DEV_COUNT(10, SMR_DEV_CLOCK() - ps2); (void)ps2;
 }
 
 // one iteration; true when the run is settled, dist = distance with the margins subtracted

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     int code;
     safe_acc_range_joint<64>(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code, live);
     if (!live) return;
-    if (j == 0 && S.check_braking) { st.braked[e] = 0; if (e == 0) *st.brake_job_count = 0; }   // set by brake_plan / brake_walk; the scan's job list
+    if (j == 0 && S.check_braking) st.braked[e] = 0;   // set by brake_plan_kernel / brake_check_kernel
     if (j == 0 && S.jobs_on) {                         // the accumulators and lists of this step's jobs (self_bounds / keys / enumerate / jobs kernels)
         if (S.planets_jobs) {
             st.env_best[e] = 0xFFFFFFFFu;
@@ -331,6 +331,11 @@ __global__ __launch_bounds__(256) void keys_kernel(const DScene *__restrict__ Sp
         // distance cannot exceed it
 #pragma unroll
         for (int w = 0; w < 7; ++w) st.keyw[((size_t)w * NB + l) * B + e] = lds_keys[w * kBlock + threadIdx.x];
+        {   // the body's frame for the jobs of this (env, body): 48 contiguous bytes per lane
+            SMR_GLOBAL V4 *f = (SMR_GLOBAL V4 *)st.frames + 3 * ((size_t)l * B + e);
+            const Xf &T = r.frame;
+            f[0] = V4{T.r[0], T.r[1], T.r[2], T.r[3]}; f[1] = V4{T.r[4], T.r[5], T.r[6], T.r[7]}; f[2] = V4{T.r[8], T.t.x, T.t.y, T.t.z};
+        }
         if (r.best != 0xFFFFFFFFu) {
             st.env_best[e] = 1u;                             // some body of the env has a candidate
             if (r.ub <= S.moving_max) atomicMin(&st.env_min[e], dist_bits(r.ub));
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
 // for more than one setup and the kernel ends within one run's length of the moment the stream runs dry.  The order in which the
 // jobs are worked does not matter: their results are minima and flags (job_result).
 #ifndef SMR_JOB_REFILL
-#define SMR_JOB_REFILL 24
+#define SMR_JOB_REFILL 64
 #endif
 template <bool SELF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st) {
@@ -549,6 +554,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     const int lane = (int)__lane_id();
     const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
     bool active = false, mov = false, con = false, dry = false;
+    // when there are fewer jobs than lanes (small batches) the wavefronts share them out thinly: every SIMD gets a few runs instead of a
+    // few CUs getting them all, and a wavefront's chain is the longest of eight runs, not of sixty-four
+    const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
+    const int quota = min(64, max(8, (n_jobs + n_waves - 1) / n_waves));
     Job jb = {0, 0, 0, 0, 0};
     JobLane J;
     J.g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);               // defined state for the lanes that never get a job
@@ -557,17 +566,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
-        if (!dry && (n_idle >= SMR_JOB_REFILL || n_idle == 64)) {
+        if (!dry && (n_idle == 64 || (quota == 64 && n_idle >= SMR_JOB_REFILL))) {
 #ifdef SMR_PROFILE_ROWS
             const unsigned long long t0 = SMR_DEV_CLOCK();
             ++prof_refills;
 #endif
+            const int take = min(n_idle, quota);
             int base = 0;
-            if (lane == 0) base = atomicAdd(st.job_next, n_idle);
+            if (lane == 0) base = atomicAdd(st.job_next, take);
             base = __builtin_amdgcn_readfirstlane(base);
-            dry = base + n_idle >= n_jobs;                 // the stream is exhausted (for every wavefront that asks from now on)
-            const int j = base + __popcll(idle & ((1ull << lane) - 1ull));
-            if (!active && j < n_jobs) {
+            dry = base + take >= n_jobs;                   // the stream is exhausted (for every wavefront that asks from now on)
+            const int rank = __popcll(idle & ((1ull << lane) - 1ull)), j = base + rank;
+            if (!active && rank < take && j < n_jobs) {
                 jb = job_unpack(st.jobs[j]);
                 const LaneInput in = load_lane_input(S, st, jb.env);
                 job_flags(S, in, jb.body, mov, con);
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
                 float cutoff, stop;
                 const unsigned *running = (SELF && jb.kind == kJobSelf) ? st.env_dself : st.env_min;      // the env's minimum so far prunes the run
                 job_limits(S, jb, mov, con, __uint_as_float(__hip_atomic_load(&running[jb.env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), cutoff, stop);
-                job_setup<SELF>(S, JT.BP, JT.pv, JT.pd, JT.cyl, in, jb, cutoff, stop, J);
+                job_setup<SELF>(S, JT.BP, JT.pv, JT.pd, JT.cyl, in, st.frames, jb, cutoff, stop, J);
                 active = true;
             }
 #ifdef SMR_PROFILE_ROWS
@@ -1109,155 +1119,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
             p[j] = p1; v[j] = v1; ap[j] = an[j];
             if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
         }
-    }
-}
-
-// ---- the same check in two passes (the default; SMR_BRAKE_ROWS=1: brake_check_kernel above, for A/B runs) ----
-// brake_scan: the grid of brake_check, but a lane only walks its row (env x body against the static pieces, env x self-collision
-// pair) with LOWER BOUNDS - bound table / spheres / capsules, no hull is touched - and the same conservative advancement between
-// evaluations.  The first sample whose bound does not clear the safety distance is handed over as a job (env, row, segment, sample);
-// a row whose whole braking trajectory is cleared by bounds (most rows of most envs) is done.  brake_walk: one lane per job, dense
-// wavefronts - the walk of brake_check from the job's sample on with the real queries (hulls of all bodies in an LDS pool, the row
-// differs between the lanes).  The decision is the one of brake_check: a bound never exceeds the distance, so no sample that
-// brake_check would have found closer than the safety distance is skipped.
-__device__ __forceinline__ unsigned long long brake_job_word(int env, int row, int m, int sidx) {
-    return (unsigned long long)(unsigned)env | ((unsigned long long)row << 32) | ((unsigned long long)m << 40) | ((unsigned long long)sidx << 48);
-}
-
-template <bool SELF>
-__global__ __launch_bounds__(256) void brake_scan_kernel(const DScene *__restrict__ Sp, DState st) {
-    const DScene &S = *Sp;
-    const int n_pair_rows = SELF ? S.n_self_pairs : 0;
-    const int row = (int)blockIdx.y;
-    const bool pair_row = SELF && row < n_pair_rows;
-    const int pair = pair_row ? row : 0;
-    const int body = pair_row ? S.self_pair[pair][0] : row - n_pair_rows;
-    const int partner = pair_row ? S.self_pair[pair][1] : -1;
-    if (!pair_row && !((S.static_mask >> body) & 1u)) return;
-    const int B = S.B;
-    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = e0 < B;
-    const int e = valid ? e0 : B - 1;
-    const int steps = valid ? st.brake_steps[e] : -1;      // < 0: braking timeout, latched by brake_plan_kernel already
-    float p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ], q_ref[SMR_NJ], lever[SMR_NJ];
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) {
-        p[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; ap[j] = st.a[j * B + e]; an[j] = st.a1[j * B + e]; q_ref[j] = p[j];
-        lever[j] = (partner >= 0 && j < partner) ? 0.f : S.sweep_R[body][j];
-    }
-    const float thr = S.brake_safety + kBoundSlack;
-    float margin = -1.f;
-    int found = -1;                                        // segment << 8 | sample of the first evaluation the bounds cannot clear
-    int max_steps = steps;                                 // of the wavefront: its lanes walk in step
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) max_steps = max(max_steps, __shfl_xor(max_steps, d));
-    for (int m = 0; m <= max_steps; ++m) {
-        const bool live = found < 0 && m <= steps;
-        for (int sidx = 1; sidx <= S.brake_checks; ++sidx) {
-            const float t = sidx == S.brake_checks ? S.dt : S.dt * (float)sidx / (float)S.brake_checks;
-            float qs[SMR_NJ], moved = 0.f;
-#pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) { qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt); moved += fabsf(qs[j] - q_ref[j]) * lever[j]; }
-            const bool eval = live && found < 0 && !(moved * 1.0001f + 1e-6f < margin);
-            if (!__any(eval)) continue;
-            const float lb = pair_row ? self_pair_lower_bound(S, pair, qs, 3.0e38f) : static_lower_bound(S, body, qs);
-            if (eval) {
-                if (lb <= thr) found = (m << 8) | sidx;
-                else {
-                    margin = lb - thr - 1e-5f;
-#pragma unroll
-                    for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = qs[j];
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) {
-            const float p1 = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt), v1 = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
-            p[j] = p1; v[j] = v1; ap[j] = an[j];
-            if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
-        }
-    }
-    // the jobs of the wavefront: one atomic
-    const unsigned long long has = __ballot(found >= 0);
-    if (has) {
-        const int lane = (int)__lane_id();
-        int base = 0;
-        if (lane == 0) base = atomicAdd(st.brake_job_count, __popcll(has));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (found >= 0) st.brake_jobs[base + __popcll(has & ((1ull << lane) - 1ull))] = brake_job_word(e, row, found >> 8, found & 255);
-    }
-}
-
-template <bool SELF>
-__global__ SMR_SIDE_KERNEL void brake_walk_kernel(const DScene *__restrict__ Sp, DState st) {
-    const DScene &S = *Sp;
-    __shared__ uint32_t pool[kBodyPoolDwords];
-    const int n_jobs = *st.brake_job_count;
-    if ((int)blockIdx.x * (int)blockDim.x >= n_jobs) return;           // (block uniform: before the pool is staged)
-    {
-        const SMR_GLOBAL uint32_t *g = (const SMR_GLOBAL uint32_t *)S.body_pool;
-        for (int i = threadIdx.x; i < S.body_pool_dwords; i += blockDim.x) pool[i] = g[i];
-        __syncthreads();
-    }
-    const BodyPool BP{pool};
-    const int B = S.B, n_pair_rows = SELF ? S.n_self_pairs : 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_jobs; i += gridDim.x * blockDim.x) {
-        const unsigned long long w = st.brake_jobs[i];
-        const int e = (int)(unsigned)(w & 0xFFFFFFFFull), row = (int)((w >> 32) & 255ull), m0 = (int)((w >> 40) & 255ull), s0 = (int)((w >> 48) & 255ull);
-        const bool pair_row = SELF && row < n_pair_rows;
-        const int pair = pair_row ? row : 0;
-        const int body = pair_row ? S.self_pair[pair][0] : row - n_pair_rows;
-        const int partner = pair_row ? S.self_pair[pair][1] : -1;
-        const int steps = st.brake_steps[e];
-        const DPiece LP = BP.piece(body);
-        const LocalHull hull = BP.hull(body);
-        float p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ], q_ref[SMR_NJ], lever[SMR_NJ];
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) {
-            p[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; ap[j] = st.a[j * B + e]; an[j] = st.a1[j * B + e];
-            lever[j] = (partner >= 0 && j < partner) ? 0.f : S.sweep_R[body][j];
-        }
-        for (int m = 0; m < m0; ++m)                          // the state at the start of the job's segment
-#pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) {
-                const float p1 = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt), v1 = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
-                p[j] = p1; v[j] = v1; ap[j] = an[j];
-                an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
-            }
-#pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = p[j];
-        const float thr = S.brake_safety;
-        float margin = -1.f;
-        F3 warm = {0.f, 0.f, 0.f};
-        bool hit = false;
-        for (int m = m0; m <= steps && !hit; ++m) {
-            for (int sidx = (m == m0 ? s0 : 1); sidx <= S.brake_checks && !hit; ++sidx) {
-                const float t = sidx == S.brake_checks ? S.dt : S.dt * (float)sidx / (float)S.brake_checks;
-                float qs[SMR_NJ], moved = 0.f;
-#pragma unroll
-                for (int j = 0; j < SMR_NJ; ++j) { qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt); moved += fabsf(qs[j] - q_ref[j]) * lever[j]; }
-                if (moved * 1.0001f + 1e-6f < margin) continue;
-                const Xf T = body_frame(S, qs, body);
-                float d;
-                if (pair_row) d = self_pair_distance<true>(S, pair, qs, LP, hull, T, S.static_max, thr, &BP, nullptr, &warm);
-                else {
-                    d = 3.0e38f;
-                    for (int sp = 0; sp < S.n_static; ++sp)
-                        d = fminf(d, piece_distance<true>(S, S.static_piece[sp], T, LP, hull, T, S.static_max, thr, S.n_static == 1 ? &warm : nullptr));
-                }
-                if (d < thr) { hit = true; break; }
-                margin = d - thr - 1e-5f;
-#pragma unroll
-                for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = qs[j];
-            }
-#pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) {
-                const float p1 = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt), v1 = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
-                p[j] = p1; v[j] = v1; ap[j] = an[j];
-                if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
-            }
-        }
-        if (hit) st.braked[e] = 1;                            // ctlp.py:3307-3312,3364-3368
     }
 }
 
@@ -1997,6 +1858,7 @@ struct smr_env {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // the refills of consecutive steps overlap (each has two step periods): a second set of streams / events, used by odd steps
     hipStream_t side_b = nullptr, side2_b = nullptr;
+    int self_job_blocks = 0;          // grid of a jobs kernel launch that only has self-pair jobs (0.3 per env)
     hipEvent_t ev_commit_b = nullptr, ev_refill_b = nullptr, ev_fork_b = nullptr, ev_join_b = nullptr;
     int rot = 0;                      // which of the three list slots this step uses (a list is re-used two steps after its refill was awaited)
     int *refill_lists = nullptr;      // [3][B]
@@ -2016,7 +1878,6 @@ struct smr_env {
     int *risky_buf = nullptr;
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
     int job_blocks = 0;               // their persistent grid: two 512-lane blocks per CU
-    int walk_blocks = 0;              // brake_walk's grid: two 256-lane blocks per CU
     bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
     DState st;
@@ -2325,13 +2186,12 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) || (rc = dev_alloc(env, &st.brake_job_count, 1)) ||
-        (rc = dev_alloc(env, &st.brake_jobs, scene->check_braking_trajectory_collisions ? (size_t)(scene->n_bodies + scene->n_self_pairs) * B : 1)) ||
+        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) || 
         (rc = dev_alloc(env, &st.brake_acc, scene->check_braking_trajectory_collisions ? (size_t)(scene->brake_timeout_steps + 1) * SMR_NJ * B : 1)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)) || (rc = dev_alloc(env, &env->spawn_tag_lists, 3 * B)))
         return fail(rc);
-    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12) || hipMemset(st.lb_moving, 0xFF, (size_t)scene->n_bodies * B * 4) || hipMemset(st.braked, 0, B * 4) || hipMemset(st.brake_job_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (hipMemset(st.ball, 0, 10 * B * 4) || hipMemset(st.ball_i, 0, 5 * B * 4) || hipMemset(env->spawn_counts, 0, 12) || hipMemset(st.lb_moving, 0xFF, (size_t)scene->n_bodies * B * 4) || hipMemset(st.braked, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts; st.spawn_tags = env->spawn_tag_lists;
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
@@ -2347,7 +2207,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (cap > 0x7FFFFFFFull) { env->err = "num_envs too large for the job list"; return fail(SMR_E_INVALID); }
         st.job_cap = (int)cap;
         if ((rc = dev_alloc(env, &st.keyw, pj ? 7 * NB * B : 1)) || (rc = dev_alloc(env, &st.env_best, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_min, pj ? B : 1)) ||
-            (rc = dev_alloc(env, &st.env_dstatic, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_dself, B)) || (rc = dev_alloc(env, &st.items, (pj && N > 1) ? B * NB * (N - 1) : 1)) ||
+            (rc = dev_alloc(env, &st.env_dstatic, pj ? B : 1)) || (rc = dev_alloc(env, &st.frames, pj ? 12 * NB * B : 4)) || (rc = dev_alloc(env, &st.env_dself, B)) || (rc = dev_alloc(env, &st.items, (pj && N > 1) ? B * NB * (N - 1) : 1)) ||
             (rc = dev_alloc(env, &st.jobs, std::max<size_t>(cap, 1))) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) || (rc = dev_alloc(env, &st.job_next, 1)) ||
             (rc = dev_alloc(env, &st.overflow_env, B))) return fail(rc);
         if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4) || hipMemset(st.job_next, 0, 4) || hipMemset(st.overflow_env, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
@@ -2355,6 +2215,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
         env->job_blocks = 2 * std::max(prop.multiProcessorCount, 1);
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
+        env->self_job_blocks = std::max(8, std::min(env->job_blocks, (int)((B + 1023) / 1024)));      // ~40 jobs per wavefront
     }
     if ((rc = dev_alloc(env, &st.tp, 5 * B)) || (rc = dev_alloc(env, &st.tp_count, B)) || (rc = dev_alloc(env, &st.tp_list, B)) ||
         (rc = dev_alloc(env, &st.tp_list_count, 1)) || (rc = dev_alloc(env, &st.error_flags, 1))) return fail(rc);
@@ -2395,11 +2256,6 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if ((env->tp_refill_slots || env->stage_balls) &&
             (hipStreamCreateWithFlags(&env->side2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_fork, hipEventDisableTiming) != hipSuccess ||
              hipEventCreateWithFlags(&env->ev_join, hipEventDisableTiming) != hipSuccess)) { env->err = "could not create the second side stream"; return fail(SMR_E_HIP); }
-    }
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
-        env->walk_blocks = 2 * std::max(prop.multiProcessorCount, 1);
     }
     if (hipDeviceSynchronize() != hipSuccess) { env->err = "hipDeviceSynchronize failed"; return fail(SMR_E_HIP); }
     *out = env;
@@ -2703,21 +2559,8 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         LaunchTimer t(env, SMR_K_BRAKE);
         hipLaunchKernelGGL(brake_plan_kernel, dim3(((size_t)B * 8 + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st);
         const dim3 grid((B + 255) / 256, env->hscene.n_bodies + env->hscene.n_self_pairs);
-        static const bool rows = [] { const char *v = getenv("SMR_BRAKE_ROWS"); return !v || atoi(v); }();      // A/B switch (0: the two-pass form, measured slower so far)
-        const bool self = env->hscene.n_self_pairs > 0;
-        if (rows) {
-            if (self) hipLaunchKernelGGL((brake_check_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-            else hipLaunchKernelGGL((brake_check_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-        } else {
-            const dim3 wgrid(std::max(env->walk_blocks, 1));
-            if (self) {
-                hipLaunchKernelGGL((brake_scan_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-                hipLaunchKernelGGL((brake_walk_kernel<true>), wgrid, dim3(256), 0, env->stream, env->dscene, env->st);
-            } else {
-                hipLaunchKernelGGL((brake_scan_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-                hipLaunchKernelGGL((brake_walk_kernel<false>), wgrid, dim3(256), 0, env->stream, env->dscene, env->st);
-            }
-        }
+        if (env->hscene.n_self_pairs > 0) hipLaunchKernelGGL((brake_check_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((brake_check_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
         hipLaunchKernelGGL(brake_apply_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st);
         SMR_HIP(hipGetLastError());
     }
@@ -2729,7 +2572,13 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         const dim3 jgrid(env->job_blocks);
         // the self-collision pairs: bounds per env, the survivors as jobs (worked by the jobs kernel behind the pair jobs of a planet
         // scene, by a launch of its own otherwise)
-        if (pairs) hipLaunchKernelGGL(self_bounds_kernel, dim3((B + 255) / 256, env->hscene.n_self_pairs), dim3(256), 0, env->stream, env->dscene, env->st);
+        const bool self_jobs_alone = pairs && !env->hscene.planets_jobs;      // no pair jobs to work them behind
+        // (on a stream of their own beside the other distance kernels they finished sooner, but took from the staged refills what they
+        // gained: reaching task 94 -> 86 M env-steps/s, measured)
+        if (pairs) {
+            hipLaunchKernelGGL(self_bounds_kernel, dim3((B + 255) / 256, env->hscene.n_self_pairs), dim3(256), 0, env->stream, env->dscene, env->st);
+            if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+        }
         if (env->hscene.planets_jobs) {
             const int env_blocks = (B + 255) / 256;
             const dim3 egrid(env_blocks + (env->N > 1 ? 4 * env->job_blocks : 0));      // behind the env blocks: a fixed grid striding over the items
@@ -2745,8 +2594,10 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         if (env->hscene.jobs_on) {
-            if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
-            else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+            if (env->hscene.planets_jobs) {
+                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+            }
             hipLaunchKernelGGL(overflow_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st);
         }
     }

@@ -44,8 +44,9 @@ def main():
     total = cyc[:32].sum()
     print("config %s: %.1f M wave-cycles per step over %d rows" % (name, total / 1e6, int((waves > 0).sum())))
     phases = {32: "reset: start position", 33: "reset: velocity / acceleration", 34: "reset: planet phase", 36: "staged spawn: launch",
-              38: "target point", 40: "job setup: frame of the body", 41: "job setup: piece record + hull pointers", 42: "job setup: planet pose, run start", 52: "first kernel: staging", 53: "first kernel: setup of the first run", 54: "first kernel: trip loop",
+              38: "target point", 40: "job setup: frame of the body", 41: "job setup: piece record + hull pointers", 42: "job setup: planet pose, run start", 
               55: "first kernel: trips per chunk (count, not cycles)", 56: "first kernel: enumeration / job append", 57: "first kernel: item chunk",
+              
               57: "jobs kernel: refills per wavefront (count)",
               58: "jobs kernel: staging", 59: "jobs kernel: job setup (per wavefront)", 60: "jobs kernel: trips (per wavefront)", 61: "jobs kernel: trips per wavefront (count)",
               62: "jobs kernel: MAX iterations of one job", 63: "jobs kernel: MAX cycles of a wavefront"}
