@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 8
+#define SMR_ABI_VERSION 9
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
@@ -61,7 +61,9 @@ extern "C" {
                                          (ctlp.py:2839-2861); 0 none */
 #define SMR_INFO_RISKY 11             /* 1: the risk network rated the action risky and the backup policy's action was executed
                                          (risky_action_rate, actions.py:303-340); 0 without risk networks */
-#define SMR_INFO_N 12
+#define SMR_INFO_END_MIN_DISTANCE_PUNISHMENT 12   /* end_min_distance_punishment in [0, 1], rewards.py:322-332; 0 without punish_end_min_distance */
+#define SMR_INFO_BRAKING_TRAJECTORY_PUNISHMENT 13 /* braking_trajectory_min_distance_punishment in [0, 1], ctlp.py:2393-2415 */
+#define SMR_INFO_N 14
 
 /* kernels timed by smr_get_profile */
 #define SMR_K_PLAN 0      /* A2/A4: safe acceleration range + action mapping            */
@@ -186,6 +188,10 @@ int smr_test_ball_distances(smr_env_t *env, const float *q_host, const float *ba
 /* self-collision pairs: the table lower bounds the step's pruning uses (csrc/smr_device.h "Self pairs: bound tables") for n joint
  * vectors; out [n][SMR_MAX_SELF_PAIRS], -3e38 for a pair without a table.  Each must not exceed the pair's distance (ctlp.py:3345-3372). */
 int smr_test_self_bounds(smr_env_t *env, const float *q_host, int32_t n, float *out);
+/* braking layer: what the LAST smr_step planned - acc_out [brake_timeout_steps + 1][7][B] the braking accelerations of the segments
+ * behind the planned step ([0]: the one that replaces a refused action, btg.py:44-93), steps_out [B] braking segments until
+ * standstill (-1: braking timeout), braked_out [B] the decision (ctlp.py:3026-3053).  Any pointer may be NULL.  Synchronises. */
+int smr_test_brake_plan(smr_env_t *env, float *acc_out, int32_t *steps_out, int32_t *braked_out);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SMR_SCENE_VERSION 7
+#define SMR_SCENE_VERSION 8
 #define SMR_NJ 7          /* manipulator joints (iiwa_joint_1..7, robot.urdf)            */
 #define SMR_NLINK 8       /* chain links iiwa_link_0..7; link k moves with joints 1..k      */
 #define SMR_MAX_BODIES 10 /* collision bodies = the 8 chain links + convex pieces rigidly mounted on one of them
@@ -193,6 +193,21 @@ typedef struct smr_scene {
     double brake_jerk_max[SMR_NJ];      /* actions.py:78-82 */
     double brake_stop_velocity;         /* 0.01: below it (and brake_stop_acceleration) a joint counts as stopped, btg.py:45,75-77 */
     double brake_stop_acceleration;
+    /* the reward terms of TargetPointReachingReward that read the braking layer's results (rewards.py:229-262,315-334,357-375);
+     * each punishment in [0, 1] is also an info column */
+    int32_t punish_adaptation;          /* - adaptation_max_punishment where the braking trajectory was executed instead of the action
+                                           (adaptation_punishment, ctlp.py:3060,3077-3078; rewards.py:319-320,356) */
+    int32_t punish_end_min_distance;    /* - end_min_distance_max_punishment x quadratic(end_min_distance): the minimum distance (static
+                                           obstacles and self-collision partners, ctlp.py:3282-3374) at the END of the executed step
+                                           (the first entry of the valid braking trajectory's min_distance list, ctlp.py:3099-3102,3194;
+                                           rewards.py:322-332) */
+    int32_t punish_braking_trajectory_min_distance;   /* - braking_trajectory_max_punishment x quadratic(the smallest minimum distance
+                                           over the samples of this step's braking-trajectory check, 1 below the safety distance)
+                                           (get_braking_trajectory_punishment, ctlp.py:2393-2415; rewards.py:361-375) */
+    int32_t _pad5;
+    double adaptation_max_punishment;
+    double end_min_distance_max_punishment, end_min_distance_max_threshold;
+    double braking_trajectory_max_punishment, braking_trajectory_min_distance_max_threshold;
 
     /* ---- reset (A17), ctlp.py:1461-1656,1980-2138 ---- */
     double start_box[3][2];             /* ctlp.py:172-183 */

@@ -915,10 +915,39 @@ bool closer_than_safety_distance(const Oracle &O, const double q[SMR_NJ]) {
     return !self_pairs_clear(O, link, thr);
 }
 
+/* get_minimum_distance(check_safety_distance=True), ctlp.py:3282-3374, as the braking-trajectory check calls it: the minimum over the
+ * static obstacles x observed links, then over the self-collision pairs, both capped at the cut-off; the FIRST query below the
+ * safety distance ends it (collision_found) and the minimum so far is what is returned */
+double minimum_distance_checked(const Oracle &O, const double q[SMR_NJ], bool &collision_found) {
+    const smr_scene_t &S = O.S;
+    Xf link[SMR_MAX_BODIES];
+    forward_kinematics(S, q, link);
+    Xf I = identity_xf();
+    double dmin = S.static_max_distance;
+    collision_found = false;
+    for (int s = 0; s < S.n_static; ++s)
+        for (int k = 0; k < S.n_bodies; ++k) {
+            if (!(S.static_link_mask & (1u << k))) continue;
+            const double d = piece_distance(O, S.static_piece[s], I, S.link_piece[k], link[k], S.static_max_distance);
+            if (d > S.static_max_distance) continue;                              /* no closest point returned, ctlp.py:2915-2931 */
+            dmin = std::min(dmin, d);
+            if (d < S.brake_safety_distance) { collision_found = true; return dmin; }
+        }
+    for (int i = 0; i < S.n_self_pairs; ++i) {
+        const double d = self_pair_distance(O, link, i, S.static_max_distance);
+        if (d > S.static_max_distance) continue;
+        dmin = std::min(dmin, d);
+        if (d < S.brake_safety_distance) { collision_found = true; return dmin; }
+    }
+    return dmin;
+}
+
 /* check_braking_trajectory_method, ctlp.py:3026-3053: true = executing target acceleration a1 and braking afterwards is NOT
- * collision free (or does not stop within the braking timeout): the braking trajectory has to be executed instead */
+ * collision free (or does not stop within the braking timeout): the braking trajectory has to be executed instead.
+ * bt_min (optional): _braking_trajectory_minimum_distance, the smallest minimum distance over the samples that were checked
+ * (ctlp.py:3157,3185-3186) */
 bool braking_trajectory_unsafe(const Oracle &O, const double q0[SMR_NJ], const double v0[SMR_NJ], const double a0[SMR_NJ],
-                               const double a1[SMR_NJ]) {
+                               const double a1[SMR_NJ], double *bt_min = nullptr) {
     const smr_scene_t &S = O.S;
     double p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ];
     std::memcpy(p, q0, sizeof p); std::memcpy(v, v0, sizeof v); std::memcpy(ap, a0, sizeof ap); std::memcpy(an, a1, sizeof an);
@@ -927,7 +956,11 @@ bool braking_trajectory_unsafe(const Oracle &O, const double q0[SMR_NJ], const d
         for (int sidx = 1; sidx <= Nb; ++sidx) {                                  /* time_since_start = linspace(dt / Nb, dt, Nb), ctlp.py:3167-3169 */
             double t = sidx == Nb ? S.dt : S.dt * sidx / Nb, qs[SMR_NJ];
             for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt);
-            if (closer_than_safety_distance(O, qs)) return true;
+            if (bt_min) {
+                bool hit;
+                *bt_min = std::min(*bt_min, minimum_distance_checked(O, qs, hit));
+                if (hit) return true;
+            } else if (closer_than_safety_distance(O, qs)) return true;
         }
         if (m >= S.brake_timeout_steps) return true;                              /* braking_timeout, ctlp.py:3468-3473 */
         double p1[SMR_NJ], v1[SMR_NJ], b[SMR_NJ];
@@ -1051,7 +1084,7 @@ void reset_env(Oracle &O, int e) {
 
 /* info columns written by step (mirrors the product's SMR_INFO_* layout) */
 enum { INFO_D_STATIC = 0, INFO_D_SELF, INFO_D_MOVING, INFO_ACTION_PUNISHMENT, INFO_R_SELF, INFO_R_STATIC,
-       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_BRAKED, INFO_TARGET_REACHED, INFO_BALL_EVENT, INFO_RISKY, INFO_N };
+       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_BRAKED, INFO_TARGET_REACHED, INFO_BALL_EVENT, INFO_RISKY, INFO_END_MIN_PUNISHMENT, INFO_BT_PUNISHMENT, INFO_N };
 
 /* A1/A2/A3/A11/A12/A13/A16: SafeMotionsBase.step + process_step_outcome for one env. */
 void step_env(Oracle &O, int e, const double *action, float *obs, double *reward, uint8_t *done,
@@ -1071,7 +1104,9 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
     /* adapt_action, ctlp.py:3055-3153 / actions.py:340-361: the braking acceleration replaces an action whose step + braking
      * trajectory is not collision free (the stored valid braking trajectory continues from exactly this state) */
     bool braked = false;
-    if (S.check_braking_trajectory_collisions && braking_trajectory_unsafe(O, st.q, st.v, st.a, a1)) {
+    double bt_min = 1e300;                                                   /* np.inf, ctlp.py:3157 */
+    if (S.check_braking_trajectory_collisions &&
+        braking_trajectory_unsafe(O, st.q, st.v, st.a, a1, S.punish_braking_trajectory_min_distance ? &bt_min : nullptr)) {
         braking_acceleration(S, st.q, st.v, st.a, a1);
         braked = true;
     }
@@ -1127,6 +1162,10 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
     /* A12: _compute_collision_avoidance_reward, rewards.py:95-162 (link[] holds FK of the end setpoint) */
     double d_static, d_self;
     min_distance_static_self(O, link, d_static, d_self);
+    /* _end_min_distance: the minimum distance at the end of the executed step - the first entry of the valid braking trajectory's
+     * min_distance list when the action was accepted (ctlp.py:3099-3102,3194), the next entry of the stored list while a braking
+     * trajectory is executed (ctlp.py:3000-3011, the same state), get_minimum_distance(_start_position) otherwise (rewards.py:322-327) */
+    const double end_min_distance = std::min(d_static, d_self);
     bool col_static = false, col_self = false, col_moving = false;
     if (d_static < S.collision_distance) { d_static = 0; col_static = true; }
     if (d_self < S.collision_distance) { d_self = 0; col_self = true; }
@@ -1201,9 +1240,22 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         *reward = (1 - action_punishment) * S.action_max_punishment + r_self * S.self_max_reward +
                   r_static * S.static_max_reward + r_moving * S.moving_max_reward +
                   low_acc_reward * S.low_acc_max_reward + low_vel_reward * S.low_vel_max_reward + bonus + punishment;
-    else                                                                     /* TargetPointReachingReward, rewards.py:303-396 */
-        *reward = target_reward * S.target_factor - (S.punish_action ? action_punishment : 0.0) * S.action_max_punishment +
-                  r_self * S.self_max_reward + r_static * S.static_max_reward + r_moving * S.moving_max_reward;
+    double end_min_punishment = 0, bt_punishment = 0;                        /* rewards.py:18-21,322-332; ctlp.py:2393-2415 */
+    if (S.punish_end_min_distance) {
+        const double x = (S.end_min_distance_max_threshold - end_min_distance) / (S.end_min_distance_max_threshold - S.brake_safety_distance);
+        end_min_punishment = std::pow(std::max(std::min(x, 1.0), 0.0), 2);
+    }
+    if (S.punish_braking_trajectory_min_distance && S.check_braking_trajectory_collisions) {
+        const double thr = S.braking_trajectory_min_distance_max_threshold;
+        if (bt_min < S.brake_safety_distance) bt_punishment = 1.0;
+        else if (bt_min < thr) bt_punishment = std::pow(std::max(std::min((thr - bt_min) / (thr - S.brake_safety_distance), 1.0), 0.0), 2);
+    }
+    if (!S.collision_avoidance_mode)                                         /* TargetPointReachingReward, rewards.py:303-396 */
+        *reward = target_reward * S.target_factor - (S.punish_action ? action_punishment : 0.0) * S.action_max_punishment -
+                  (S.punish_adaptation && braked ? 1.0 : 0.0) * S.adaptation_max_punishment -
+                  end_min_punishment * S.end_min_distance_max_punishment +
+                  r_self * S.self_max_reward + r_static * S.static_max_reward + r_moving * S.moving_max_reward -
+                  bt_punishment * S.braking_trajectory_max_punishment;
 
     /* A16: _check_termination, base.py:1775-1799 */
     int r = SMR_TERMINATION_UNSET;
@@ -1218,7 +1270,7 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         info[INFO_D_STATIC] = d_static; info[INFO_D_SELF] = d_self; info[INFO_D_MOVING] = d_moving;
         info[INFO_ACTION_PUNISHMENT] = action_punishment; info[INFO_R_SELF] = r_self;
         info[INFO_R_STATIC] = r_static; info[INFO_R_MOVING] = r_moving; info[INFO_EPISODE_LENGTH] = st.step_count;
-        info[INFO_BRAKED] = braked ? 1.0 : 0.0; info[INFO_TARGET_REACHED] = tp_reached ? 1.0 : 0.0; info[INFO_BALL_EVENT] = ball_event; info[INFO_RISKY] = 0.0;     /* the risk check sits above step() (tests/test_gpu_policy.py) */
+        info[INFO_BRAKED] = braked ? 1.0 : 0.0; info[INFO_TARGET_REACHED] = tp_reached ? 1.0 : 0.0; info[INFO_BALL_EVENT] = ball_event; info[INFO_RISKY] = 0.0; info[INFO_END_MIN_PUNISHMENT] = end_min_punishment; info[INFO_BT_PUNISHMENT] = bt_punishment;     /* the risk check sits above step() (tests/test_gpu_policy.py) */
     }
     if (d && S.auto_reset) reset_env(O, e);
     else {

@@ -155,6 +155,9 @@ struct DScene {
     // braking-trajectory safety layer (btg.py, ctlp.py:3026-3207)
     int check_braking, brake_checks, brake_timeout_steps;
     float brake_safety, brake_acc_max[SMR_NJ], brake_jerk_max[SMR_NJ], brake_stop_v, brake_stop_a;
+    // the reward terms that read the braking layer's results (rewards.py:315-334,357-375; smr_scene.h)
+    int punish_adaptation, punish_end_min, punish_bt_min;
+    float adaptation_max_pun, end_min_max_pun, end_min_thr, bt_max_pun, bt_thr;
     float start_box[3][2];
     float start_min_static, start_min_self;
     int kin_mode;
@@ -179,6 +182,8 @@ struct DState {
     float *brake_acc;          // [brake_timeout_steps + 1][7][B] end acceleration of braking segment m >= 1 behind the planned step
                                // ([0]: the braking acceleration at the current state, what adapt_action puts in place of the action)
     int *brake_steps;          // [B] braking segments until the robot stands (-1: not within the braking timeout)
+    unsigned *bt_min;          // [B] float bits of the smallest distance brake_check_kernel's rows found along this step's braking trajectory
+                               //     (_braking_trajectory_minimum_distance, ctlp.py:3157,3185-3186; atomicMin, plan_kernel starts it at +inf)
     float *lb_moving;          // [n_bodies][B] lower bound of the body's distance to every moving piece at the end of the last step
                                // (< 0: none - new episode, injected state); the next step's lanes rule out their first samples with it
     int *done_list;            // [B]

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     int code;
     safe_acc_range_joint<64>(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code, live);
     if (!live) return;
-    if (j == 0 && S.check_braking) st.braked[e] = 0;   // set by brake_plan_kernel / brake_check_kernel
+    if (j == 0 && S.check_braking) { st.braked[e] = 0; st.bt_min[e] = 0x7F800000u; }   // set by brake_plan_kernel / brake_check_kernel
     if (j == 0 && S.jobs_on) {                         // the accumulators and lists of this step's jobs (self_bounds / keys / enumerate / jobs kernels)
         if (S.planets_jobs) {
             st.env_best[e] = 0xFFFFFFFFu;
@@ -732,6 +732,9 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     for (int p = 0; p < SMR_MAX_PLANETS; ++p)
         if (p < S.n_planets) idx[p] = (st.planet_idx[p * B + e] + S.updates_per_step) % S.planet[p].n_orbit;   // ctlp.py:4504
 
+    // _end_min_distance: the minimum distance (static obstacles, self-collision partners) at the end of the executed step,
+    // rewards.py:322-332 (actions.py:340-369: the first entry of the valid braking trajectory's list, ctlp.py:3099-3102,3194)
+    const float end_min_distance = fminf(d_static, d_self);
     // A12: rewards.py:95-162
     bool col_static = false, col_self = false, col_moving = false;
     if (d_static < S.collision_dist) { d_static = 0.f; col_static = true; }
@@ -791,12 +794,24 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
             st.tp[3 * B + e] = cur;                                           // the next observation, ctlp.py:2241-2243
         }
     }
+    float end_min_pun = 0.f, bt_pun = 0.f;                                    // rewards.py:18-21,322-332; ctlp.py:2393-2415
+    const int braked = S.check_braking ? st.braked[e] : 0;
+    if (S.punish_end_min) {
+        const float x = (S.end_min_thr - end_min_distance) / (S.end_min_thr - S.brake_safety);
+        end_min_pun = fmaxf(fminf(x, 1.f), 0.f); end_min_pun *= end_min_pun;
+    }
+    if (S.punish_bt_min && S.check_braking) {
+        const float bt = __uint_as_float(st.bt_min[e]);
+        if (braked || bt < S.brake_safety) bt_pun = 1.f;                      // (a hit: below the safety distance; no standstill within the timeout counts as one)
+        else if (bt < S.bt_thr) { const float x = fmaxf(fminf((S.bt_thr - bt) / (S.bt_thr - S.brake_safety), 1.f), 0.f); bt_pun = x * x; }
+    }
     if (S.ca_mode)                                                            // CollisionAvoidanceReward, rewards.py:432-502
         reward[e] = (1.f - action_pun) * S.action_max_pun + r_self * S.self_max_reward + r_static * S.static_max_reward +
                     r_moving * S.moving_max_reward + low_acc * S.low_acc_reward + low_vel * S.low_vel_reward + bonus + pun;
     else                                                                      // TargetPointReachingReward, rewards.py:303-396
-        reward[e] = target_reward * S.target_factor - (S.punish_action ? action_pun : 0.f) * S.action_max_pun +
-                    r_self * S.self_max_reward + r_static * S.static_max_reward + r_moving * S.moving_max_reward;
+        reward[e] = target_reward * S.target_factor - (S.punish_action ? action_pun : 0.f) * S.action_max_pun -
+                    ((S.punish_adaptation && braked) ? S.adaptation_max_pun : 0.f) - end_min_pun * S.end_min_max_pun +
+                    r_self * S.self_max_reward + r_static * S.static_max_reward + r_moving * S.moving_max_reward - bt_pun * S.bt_max_pun;
 
     // A16: base.py:1775-1799
     int rs = SMR_TERMINATION_UNSET;
@@ -814,6 +829,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         row[SMR_INFO_R_MOVING] = r_moving; row[SMR_INFO_EPISODE_LENGTH] = (float)steps;
         row[SMR_INFO_BRAKED] = S.check_braking ? (float)st.braked[e] : 0.f; row[SMR_INFO_TARGET_REACHED] = tp_reached ? 1.f : 0.f;
         row[SMR_INFO_BALL_EVENT] = (float)ball_event; row[SMR_INFO_RISKY] = st.risky ? (float)st.risky[e] : 0.f;
+        row[SMR_INFO_END_MIN_DISTANCE_PUNISHMENT] = end_min_pun; row[SMR_INFO_BRAKING_TRAJECTORY_PUNISHMENT] = bt_pun;
     }
 
 #pragma unroll
@@ -1078,6 +1094,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
 #pragma unroll
     for (int j = 0; j < SMR_NJ; ++j) lever[j] = (partner >= 0 && j < partner) ? 0.f : S.sweep_R[body][j];
     const float thr = S.brake_safety;
+    // with punish_braking_trajectory_min_distance the smallest distance of the walk is asked for below bt_thr as well: a sample is
+    // only skipped when its distance is proven beyond that (get_braking_trajectory_punishment, ctlp.py:2393-2415)
+    const float thr_skip = S.punish_bt_min ? fmaxf(thr, S.bt_thr) : thr;
+    float dmin = 3.0e38f;
     float margin = -1.f;                                 // clearance beyond the safety distance found at q_ref (< 0: nothing evaluated yet)
     // consecutive evaluations look at nearly the same configuration: each GJK run starts in the direction the last one ended with
     // (world frame; the first support points then already span the closest feature)
@@ -1108,8 +1128,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
                 for (int sp = 0; sp < S.n_static; ++sp)
                     d = fminf(d, piece_distance<true>(S, S.static_piece[sp], T, LP, hull, T, S.static_max, thr, S.n_static == 1 ? &warm : nullptr));
             }
-            if (d < thr) { st.braked[e] = 1; return; }                                    // ctlp.py:3307-3312,3364-3368; several lanes of an env may write the same 1
-            margin = d - thr - 1e-5f;
+            dmin = fminf(dmin, d);
+            if (d < thr) {                                                                // ctlp.py:3307-3312,3364-3368; several lanes of an env may write the same 1
+                st.braked[e] = 1;
+                if (S.punish_bt_min) atomicMin(&st.bt_min[e], dist_bits(dmin));
+                return;
+            }
+            margin = d - thr_skip - 1e-5f;
 #pragma unroll
             for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = qs[j];
         }
@@ -1120,6 +1145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
             if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
         }
     }
+    if (S.punish_bt_min && dmin <= S.static_max) atomicMin(&st.bt_min[e], dist_bits(dmin));
 }
 
 // adapt_action (ctlp.py:3055-3153, actions.py:340-361): where the braking trajectory of the planned end acceleration is not collision free
@@ -2092,7 +2118,12 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed,
     d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32); d.env_base = env_index_base;
     // the range of self distances anything reads: the reward's min(1, d / max_reward_distance) and the d < collision_distance flag
     // (rewards.py:119-126); never beyond the cut-off of the queries (ctlp.py:354-366)
-    d.self_cut = std::min(d.static_max, std::max(d.self_max_reward != 0.f ? d.self_max_dist : 0.f, d.collision_dist));
+    d.punish_adaptation = s.punish_adaptation; d.punish_end_min = s.punish_end_min_distance; d.punish_bt_min = s.punish_braking_trajectory_min_distance;
+    d.adaptation_max_pun = (float)s.adaptation_max_punishment; d.end_min_max_pun = (float)s.end_min_distance_max_punishment;
+    d.end_min_thr = (float)s.end_min_distance_max_threshold; d.bt_max_pun = (float)s.braking_trajectory_max_punishment;
+    d.bt_thr = (float)s.braking_trajectory_min_distance_max_threshold;
+    d.self_cut = std::min(d.static_max, std::max(std::max(d.self_max_reward != 0.f ? d.self_max_dist : 0.f, d.collision_dist),
+                                                 d.punish_end_min ? d.end_min_thr : 0.f));      // ... and the end-of-step minimum distance (rewards.py:322-332)
     if ((rc = dev_alloc(env, &env->dscene, 1))) return rc;
     // self-pair bound tables: laid out here, filled by the device GJK itself (the scene goes up without them first)
     const size_t tab_entries = getenv("SMR_NO_SELF_TABLES") ? 0 : self_table_layout(s, G, d);
@@ -2186,7 +2217,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
-        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) || 
+        (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) || (rc = dev_alloc(env, &st.bt_min, B)) || 
         (rc = dev_alloc(env, &st.brake_acc, scene->check_braking_trajectory_collisions ? (size_t)(scene->brake_timeout_steps + 1) * SMR_NJ * B : 1)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
         (rc = dev_alloc(env, &st.ball_i, 5 * B)) || (rc = dev_alloc(env, &env->spawn_lists, 3 * B)) || (rc = dev_alloc(env, &env->spawn_counts, 3)) || (rc = dev_alloc(env, &env->spawn_tag_lists, 3 * B)))
@@ -2861,6 +2892,17 @@ int smr_test_distances(smr_env_t *env, const float *q_host, const int32_t *plane
     SMR_HIP(hipGetLastError());
     SMR_HIP(hipStreamSynchronize(env->stream));
     SMR_HIP(hipMemcpy(out, o, (size_t)n * 16, hipMemcpyDeviceToHost));
+    return SMR_OK;
+}
+
+int smr_test_brake_plan(smr_env_t *env, float *acc_out, int32_t *steps_out, int32_t *braked_out) {
+    if (!env || !env->hscene.check_braking) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    const size_t B = (size_t)env->B, n = (size_t)(env->hscene.brake_timeout_steps + 1) * SMR_NJ * B;
+    if (acc_out) SMR_HIP(hipMemcpy(acc_out, env->st.brake_acc, n * 4, hipMemcpyDeviceToHost));
+    if (steps_out) SMR_HIP(hipMemcpy(steps_out, env->st.brake_steps, B * 4, hipMemcpyDeviceToHost));
+    if (braked_out) SMR_HIP(hipMemcpy(braked_out, env->st.braked, B * 4, hipMemcpyDeviceToHost));
     return SMR_OK;
 }
 

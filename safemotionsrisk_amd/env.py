@@ -44,7 +44,8 @@ class VecSafeMotionsEnv:
     INFO_COLUMNS = ("minimum_distance_to_static_obstacles", "minimum_distance_self_collision",
                     "minimum_distance_to_moving_obstacles", "action_punishment", "self_collision_reward",
                     "static_obstacles_collision_reward", "moving_obstacles_collision_reward", "episode_length",
-                    "braking_trajectory_executed", "target_point_reached", "moving_object_final_state", "risky_action")
+                    "braking_trajectory_executed", "target_point_reached", "moving_object_final_state", "risky_action",
+                    "end_min_distance_punishment", "braking_trajectory_min_distance_punishment")
 
     def __init__(self, num_envs, device=0, seed=None, auto_reset=True, collision_checks_per_step=None,
                  contact_distance=None, return_info=True, env_index_base=0, **env_config):
@@ -243,6 +244,14 @@ class VecSafeMotionsEnv:
         _lib.check(self._L, self._h, rc, "smr_test_distances")
         return out
 
+
+    def test_brake_plan(self):
+        """(acc [segments + 1, 7, B], steps [B], braked [B]) of the last step's braking-trajectory plan (smr_test_brake_plan)"""
+        B, n = self.num_envs, int(self.scene.struct.brake_timeout_steps) + 1
+        acc, steps, braked = np.zeros((n, NJ, B), np.float32), np.zeros(B, np.int32), np.zeros(B, np.int32)
+        rc = self._L.smr_test_brake_plan(self._h, acc.ctypes.data, steps.ctypes.data, braked.ctypes.data)
+        _lib.check(self._L, self._h, rc, "smr_test_brake_plan")
+        return acc, steps, braked
 
     def test_self_bounds(self, q):
         """[n][n_self_pairs] table lower bounds of the self-collision pairs' distances (-3e38: the pair has no table)"""

@@ -17,8 +17,8 @@ LIB_PATH = os.environ.get("SMR_LIB") or os.path.join(_PKG, "libsmr_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 
-ABI_VERSION = 8
-INFO_N = 12
+ABI_VERSION = 9
+INFO_N = 14
 K_COUNT = 7
 KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn", "brake", "risk")
 
@@ -26,7 +26,7 @@ KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn", "brake", "risk")
 EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "smr_last_error", "smr_num_envs",
            "smr_obs_size", "smr_reset", "smr_step", "smr_observe", "smr_get_state", "smr_set_state",
            "smr_synchronize", "smr_set_profiling", "smr_get_profile", "smr_test_fk", "smr_test_safe_acc_range",
-           "smr_test_distances", "smr_test_ball_distances", "smr_test_self_bounds", "smr_mlp_create", "smr_mlp_destroy", "smr_mlp_forward",
+           "smr_test_distances", "smr_test_ball_distances", "smr_test_self_bounds", "smr_test_brake_plan", "smr_mlp_create", "smr_mlp_destroy", "smr_mlp_forward",
            "smr_set_risk_networks")
 
 
@@ -92,6 +92,7 @@ def load():
     L.smr_test_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.smr_test_ball_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.smr_test_self_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.smr_test_brake_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smr_mlp_create.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
     L.smr_mlp_destroy.argtypes = [C.c_void_p]
     L.smr_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]

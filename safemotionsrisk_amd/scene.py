@@ -17,7 +17,7 @@ import os
 
 import numpy as np
 
-SCENE_VERSION = 7
+SCENE_VERSION = 8
 NJ = 7
 NLINK = 8
 MAX_BODIES = 10
@@ -101,6 +101,10 @@ class Scene(C.Structure):
         ("check_braking_trajectory_collisions", C.c_int32), ("brake_checks_per_step", C.c_int32), ("brake_timeout_steps", C.c_int32),
         ("_pad4", C.c_int32), ("brake_safety_distance", C.c_double), ("brake_acc_max", _D7), ("brake_jerk_max", _D7),
         ("brake_stop_velocity", C.c_double), ("brake_stop_acceleration", C.c_double),
+        ("punish_adaptation", C.c_int32), ("punish_end_min_distance", C.c_int32), ("punish_braking_trajectory_min_distance", C.c_int32),
+        ("_pad5", C.c_int32), ("adaptation_max_punishment", C.c_double),
+        ("end_min_distance_max_punishment", C.c_double), ("end_min_distance_max_threshold", C.c_double),
+        ("braking_trajectory_max_punishment", C.c_double), ("braking_trajectory_min_distance_max_threshold", C.c_double),
         ("start_box", (C.c_double * 2) * 3), ("start_min_dist_static", C.c_double),
         ("start_min_dist_self", C.c_double),
         ("kinematic_state_sampling_mode", C.c_int32), ("_pad2", C.c_int32),
@@ -154,6 +158,15 @@ def reach_brake_env_config():
     return dict(REACH_ENV_CONFIG, experiment_name="reaching_task_space_braking", check_braking_trajectory_collisions=True)
 
 
+#: ... with the reward terms that read the braking layer's results (rewards.py:315-334,357-375), thresholds and weights as
+#: trained_networks/human_network/params.json sets them (the one shipped config that switches the layer on)
+def reach_brake_punish_env_config():
+    return dict(reach_brake_env_config(), experiment_name="reaching_task_space_braking_punish", punish_adaptation=True, adaptation_max_punishment=1.0,
+                punish_end_min_distance=True, end_min_distance_max_punishment=0.5, end_min_distance_max_threshold=0.05,
+                punish_braking_trajectory_min_distance=True, braking_trajectory_min_distance_max_threshold=0.05,
+                braking_trajectory_max_punishment=1.0)
+
+
 #: the target-point reaching task in the space scene: trained_networks/task_networks/reaching_task/space/state_action/
 #: params.json without its risk network (risk_config_dir) - SafeMotionsEnv with
 #: TargetPointReachingReward, ball machine mounted, 8 s episodes
@@ -203,11 +216,13 @@ _DEFAULTS = dict(
     target_point_use_actual_position=False, obs_add_target_point_pos=False, obs_add_target_point_relative_pos=False,
     normalize_reward_to_initial_target_point_distance=False, target_point_reward_factor=1.0,
     check_braking_trajectory_collisions=False, acc_limit_factor_braking=1.0, jerk_limit_factor_braking=1.0,
+    punish_adaptation=False, adaptation_max_punishment=1.0, punish_end_min_distance=False,                     # rewards.py:219-246
+    end_min_distance_max_punishment=1.0, end_min_distance_max_threshold=None, punish_braking_trajectory_min_distance=False,
+    braking_trajectory_min_distance_max_threshold=None, braking_trajectory_max_punishment=1.0,
 )
 
 # features of the reference outside the hot-path scope ("out of scope"/"next")
-_UNSUPPORTED_TRUE = ("use_real_robot", "punish_adaptation", "punish_end_min_distance",
-                     "punish_end_max_torque", "punish_braking_trajectory_min_distance", "punish_braking_trajectory_max_torque",
+_UNSUPPORTED_TRUE = ("use_real_robot", "punish_end_max_torque", "punish_braking_trajectory_max_torque",
                      "target_point_use_actual_position",
                      "check_braking_trajectory_torque_limits", "use_gui", "render_video",
                      "risk_check_initial_backup_trajectory", "risk_store_ground_truth", "static_robot",
@@ -571,6 +586,13 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     if _cfg(config, "collision_avoidance_static_obstacles_max_reward") != 0 and \
             float(_cfg(config, "collision_avoidance_static_obstacles_max_reward_distance")) > rmax:
         rmax = float(_cfg(config, "collision_avoidance_static_obstacles_max_reward_distance"))
+    ca_mode_ = bool(_cfg(config, "collision_avoidance_mode"))
+    for flag, key in (("punish_braking_trajectory_min_distance", "braking_trajectory_min_distance_max_threshold"),
+                      ("punish_end_min_distance", "end_min_distance_max_threshold")):         # TargetPointReachingReward, rewards.py:270-300
+        if not ca_mode_ and _cfg(config, flag):
+            if _cfg(config, key) is None:
+                raise ValueError("%s requires %s to be specified" % (flag, key))               # rewards.py:275-282
+            rmax = max(rmax, float(_cfg(config, key)))
     if rmax == -1.0:
         s.static_max_distance = safety + 0.002
     else:
@@ -713,6 +735,20 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     s.brake_stop_velocity, s.brake_stop_acceleration = 0.01, 0.01                          # btg.py:45,75-77
     if s.check_braking_trajectory_collisions and s.static_max_distance < s.brake_safety_distance:
         raise ValueError("closest_point_safety_distance beyond the distance the closest-point queries report")
+    # the reward terms that read the braking layer's results: TargetPointReachingReward only (rewards.py:229-262)
+    reach_reward = not bool(_cfg(config, "collision_avoidance_mode"))
+    s.punish_adaptation = int(reach_reward and bool(_cfg(config, "punish_adaptation")))
+    s.punish_end_min_distance = int(reach_reward and bool(_cfg(config, "punish_end_min_distance")))
+    s.punish_braking_trajectory_min_distance = int(reach_reward and bool(_cfg(config, "punish_braking_trajectory_min_distance")))
+    s.adaptation_max_punishment = float(_cfg(config, "adaptation_max_punishment"))
+    s.end_min_distance_max_punishment = float(_cfg(config, "end_min_distance_max_punishment"))
+    s.braking_trajectory_max_punishment = float(_cfg(config, "braking_trajectory_max_punishment"))
+    s.end_min_distance_max_threshold = float(_cfg(config, "end_min_distance_max_threshold") or 0.0)
+    s.braking_trajectory_min_distance_max_threshold = float(_cfg(config, "braking_trajectory_min_distance_max_threshold") or 0.0)
+    for flag, thr in ((s.punish_end_min_distance, s.end_min_distance_max_threshold),
+                      (s.punish_braking_trajectory_min_distance, s.braking_trajectory_min_distance_max_threshold)):
+        if flag and thr <= s.brake_safety_distance:
+            raise ValueError("the distance threshold of a braking-layer punishment must exceed closest_point_safety_distance")
 
     # ---- reset ----
     box = {0: [[-0.6, 0.6], [-0.8, 0.8], [0.1, 1]], 1: [[-1.1, 1.1], [-1.1, 1.1], [-0.1, 1.5]],

@@ -74,8 +74,11 @@ def explain_mismatches(ora, scene, st0, st1, bad, tie=TIE):
 
 def braking_decision_is_tie(ora, scene, q, v, a, action, tie=TIE):
     """The braking-trajectory check of one env (ctlp.py:3155-3207) replayed with the oracle's component functions: True when one of
-    its decisions sits on a threshold - a static / self distance of a sample within `tie` of the safety distance, or a joint
-    within 1e-6 of the stop band that ends the braking trajectory (btg.py:45) - so that float32 may decide the other way."""
+    its decisions sits on a threshold - a static / self distance of a sample within `tie` of the safety distance, a joint
+    within 1e-6 of the stop band that ends the braking trajectory (btg.py:45), or a joint that rides ON a position limit at a knot
+    of the braking trajectory (within 3e-4 rad: the clip of its braking acceleration into the safe range, btg.py:80-93, then hangs
+    on a margin of micrometres - seen: 19.02 against 20.0 m/s^2 with the joint 1.0e-4 rad from its limit and a dip of 1.1e-4 rad
+    ahead of it - and the two trajectories part by millimetres) - so that float32 may decide the other way."""
     s = scene.struct
     dt, Nb, safety = float(s.dt), int(s.brake_checks_per_step), float(s.brake_safety_distance)
     q, v, a = (np.asarray(x, dtype=np.float64) for x in (q, v, a))
@@ -91,6 +94,8 @@ def braking_decision_is_tie(ora, scene, q, v, a, action, tie=TIE):
                 return False                                # a clear collision ends the check
         p1 = cubic(p, vv, ap, an, dt, dt)
         v1 = vv + 0.5 * (ap + an) * dt
+        if (np.minimum(p1 - np.array(s.pos_lo), np.array(s.pos_hi) - p1) < 3e-4).any():
+            return True
         if (np.abs(np.abs(v1) - float(s.brake_stop_velocity)) < 1e-6).any() or (np.abs(np.abs(an) - float(s.brake_stop_acceleration)) < 1e-6).any():
             return True
         b, stopped = ora.braking_acceleration(p1, v1, an)

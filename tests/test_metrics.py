@@ -107,7 +107,7 @@ class _FakeEnv:
     def step(self, action):
         self.k += 1
         done = self.k >= 3
-        vals = torch.zeros(self.num_envs, 8)
+        vals = torch.zeros(self.num_envs, len(COLS))
         vals[:, 7] = self.k
         vals[:, 2] = 0.5
         info = {"values": vals, "termination_reason": torch.where(done, 2, -1).to(torch.int8)}

@@ -109,3 +109,41 @@ def test_braking_layer_prevents_table_and_self_collisions(built):
         assert (braked > 300) == (name == "brake")
     assert not set(reasons["brake"]) & {3, 4} and 5 in reasons["brake"]
     assert set(reasons["plain"]) & {3, 4}
+
+
+def test_braking_layer_reward_terms(built):
+    """punish_adaptation / punish_end_min_distance / punish_braking_trajectory_min_distance (rewards.py:315-334,357-375): against the
+    same env without them the reward differs by exactly the three weighted punishments; each is in [0, 1]; a step whose braking
+    trajectory was executed carries the full adaptation and braking-trajectory punishments; the end-of-step punishment is the
+    quadratic of min(static, self distance) between the safety distance and its threshold (rewards.py:18-21)."""
+    from safemotionsrisk_amd.scene import reach_brake_env_config, reach_brake_punish_env_config
+    B = 256
+    plain = O.OracleEnv(build_scene(reach_brake_env_config(), auto_reset=False), B, seed=3, num_threads=4)
+    pun = O.OracleEnv(build_scene(reach_brake_punish_env_config(), auto_reset=False), B, seed=3, num_threads=4)
+    s = pun.bundle.struct
+    assert s.punish_adaptation and s.punish_end_min_distance and s.punish_braking_trajectory_min_distance and abs(s.static_max_distance - 0.052) < 1e-12
+    plain.reset()
+    rng = np.random.default_rng(0)
+    st = plain.get_state()
+    st["q"][::2, 1] = rng.uniform(1.2, 1.9, B // 2) * rng.choice([-1, 1], B // 2)            # half of the envs: elbow towards the table
+    st["q"][::2, 3] = rng.uniform(-1.0, 1.0, B // 2)
+    st["v"][::2, 1] = np.sign(st["q"][::2, 1]) * rng.uniform(0.2, 1.2, B // 2)
+    n_braked = n_end = n_bt = 0
+    for t in range(5):
+        plain.set_state(**st); pun.set_state(**st)
+        act = rng.uniform(-1, 1, (B, 7))
+        _, r0, d0, _, i0 = plain.step(act)
+        _, r1, d1, _, i1 = pun.step(act)
+        assert np.array_equal(i0[:, 8], i1[:, 8]) and np.array_equal(d0, d1) and not i0[:, 12:].any()      # the terms do not touch the dynamics
+        braked, end_pun, bt_pun = i1[:, 8], i1[:, 12], i1[:, 13]
+        assert ((end_pun >= 0) & (end_pun <= 1) & (bt_pun >= 0) & (bt_pun <= 1)).all()
+        assert np.allclose(r1, r0 - braked * 1.0 - end_pun * 0.5 - bt_pun * 1.0, atol=1e-9)
+        assert (bt_pun[braked == 1] == 1).all()
+        # the cut-off differs between the two scenes (0.052 here): below it the distances are the same queries
+        dmin = np.minimum(i1[:, 0], i1[:, 1])
+        expect = np.clip((0.05 - dmin) / (0.05 - s.brake_safety_distance), 0, 1) ** 2
+        assert np.allclose(end_pun, expect, atol=1e-12)
+        n_braked += int(braked.sum()); n_end += int((end_pun > 0).sum()); n_bt += int(((bt_pun > 0) & (bt_pun < 1)).sum())
+        st = plain.get_state()
+    assert n_braked > 20 and n_end > 20 and n_bt > 5
+    plain.close(); pun.close()

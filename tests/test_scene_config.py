@@ -55,7 +55,7 @@ def test_obs_planet_size_variants():
 
 
 @pytest.mark.parametrize("key,value,exc", [
-    ("punish_end_min_distance", True, NotImplementedError),
+    ("punish_end_max_torque", True, NotImplementedError), ("punish_braking_trajectory_max_torque", True, NotImplementedError),
     ("check_braking_trajectory_collisions", True, NotImplementedError), ("use_real_robot", True, NotImplementedError),
     ("human_network_checkpoint", "human_network/checkpoint/checkpoint", NotImplementedError),
     ("risk_config_dir", "risk_networks/state_action/space", NotImplementedError),
