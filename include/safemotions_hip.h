@@ -63,7 +63,10 @@ extern "C" {
                                          (risky_action_rate, actions.py:303-340); 0 without risk networks */
 #define SMR_INFO_END_MIN_DISTANCE_PUNISHMENT 12   /* end_min_distance_punishment in [0, 1], rewards.py:322-332; 0 without punish_end_min_distance */
 #define SMR_INFO_BRAKING_TRAJECTORY_PUNISHMENT 13 /* braking_trajectory_min_distance_punishment in [0, 1], ctlp.py:2393-2415 */
-#define SMR_INFO_N 14
+#define SMR_INFO_START_ATTEMPTS 14    /* _starting_point_sampling_attempts of the env's running episode: candidates drawn until its start
+                                         position was collision free (ctlp.py:1480-1488) -> obstacles_starting_point_sampling_attempts at
+                                         the end of the episode (ctlp.py:1154) */
+#define SMR_INFO_N 15
 
 /* kernels timed by smr_get_profile */
 #define SMR_K_PLAN 0      /* A2/A4: safe acceleration range + action mapping            */
@@ -169,6 +172,15 @@ int smr_mlp_forward(smr_mlp_t *mlp, const float *x_dev, int32_t ldx, float *y_de
  * target-point columns (obs.py:419-431).  risk: input obs_size - target columns + 7, one output; backup: input obs_size - target
  * columns, >= 7 outputs.  Pass NULL networks to switch it off.  The handles must outlive the env's use of them. */
 int smr_set_risk_networks(smr_env_t *env, smr_mlp_t *risk, smr_mlp_t *backup, float risk_threshold);
+/* A risk network WITHOUT an action input (risk_config.json "action_size": null; its input is the risk observation alone) rates a
+ * state; risk_state_config (base.py:73-83,174) says which: */
+#define SMR_RISK_STATE_ACTION (-1)    /* (not a risk_state_config: the mode in force when the network takes the action) */
+#define SMR_RISK_CURRENT_STATE 0      /* RISK_CHECK_CURRENT_STATE: the current risk observation, base.py:1504-1506 */
+#define SMR_RISK_NEXT_KINEMATIC 1     /* RISK_CHECK_NEXT_STATE_KINEMATIC_FORECASTING: the next step's kinematic columns for the requested
+                                         action, the rest as now (base.py:1507-1517, obs.py:192-231) */
+#define SMR_RISK_NEXT_FULL 2          /* RISK_CHECK_NEXT_STATE_FULL_FORECASTING: the planets / the ball one step on as well */
+/* (3, 4 - RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP[_AND_BACKUP_TRAJECTORY], a background copy of the env stepped ahead - are refused) */
+int smr_set_risk_state_config(smr_env_t *env, int32_t risk_state_config);
 
 /* ---- component entry points (parity tests): each runs the same device functions the step kernels
  * use on n host-provided inputs and copies the results back; all synchronise ---- */

@@ -10,7 +10,7 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_DIR, "libsmr_oracle.so")
-INFO_N = 14
+INFO_N = 15
 NJ = 7
 
 

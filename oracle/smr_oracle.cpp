@@ -425,6 +425,7 @@ struct EnvState {
     /* target point (A14): position, distance at the last observation, distance when it was sampled (ctlp.py:2210-2350) */
     double tp_pos[3], tp_last, tp_init;
     uint32_t tp_count;         /* target points sampled so far = Philox tag of the next one */
+    uint32_t start_attempts;   /* _starting_point_sampling_attempts of the running episode, ctlp.py:1480-1488 */
 };
 
 struct Oracle {
@@ -981,6 +982,7 @@ void reset_env(Oracle &O, int e) {
     double q[SMR_NJ], v[SMR_NJ] = {0}, a[SMR_NJ] = {0};
     uint32_t attempt = 0;
     sample_position(O, rng, attempt, q);
+    st.start_attempts = attempt;                                                              /* ctlp.py:1488 */
     /* A17 part 2: get_starting_point_joint_pos_vel_acc, ctlp.py:1490-1654 (outside collision_avoidance_mode the episode
      * starts at rest, ctlp.py:1490-1491) */
     if (!S.collision_avoidance_mode) {
@@ -1084,7 +1086,7 @@ void reset_env(Oracle &O, int e) {
 
 /* info columns written by step (mirrors the product's SMR_INFO_* layout) */
 enum { INFO_D_STATIC = 0, INFO_D_SELF, INFO_D_MOVING, INFO_ACTION_PUNISHMENT, INFO_R_SELF, INFO_R_STATIC,
-       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_BRAKED, INFO_TARGET_REACHED, INFO_BALL_EVENT, INFO_RISKY, INFO_END_MIN_PUNISHMENT, INFO_BT_PUNISHMENT, INFO_N };
+       INFO_R_MOVING, INFO_EPISODE_LENGTH, INFO_BRAKED, INFO_TARGET_REACHED, INFO_BALL_EVENT, INFO_RISKY, INFO_END_MIN_PUNISHMENT, INFO_BT_PUNISHMENT, INFO_START_ATTEMPTS, INFO_N };
 
 /* A1/A2/A3/A11/A12/A13/A16: SafeMotionsBase.step + process_step_outcome for one env. */
 void step_env(Oracle &O, int e, const double *action, float *obs, double *reward, uint8_t *done,
@@ -1270,7 +1272,7 @@ void step_env(Oracle &O, int e, const double *action, float *obs, double *reward
         info[INFO_D_STATIC] = d_static; info[INFO_D_SELF] = d_self; info[INFO_D_MOVING] = d_moving;
         info[INFO_ACTION_PUNISHMENT] = action_punishment; info[INFO_R_SELF] = r_self;
         info[INFO_R_STATIC] = r_static; info[INFO_R_MOVING] = r_moving; info[INFO_EPISODE_LENGTH] = st.step_count;
-        info[INFO_BRAKED] = braked ? 1.0 : 0.0; info[INFO_TARGET_REACHED] = tp_reached ? 1.0 : 0.0; info[INFO_BALL_EVENT] = ball_event; info[INFO_RISKY] = 0.0; info[INFO_END_MIN_PUNISHMENT] = end_min_punishment; info[INFO_BT_PUNISHMENT] = bt_punishment;     /* the risk check sits above step() (tests/test_gpu_policy.py) */
+        info[INFO_BRAKED] = braked ? 1.0 : 0.0; info[INFO_TARGET_REACHED] = tp_reached ? 1.0 : 0.0; info[INFO_BALL_EVENT] = ball_event; info[INFO_RISKY] = 0.0; info[INFO_END_MIN_PUNISHMENT] = end_min_punishment; info[INFO_BT_PUNISHMENT] = bt_punishment; info[INFO_START_ATTEMPTS] = st.start_attempts;     /* the risk check sits above step() (tests/test_gpu_policy.py) */
     }
     if (d && S.auto_reset) reset_env(O, e);
     else {

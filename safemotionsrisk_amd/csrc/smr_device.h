@@ -217,6 +217,8 @@ struct DState {
     float *next_q, *next_v, *next_a;   // [2][7][B]
     int *next_planet_idx;              // [2][2][B]
     int *next_hit;                     // [2][B]
+    unsigned *next_attempts;           // [2][B] candidates drawn for the staged start position
+    unsigned *start_attempts;          // [B] ... for the start position of the running episode (_starting_point_sampling_attempts, ctlp.py:1488)
     unsigned *staged_tag;              // [2][B]  reset_count value the staged state belongs to (~0u: none)
     unsigned *refill_tags;             // parallel to refill_list: the tag to prepare (the env may restart again before the refill runs)
     int *refill_list;                  // [B]  envs whose staged state was consumed

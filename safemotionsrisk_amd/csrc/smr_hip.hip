@@ -633,6 +633,7 @@ __device__ inline void commit_staged(const DScene &S, const DState &st, int e, f
     st.planet_idx[e] = idx[0]; st.planet_idx[B + e] = idx[1];
     st.step_count[e] = 0;
     st.moving_hit[e] = st.next_hit[sl * B + e];
+    st.start_attempts[e] = st.next_attempts[sl * B + e];
     st.reset_count[e] = tag + 1u;
     if (row) write_observation(S, q, v, a, idx, row);
 }
@@ -830,6 +831,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         row[SMR_INFO_BRAKED] = S.check_braking ? (float)st.braked[e] : 0.f; row[SMR_INFO_TARGET_REACHED] = tp_reached ? 1.f : 0.f;
         row[SMR_INFO_BALL_EVENT] = (float)ball_event; row[SMR_INFO_RISKY] = st.risky ? (float)st.risky[e] : 0.f;
         row[SMR_INFO_END_MIN_DISTANCE_PUNISHMENT] = end_min_pun; row[SMR_INFO_BRAKING_TRAJECTORY_PUNISHMENT] = bt_pun;
+        row[SMR_INFO_START_ATTEMPTS] = (float)st.start_attempts[e];
     }
 
 #pragma unroll
@@ -1518,6 +1520,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
     };
     SMR_PHASE_INIT;
     next_position();
+    const unsigned first_attempts = attempt;                                            // ctlp.py:1480-1488
     SMR_PHASE(0);
 
     // ---- joint velocity / acceleration.  After this block lane j (< 7) holds joint j in (qj, vj, aj).
@@ -1610,7 +1613,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
     if (STAGED) {      // robot part only; the ball of a reset depends on the env's spawn history: spawn_kernel draws it at commit time
         const size_t sl = (size_t)(rng.tag & 1u);
         if (g < SMR_NJ) { st.next_q[(sl * SMR_NJ + g) * B + e] = qj; st.next_v[(sl * SMR_NJ + g) * B + e] = vj; st.next_a[(sl * SMR_NJ + g) * B + e] = aj; }
-        else { st.next_planet_idx[(sl * 2) * B + e] = idx[0]; st.next_planet_idx[(sl * 2 + 1) * B + e] = idx[1]; st.next_hit[sl * B + e] = hit; st.staged_tag[sl * B + e] = rng.tag; }
+        else { st.next_planet_idx[(sl * 2) * B + e] = idx[0]; st.next_planet_idx[(sl * 2 + 1) * B + e] = idx[1]; st.next_hit[sl * B + e] = hit; st.next_attempts[sl * B + e] = first_attempts; st.staged_tag[sl * B + e] = rng.tag; }
         return;
     }
     // ---- ball: spawn + random initial time step, candidates in sequence (ctlp.py:1052-1111)
@@ -1651,6 +1654,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
         st.planet_idx[B + e] = idx[1];
         st.step_count[e] = 0;
         st.moving_hit[e] = hit;
+        st.start_attempts[e] = first_attempts;
         st.reset_count[e] = rng.tag + 1u;
         if (row) write_planet_observation(S, idx, row + 3 * SMR_NJ + S.obs_target_size);
         if (S.use_ball) {
@@ -1828,9 +1832,17 @@ __global__ void test_self_bounds_kernel(const DScene *__restrict__ Sp, const flo
 }
 
 // ---- risk-aware stepping: actions.py:303-340, base.py:1498-1502,1598-1603 ----
-// row e of x: the risk observation of env e (obs.py:419-431: the observation without its target-point columns) followed by the
-// action the caller asks for
-__global__ void risk_input_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions, float *__restrict__ x, int ldx) {
+// row e of x: the risk network's input for env e; row e of xb: the backup policy's - the risk observation of the CURRENT state
+// (obs.py:419-431: the observation without its target-point columns).  mode (base.py:1498-1517):
+//   SMR_RISK_STATE_ACTION     x = [risk observation | requested action]                       (a network with action_size = 7)
+//   SMR_RISK_CURRENT_STATE    x = the risk observation                                         (RISK_CHECK_CURRENT_STATE)
+//   SMR_RISK_NEXT_KINEMATIC   x = the risk observation the NEXT step would see for the requested action: joint positions, velocities
+//                                 and accelerations at the end of the planned cubic (plan_kernel has run on the requested action:
+//                                 a1), the planets / the ball as now (_get_next_risk_observation, obs.py:192-231)
+//   SMR_RISK_NEXT_FULL        ... and the planets / the ball one step on as well (forecast_non_kinematic_components, obs.py:262-271,
+//                                 ctlp.py:2364-2377)
+__global__ void risk_input_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions, float *__restrict__ x, int ldx,
+                                  float *__restrict__ xb, int ldxb, int mode) {
     const DScene &S = *Sp;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
@@ -1838,20 +1850,33 @@ __global__ void risk_input_kernel(const DScene *__restrict__ Sp, DState st, cons
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
 #pragma unroll
     for (int j = 0; j < SMR_NJ; ++j) { q[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; a[j] = st.a[j * B + e]; }
-    float *row = x + (size_t)e * ldx;
+    const bool forecast = mode == SMR_RISK_NEXT_KINEMATIC || mode == SMR_RISK_NEXT_FULL;
+    for (int pass = 0; pass < 2; ++pass) {               // 0: the backup policy's row (the current state), 1: the risk network's
+        float *row = pass == 0 ? xb + (size_t)e * ldxb : x + (size_t)e * ldx;
+        const bool next = pass == 1 && forecast, next_all = pass == 1 && mode == SMR_RISK_NEXT_FULL;
 #pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) {
-        row[j] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (q[j] - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
-        row[SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, v[j] / S.vel_max[j]));
-        row[2 * SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, a[j] / S.acc_max[j]));
+        for (int j = 0; j < SMR_NJ; ++j) {
+            float qj = q[j], vj = v[j], aj = a[j];
+            if (next) {
+                const float a1 = st.a1[j * B + e];
+                qj = interp_pos(q[j], v[j], a[j], a1, S.dt, S.dt); vj = interp_vel(v[j], a[j], a1, S.dt, S.dt); aj = a1;
+            }
+            row[j] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (qj - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
+            row[SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, vj / S.vel_max[j]));
+            row[2 * SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, aj / S.acc_max[j]));
+        }
+        int o = 3 * SMR_NJ;
+        if (S.use_ball) { write_ball_observation(S, load_ball(st, B, e), st.ball_i[e] + (next_all ? S.updates_per_step : 0), row + o); o += 6; }     // moving object, then planets: obs.py:424-427
+        int idx[SMR_MAX_PLANETS] = {st.planet_idx[e], st.planet_idx[B + e]};
+        if (next_all)
+#pragma unroll
+            for (int p = 0; p < SMR_MAX_PLANETS; ++p) if (p < S.n_planets) idx[p] = (idx[p] + S.updates_per_step) % S.planet[p].n_orbit;
+        write_planet_observation(S, idx, row + o);
+        o += S.obs_num_planets * S.obs_planet_size;
+        if (pass == 1 && mode == SMR_RISK_STATE_ACTION)
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) row[o + j] = actions[(size_t)e * SMR_NJ + j];
     }
-    int o = 3 * SMR_NJ;
-    if (S.use_ball) { write_ball_observation(S, load_ball(st, B, e), st.ball_i[e], row + o); o += 6; }     // moving object, then planets: obs.py:424-427
-    const int idx[SMR_MAX_PLANETS] = {st.planet_idx[e], st.planet_idx[B + e]};
-    write_planet_observation(S, idx, row + o);
-    o += S.obs_num_planets * S.obs_planet_size;
-#pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) row[o + j] = actions[(size_t)e * SMR_NJ + j];
 }
 
 __global__ void risk_apply_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions, const float *__restrict__ risk,
@@ -1900,7 +1925,9 @@ struct smr_env {
     int parity = 0;
     struct smr_mlp *risk_net = nullptr, *backup_net = nullptr;     // risk-aware stepping (smr_set_risk_networks)
     float risk_threshold = 0.05f;
-    float *risk_x = nullptr, *risk_y = nullptr, *backup_y = nullptr, *actions_eff = nullptr;
+    float *risk_x = nullptr, *risk_y = nullptr, *backup_x = nullptr, *backup_y = nullptr, *actions_eff = nullptr;
+    int risk_state_config = SMR_RISK_CURRENT_STATE;   // what a risk network WITHOUT an action input looks at (smr_set_risk_state_config)
+    int risk_mode = SMR_RISK_STATE_ACTION;            // the mode in force (state-action when the network takes the action)
     int *risky_buf = nullptr;
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
     int job_blocks = 0;               // their persistent grid: two 512-lane blocks per CU
@@ -2216,7 +2243,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     DState &st = env->st;
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
-        (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
+        (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.start_attempts, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
         (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) || (rc = dev_alloc(env, &st.bt_min, B)) || 
         (rc = dev_alloc(env, &st.brake_acc, scene->check_braking_trajectory_collisions ? (size_t)(scene->brake_timeout_steps + 1) * SMR_NJ * B : 1)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
@@ -2226,7 +2253,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     st.spawn_list = env->spawn_lists; st.spawn_count = env->spawn_counts; st.spawn_tags = env->spawn_tag_lists;
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
-               e7 = hipMemset(st.reset_count, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
+               e7 = hipMemset(st.reset_count, 0, B * 4) ? hipErrorUnknown : hipMemset(st.start_attempts, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     if (env->hscene.jobs_on) {
         const size_t NB = (size_t)scene->n_bodies, N = (size_t)scene->collision_checks_per_step;
@@ -2258,7 +2285,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     }
     if (env->staged) {
         if ((rc = dev_alloc(env, &st.next_q, 14 * B)) || (rc = dev_alloc(env, &st.next_v, 14 * B)) || (rc = dev_alloc(env, &st.next_a, 14 * B)) ||
-            (rc = dev_alloc(env, &st.next_planet_idx, 4 * B)) || (rc = dev_alloc(env, &st.next_hit, 2 * B)) || (rc = dev_alloc(env, &st.staged_tag, 2 * B)) ||
+            (rc = dev_alloc(env, &st.next_planet_idx, 4 * B)) || (rc = dev_alloc(env, &st.next_hit, 2 * B)) || (rc = dev_alloc(env, &st.next_attempts, 2 * B)) || (rc = dev_alloc(env, &st.staged_tag, 2 * B)) ||
             (rc = dev_alloc(env, &env->refill_lists, 3 * B)) || (rc = dev_alloc(env, &env->refill_tag_lists, 3 * B)) ||
             (rc = dev_alloc(env, &env->refill_slots, 3)) || (rc = dev_alloc(env, &st.stale_commits, 1)))
             return fail(rc);
@@ -2572,10 +2599,13 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (env->risk_net) {                                // actions.py:303-340: the backup policy's action where the risk network objects
         LaunchTimer t(env, SMR_K_RISK);
         const int robs = env->obs_size - env->hscene.obs_target_size, ldx = robs + SMR_NJ, ldb = env->backup_net->d.out_size;
-        hipLaunchKernelGGL(risk_input_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, env->risk_x, ldx);
+        if (env->risk_mode == SMR_RISK_NEXT_KINEMATIC || env->risk_mode == SMR_RISK_NEXT_FULL)      // the forecast needs the requested action's end acceleration
+            hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
+        hipLaunchKernelGGL(risk_input_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, env->risk_x, ldx, env->backup_x, robs,
+                           env->risk_mode);
         const dim3 mgrid((B + kMlpRows - 1) / kMlpRows);
         hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->risk_net->d, (const float *)env->risk_x, ldx, env->risk_y, 1, B);
-        hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->backup_net->d, (const float *)env->risk_x, ldx, env->backup_y, ldb, B);
+        hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->backup_net->d, (const float *)env->backup_x, robs, env->backup_y, ldb, B);
         hipLaunchKernelGGL(risk_apply_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, (const float *)env->risk_y,
                            (const float *)env->backup_y, ldb, env->risk_threshold, env->actions_eff);
         SMR_HIP(hipGetLastError());
@@ -2831,16 +2861,31 @@ int smr_set_risk_networks(smr_env_t *env, smr_mlp_t *risk, smr_mlp_t *backup, fl
     const int robs = env->obs_size - env->hscene.obs_target_size;                         // obs.py:419-431: no target-point columns
     if (!risk || !backup) { env->err = "smr_set_risk_networks: both networks are needed"; return SMR_E_INVALID; }
     if (risk->device != env->device || backup->device != env->device) { env->err = "smr_set_risk_networks: networks live on another device"; return SMR_E_INVALID; }
-    if (risk->d.in_size != robs + SMR_NJ || risk->d.out_size != 1) { env->err = "smr_set_risk_networks: the risk network must map (risk observation, action) to one value"; return SMR_E_INVALID; }
+    if ((risk->d.in_size != robs + SMR_NJ && risk->d.in_size != robs) || risk->d.out_size != 1) {
+        env->err = "smr_set_risk_networks: the risk network must map (risk observation, action) or the risk observation alone to one value"; return SMR_E_INVALID;
+    }
     if (backup->d.in_size != robs || backup->d.out_size < SMR_NJ) { env->err = "smr_set_risk_networks: the backup policy must map the risk observation to >= 7 outputs"; return SMR_E_INVALID; }
     const size_t B = (size_t)env->B;
     int rc;
-    if (!env->risk_x && ((rc = dev_alloc(env, &env->risk_x, B * (robs + SMR_NJ))) || (rc = dev_alloc(env, &env->risk_y, B)) ||
+    if (!env->risk_x && ((rc = dev_alloc(env, &env->risk_x, B * (robs + SMR_NJ))) || (rc = dev_alloc(env, &env->risk_y, B)) || (rc = dev_alloc(env, &env->backup_x, B * robs)) ||
                          (rc = dev_alloc(env, &env->backup_y, B * SMR_MLP_MAX_WIDTH)) || (rc = dev_alloc(env, &env->actions_eff, B * SMR_NJ)) ||
                          (rc = dev_alloc(env, &env->risky_buf, B)))) return rc;
     SMR_HIP(hipMemset(env->risky_buf, 0, B * 4));
     env->st.risky = env->risky_buf;
     env->risk_net = risk; env->backup_net = backup; env->risk_threshold = risk_threshold;
+    env->risk_mode = risk->d.in_size == robs + SMR_NJ ? SMR_RISK_STATE_ACTION : env->risk_state_config;      // base.py:609-617: action_size decides
+    return SMR_OK;
+}
+
+int smr_set_risk_state_config(smr_env_t *env, int32_t config) {
+    if (!env) return SMR_E_INVALID;
+    if (config != SMR_RISK_CURRENT_STATE && config != SMR_RISK_NEXT_KINEMATIC && config != SMR_RISK_NEXT_FULL) {
+        env->err = "smr_set_risk_state_config: only RISK_CHECK_CURRENT_STATE (0), NEXT_STATE_KINEMATIC_FORECASTING (1) and NEXT_STATE_FULL_FORECASTING (2); "
+                   "the modes that simulate the next step in a background copy of the env (3, 4) are not built";
+        return SMR_E_INVALID;
+    }
+    env->risk_state_config = config;
+    if (env->risk_net && env->risk_mode != SMR_RISK_STATE_ACTION) env->risk_mode = config;
     return SMR_OK;
 }
 

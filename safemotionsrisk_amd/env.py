@@ -45,13 +45,16 @@ class VecSafeMotionsEnv:
                     "minimum_distance_to_moving_obstacles", "action_punishment", "self_collision_reward",
                     "static_obstacles_collision_reward", "moving_obstacles_collision_reward", "episode_length",
                     "braking_trajectory_executed", "target_point_reached", "moving_object_final_state", "risky_action",
-                    "end_min_distance_punishment", "braking_trajectory_min_distance_punishment")
+                    "end_min_distance_punishment", "braking_trajectory_min_distance_punishment", "starting_point_sampling_attempts")
 
     def __init__(self, num_envs, device=0, seed=None, auto_reset=True, collision_checks_per_step=None,
-                 contact_distance=None, return_info=True, env_index_base=0, **env_config):
+                 contact_distance=None, return_info=True, env_index_base=0, trained_networks_dir=None, **env_config):
         """env_index_base: this handle owns the envs [env_index_base, env_index_base + num_envs) of a global batch that is
         sharded over several handles / GPUs (dist.py): every draw of an env is keyed by (seed, GLOBAL env index, its counters), so
-        the shards together produce bit for bit what one handle over the whole batch produces."""
+        the shards together produce bit for bit what one handle over the whole batch produces.
+        trained_networks_dir: where a relative ``risk_config_dir`` / checkpoint path of the env_config is looked up (the reference's
+        ``safemotions/trained_networks``; scene.resolve_risk_config).  An env_config with a risk network reads its two JSON files
+        and then WAITS for the weights: step() raises until set_risk_networks() has been called with arrays (policy.Mlp)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("VecSafeMotionsEnv needs a GPU: the HIP library has no CPU path")
@@ -59,7 +62,7 @@ class VecSafeMotionsEnv:
         self._L = _lib.load()
         kw = {} if contact_distance is None else dict(contact_distance=contact_distance)
         self.scene = build_scene(env_config, collision_checks_per_step=collision_checks_per_step,
-                                 auto_reset=auto_reset, **kw)
+                                 auto_reset=auto_reset, trained_networks_dir=trained_networks_dir, **kw)
         self.num_envs = int(num_envs)
         self.device = torch.device("cuda", int(device))
         self.observation_size = self.scene.obs_size
@@ -73,8 +76,14 @@ class VecSafeMotionsEnv:
         if self._env_index_base < 0 or self._env_index_base + self.num_envs > 0xFFFFFFFF:
             raise ValueError("env_index_base + num_envs must fit 32 bits")
         self._h = None
-        self._risk_nets, self._risk_threshold, self._profiling = None, 0.05, False
+        self._risk_nets, self._risk_threshold, self._risk_state_config, self._profiling = None, 0.05, 0, False
+        self.risk_config = self.scene.risk            # the env_config's risk network description (observation_size, action_size, ...) or None
+        if self.risk_config is not None:
+            self._risk_threshold, self._risk_state_config = self.risk_config["risk_threshold"], self.risk_config["risk_state_config"]
         self._create()
+        if self.risk_config is not None and self.risk_config["observation_size"] != self.risk_observation_size:
+            raise ValueError("risk_config.json: observation_size %d, the env's risk observation has %d columns (safe_motions_base.py:542-571)"
+                             % (self.risk_config["observation_size"], self.risk_observation_size))
         B, O = self.num_envs, self.observation_size
         self.obs = torch.zeros((B, O), dtype=torch.float32, device=self.device)
         self.reward = torch.zeros(B, dtype=torch.float32, device=self.device)
@@ -104,7 +113,7 @@ class VecSafeMotionsEnv:
         self.episode_counter = 0
         # the fresh handle knows nothing of what was configured on the old one: put it back (risk-aware stepping, profiling)
         if self._risk_nets is not None and self._risk_nets[0] is not None:
-            self.set_risk_networks(*self._risk_nets, risk_threshold=self._risk_threshold)
+            self.set_risk_networks(*self._risk_nets, risk_threshold=self._risk_threshold, risk_state_config=self._risk_state_config)
         if self._profiling:
             self.set_profiling(True)
 
@@ -127,6 +136,10 @@ class VecSafeMotionsEnv:
         a = action.to(device=self.device, dtype=t.float32).contiguous()
         if a.shape != (self.num_envs, NJ):
             raise ValueError("action must have shape (%d, %d), got %s" % (self.num_envs, NJ, tuple(a.shape)))
+        if self.risk_config is not None and (self._risk_nets is None or self._risk_nets[0] is None):
+            raise RuntimeError("this env_config names a risk network (%s): call set_risk_networks(risk, backup) with the weights as arrays "
+                               "(policy.Mlp / Mlp.from_npz) before the first step - checkpoints and SavedModels are never deserialised here"
+                               % self.risk_config["checkpoint"])
         rc = self._L.smr_step(self._h, C.c_void_p(a.data_ptr()), C.c_void_p(self.obs.data_ptr()),
                               C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.done.data_ptr()),
                               C.c_void_p(self.termination_reason.data_ptr()),
@@ -138,12 +151,25 @@ class VecSafeMotionsEnv:
             info["values"] = self.info
         return self.obs, self.reward, self.done, info
 
-    def set_risk_networks(self, risk, backup, risk_threshold=0.05):
-        """Risk-aware stepping (actions.py:303-340 with a state-action risk network, risk_threshold default base.py:222-223): inside
-        step(), where risk([risk observation, action]) >= risk_threshold the backup policy's deterministic action replaces the
-        action.  risk / backup: policy.Mlp objects on this env's device (None, None switches it off); info column ``risky_action``
-        reports it per step."""
-        self._risk_nets, self._risk_threshold = (risk, backup), float(risk_threshold)   # kept alive, and re-applied by set_seed()
+    def set_risk_networks(self, risk, backup, risk_threshold=None, risk_state_config=None):
+        """Risk-aware stepping (actions.py:303-340, base.py:1498-1517,1598-1603; risk_threshold default base.py:222-223): inside
+        step(), where the risk network's rating reaches risk_threshold the backup policy's deterministic action replaces the
+        action.  A network over [risk observation, action] rates the state-action pair; one over the risk observation alone rates
+        the state ``risk_state_config`` names: 0 the current one, 1 the next one with its kinematic columns forecast for the
+        requested action, 2 with the planets / the ball forecast as well (3, 4 - a background copy of the env stepped ahead - are
+        not built).  risk / backup: policy.Mlp objects on this env's device (None, None switches it off); info column
+        ``risky_action`` reports it per step.  Defaults: what the env_config's risk keys said, else 0.05 and 0."""
+        if risk_threshold is None:
+            risk_threshold = self._risk_threshold
+        if risk_state_config is None:
+            risk_state_config = self._risk_state_config
+        if risk is not None and self.risk_config is not None:
+            want = self.risk_observation_size + (NJ if self.risk_config["action_size"] is not None else 0)
+            if risk.sizes[0] != want:
+                raise ValueError("risk_config.json describes a risk network with %d inputs, the one given has %d" % (want, risk.sizes[0]))
+        self._risk_nets, self._risk_threshold, self._risk_state_config = (risk, backup), float(risk_threshold), int(risk_state_config)   # re-applied by set_seed()
+        rc = self._L.smr_set_risk_state_config(self._h, int(risk_state_config))
+        _lib.check(self._L, self._h, rc, "smr_set_risk_state_config")
         rc = self._L.smr_set_risk_networks(self._h, None if risk is None else risk._h, None if backup is None else backup._h,
                                            C.c_float(float(risk_threshold)))
         _lib.check(self._L, self._h, rc, "smr_set_risk_networks")

@@ -38,6 +38,8 @@ TERMINATION_RATE_KEYS = {
 #: event columns of the info matrix: folded into the episode-end statistics of ObstacleWrapperSim.get_info_and_print_stats
 #: (ctlp.py:1141-1309) instead of the per-step average / max / min scalars
 EVENT_COLUMNS = ("braking_trajectory_executed", "target_point_reached", "moving_object_final_state", "risky_action")
+#: a property of the whole episode that travels in the info matrix: reported as it stands at the end of the episode
+EPISODE_COLUMNS = {"starting_point_sampling_attempts": "obstacles_starting_point_sampling_attempts"}       # ctlp.py:1154
 
 
 def step_scalar_names(info_columns):
@@ -50,7 +52,7 @@ def step_scalar_names(info_columns):
     for kind in ("pos", "vel", "acc"):
         names += ["joint_%d_%s_abs" % (j, kind) for j in range(NJ)]
     names += ["joint_vel_norm"]
-    names += [c for c in info_columns if c != "episode_length" and c not in EVENT_COLUMNS]
+    names += [c for c in info_columns if c != "episode_length" and c not in EVENT_COLUMNS and c not in EPISODE_COLUMNS]
     names += ["collision_rate_self", "collision_rate_static_obstacles", "collision_rate_moving_obstacles", "reward"]
     return names
 
@@ -79,7 +81,8 @@ class EpisodeMetrics:
         self.num_envs, self.auto_reset = int(num_envs), bool(auto_reset)
         self.info_columns = tuple(info_columns)
         self.names = step_scalar_names(self.info_columns)
-        self._info_sel = [i for i, c in enumerate(self.info_columns) if c != "episode_length" and c not in EVENT_COLUMNS]
+        self._info_sel = [i for i, c in enumerate(self.info_columns) if c != "episode_length" and c not in EVENT_COLUMNS and c not in EPISODE_COLUMNS]
+        self._episode_cols = [(i, EPISODE_COLUMNS[c]) for i, c in enumerate(self.info_columns) if c in EPISODE_COLUMNS]
         self._event_cols = [self.info_columns.index(c) if c in self.info_columns else None for c in EVENT_COLUMNS]
         self._len_col = self.info_columns.index("episode_length")
         self._d_cols = [self.info_columns.index(c) for c in ("minimum_distance_self_collision", "minimum_distance_to_static_obstacles",
@@ -144,6 +147,9 @@ class EpisodeMetrics:
         for code, name in TERMINATION_RATE_KEYS.items():
             metrics[name] = (reason == code).float()
         metrics.update(self._obstacle_stats(self.events[idx]))
+        for col, name in self._episode_cols:
+            if col < info["values"].shape[1]:
+                metrics[name] = info["values"][idx, col].float()
         self.events[idx] = 0
         self.sum[idx] = 0
         self.count[idx] = 0
@@ -154,8 +160,9 @@ class EpisodeMetrics:
 
     def _obstacle_stats(self, ev):
         """ObstacleWrapperSim.get_info_and_print_stats (ctlp.py:1141-1309), the part this path produces: the braking-trajectory
-        influence (torque checks are physics: 0), target points reached, final states of the balls of the episode.  Not produced:
-        the sampling-attempt counts (ctlp.py:1151,1171-1176) and obstacles_link_data_* (log_obstacle_data)."""
+        influence (torque checks are physics: 0), target points reached, final states of the balls of the episode
+        (obstacles_starting_point_sampling_attempts comes from its info column, update()).  Not produced: the target-point
+        sampling attempts of several robots (ctlp.py:1171-1176) and obstacles_link_data_* (log_obstacle_data)."""
         t = self._t
         steps, braked, reached, hit_robot, hit_obstacle, missed, risky, first_risky = ev.unbind(dim=1)
         infl = braked / steps.clamp(min=1)

@@ -228,9 +228,93 @@ _UNSUPPORTED_TRUE = ("use_real_robot", "punish_end_max_torque", "punish_braking_
                      "risk_check_initial_backup_trajectory", "risk_store_ground_truth", "static_robot",
                      "moving_object_aim_at_current_robot_position", "normalize_reward_to_frequency",
                      "obstacle_use_computed_actual_values", "always_use_collision_avoidance_starting_point_sampling")
-_UNSUPPORTED_NOT_NONE = ("human_network_checkpoint", "risk_config", "risk_config_dir",
+_UNSUPPORTED_NOT_NONE = ("human_network_checkpoint",
                          "collision_avoidance_new_state_sample_time_range", "action_preprocessing_function",
                          "target_link_name")
+
+
+# ---- risk-aware stepping: the env_config keys (train.py:168-309 -> safe_motions_base.py:170-180,222-223,502-585) ----
+#: parameters of the env that the BACKUP policy's env_config overrides (safe_motions_base.py:525-538): the risk network and the
+#: backup policy were trained in that scene
+RISK_OVERWRITE_PARAMETERS = ("planet_mode", "planet_one_center", "planet_one_radius_xy", "planet_one_euler_angles", "planet_one_period",
+                             "planet_two_center", "planet_two_radius_xy", "planet_two_euler_angles", "planet_two_period",
+                             "planet_two_time_shift", "use_moving_objects", "moving_object_sequence", "moving_object_area_center",
+                             "moving_object_area_width_height", "moving_object_sphere_center", "moving_object_sphere_radius",
+                             "moving_object_sphere_height_min_max", "moving_object_sphere_angle_min_max",
+                             "moving_object_speed_meter_per_second", "moving_object_aim_at_current_robot_position",
+                             "moving_object_check_invalid_target_link_point_positions", "moving_object_active_number_single",
+                             "ball_machine_mode", "human_network_checkpoint", "human_network_use_full_observation")
+RISK_ERROR_PARAMETERS = ("robot_scene", "trajectory_time_step", "acc_limit_factor", "jerk_limit_factor", "pos_limit_factor", "vel_limit_factor")
+RISK_WARNING_PARAMETERS = ("obstacle_scene", "closest_point_safety_distance", "starting_point_cartesian_range_scene",
+                           "use_controller_target_velocities")
+RISK_CHECK_CURRENT_STATE, RISK_CHECK_NEXT_STATE_KINEMATIC_FORECASTING, RISK_CHECK_NEXT_STATE_FULL_FORECASTING = 0, 1, 2   # base.py:73-77
+
+
+def resolve_risk_config(config, trained_networks_dir=None):
+    """``risk_config`` / ``risk_config_dir`` of an env_config -> (env_config with the backup policy's scene parameters put in, risk
+    description or None).  Follows SafeMotionsBase._load_risk_config (safe_motions_base.py:502-585): ``risk_config.json`` (plain
+    JSON: ``observation_size``, ``action_size`` - null for a network that rates states -, ``checkpoint``) is read from the directory
+    (as given, else under ``trained_networks_dir``, the reference's ``safemotions/trained_networks``); the ``params.json`` beside
+    the backup policy's checkpoint directory supplies the scene the two networks were trained in, overrides RISK_OVERWRITE_PARAMETERS,
+    must agree on RISK_ERROR_PARAMETERS and warns about RISK_WARNING_PARAMETERS.
+    ONLY these two JSON files are opened.  The checkpoint itself (a pickle) and the risk network's SavedModel are never read: the
+    env built from such a config refuses to step until ``set_risk_networks`` has been given the weights as arrays
+    (policy.Mlp.from_npz, INTEGRATION.md)."""
+    import json
+    import warnings
+    config = dict(config)
+    risk = config.pop("risk_config", None)
+    risk_dir = config.pop("risk_config_dir", None)
+    if risk is None and risk_dir is None:
+        for k in ("risk_state_config", "risk_threshold"):        # without a risk network the reference ignores them too
+            config.pop(k, None)
+        return config, None
+    base = trained_networks_dir or os.environ.get("SMR_TRAINED_NETWORKS_DIR")
+    if risk is None:
+        if not os.path.isdir(risk_dir) and base:
+            risk_dir = os.path.join(base, risk_dir)
+        path = os.path.join(risk_dir, "risk_config.json")
+        if not os.path.isfile(path):
+            raise FileNotFoundError("Could not find config file {}.".format(path))                       # base.py:510-511
+        with open(path, "r") as f:
+            risk = json.load(f)
+    risk = dict(risk)
+    checkpoint = risk["checkpoint"]
+    if not os.path.isfile(checkpoint) and base:
+        checkpoint = os.path.join(base, checkpoint)
+    params = os.path.join(os.path.dirname(os.path.dirname(checkpoint)), "params.json")
+    if not os.path.isfile(params):
+        raise FileNotFoundError("Could not find checkpoint params file {}.".format(params))             # base.py:520-522
+    with open(params, "r") as f:
+        backup_env_config = json.load(f)["env_config"]
+    for k in RISK_OVERWRITE_PARAMETERS:
+        if k in backup_env_config:
+            config[k] = backup_env_config[k]
+    for k in RISK_ERROR_PARAMETERS:
+        if k in backup_env_config and _cfg(config, k) != backup_env_config[k]:
+            raise ValueError("The {} parameter of the risk network does not match with the environment (risk: {} / env: {}).".format(
+                k, backup_env_config[k], _cfg(config, k)))                                               # base.py:548-558
+    for k in RISK_WARNING_PARAMETERS:
+        if k in backup_env_config and k in config and config[k] != backup_env_config[k]:
+            warnings.warn("The {} parameter of the risk network does not match with the environment (risk: {} / env: {}).".format(
+                k, backup_env_config[k], config[k]))
+    state_config = config.pop("risk_state_config", None)
+    state_config = RISK_CHECK_CURRENT_STATE if state_config is None else int(state_config)
+    if risk.get("action_size") is None and state_config not in (RISK_CHECK_CURRENT_STATE, RISK_CHECK_NEXT_STATE_KINEMATIC_FORECASTING,
+                                                                 RISK_CHECK_NEXT_STATE_FULL_FORECASTING):
+        raise NotImplementedError("risk_state_config=%d: the modes that step a background copy of the env (3, 4) are outside the batched hot path" % state_config)
+    if risk.get("action_size") is not None and int(risk["action_size"]) != NJ:
+        raise ValueError("The action size of the risk network does not match with num_manip_joints")    # base.py:611-614
+    threshold = config.pop("risk_threshold", None)
+    for k, ok in (("risk_ignore_estimation_probability", (None, 0, 0.0)), ("risk_use_backup_agent_for_initial_backup_trajectory_only", (None, False)),
+                  ("risk_state_deterministic_backup_trajectory", (None, False))):
+        if config.get(k) not in ok:
+            raise NotImplementedError("env_config[%r]=%r is outside the batched hot path" % (k, config[k]))
+        config.pop(k, None)
+    for k in ("risk_state_backup_trajectory_steps", "risk_state_initial_backup_trajectory_steps", "risk_ground_truth_episodes_per_file"):
+        config.pop(k, None)                                  # only read by the initial-backup-trajectory / ground-truth code (out of scope)
+    return config, dict(observation_size=int(risk["observation_size"]), action_size=risk.get("action_size"), checkpoint=risk["checkpoint"],
+                        risk_threshold=0.05 if threshold is None else float(threshold), risk_state_config=state_config)   # base.py:222-223
 
 
 def _cfg(config, key):
@@ -428,6 +512,7 @@ class SceneBundle:
         self.pieces = []
         self.verts = None
         self.env_config = None
+        self.risk = None
 
     def pointer(self):
         return C.byref(self.struct)
@@ -456,7 +541,7 @@ def _link_mask(names):
 
 
 def build_scene(env_config, collision_checks_per_step=None, contact_distance=BULLET_CONTACT_BREAKING_THRESHOLD,
-                auto_reset=True, assets_path=_DATA):
+                auto_reset=True, assets_path=_DATA, trained_networks_dir=None):
     """Build the scene description for ``Env(**env_config)`` of the reference (train.py:620).
 
     collision_checks_per_step: N samples of the moving-obstacle contact latch per step.  Default: the reference's
@@ -467,11 +552,12 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     ``collision_check_time`` does NOT drive N: in the reference it only sets the sampling of the braking-trajectory
     checker (ctlp.py:99-103,3167-3185), which is where this library uses it too (``check_braking_trajectory_collisions``).
     """
-    config = dict(env_config)
+    config, risk = resolve_risk_config(env_config, trained_networks_dir)
     validate_env_config(config)
     assets = np.load(assets_path)
     b = SceneBundle()
     b.env_config = config
+    b.risk = risk                                    # what the env_config's risk keys asked for (resolve_risk_config), or None
     s = b.struct
     s.version = SCENE_VERSION
 

@@ -430,6 +430,29 @@ def test_ball_machine_components_against_oracle(built):
 
 
 @pytest.mark.gpu
+def test_start_position_sampling_attempts_column(built):
+    """_starting_point_sampling_attempts (ctlp.py:1480-1488 -> obstacles_starting_point_sampling_attempts, ctlp.py:1154): the info column
+    of an episode carries the number of candidates its start position took - the oracle's count on the same Philox streams where the
+    two accepted the same candidate, >= 1 everywhere, with the rejection rate of the README scene (about one candidate in ten)."""
+    import torch
+    from oracle.oracle import OracleEnv
+    B = 4096
+    env = _bm_env(B, seed=21)
+    env.reset()
+    ora = OracleEnv(env.scene, B, seed=21, num_threads=16)
+    ora.reset()
+    st, ost = env.get_state(), ora.get_state()
+    same = np.abs(ost["q"] - st["q"]).max(axis=1) < 1e-3
+    act = np.zeros((B, 7), np.float32)
+    _, _, _, info = env.step(torch.from_numpy(act).cuda())
+    _, _, _, _, o_info = ora.step(act.astype(np.float64))
+    att = info["values"][:, 14].cpu().numpy()
+    assert same.mean() > 0.97 and np.array_equal(att[same], o_info[same, 14]) and (att >= 1).all()
+    assert 1.02 < att.mean() < 1.6 and att.max() >= 3
+    env.close()
+
+
+@pytest.mark.gpu
 def test_self_pair_bound_tables_are_lower_bounds(built):
     """The bound tables of the near self-collision pairs (csrc/smr_device.h "Self pairs: bound tables"): for random and for
     near-collision configurations the bound never exceeds the oracle's float64 distance of the literal query (ctlp.py:3345-3372),
