@@ -134,7 +134,7 @@ def test_braking_layer_reward_terms(built):
         act = rng.uniform(-1, 1, (B, 7))
         _, r0, d0, _, i0 = plain.step(act)
         _, r1, d1, _, i1 = pun.step(act)
-        assert np.array_equal(i0[:, 8], i1[:, 8]) and np.array_equal(d0, d1) and not i0[:, 12:].any()      # the terms do not touch the dynamics
+        assert np.array_equal(i0[:, 8], i1[:, 8]) and np.array_equal(d0, d1) and not i0[:, 12:14].any()      # the terms do not touch the dynamics
         braked, end_pun, bt_pun = i1[:, 8], i1[:, 12], i1[:, 13]
         assert ((end_pun >= 0) & (end_pun <= 1) & (bt_pun >= 0) & (bt_pun <= 1)).all()
         assert np.allclose(r1, r0 - braked * 1.0 - end_pun * 0.5 - bt_pun * 1.0, atol=1e-9)
