@@ -76,7 +76,11 @@ extern "C" {
 #define SMR_K_SPAWN 4     /* A10: a new ball for the envs whose ball was retired         */
 #define SMR_K_BRAKE 5     /* braking-trajectory safety layer (adapt_action, ctlp.py:3055-3153) */
 #define SMR_K_RISK 6      /* risk network + backup policy (actions.py:303-340, base.py:1498-1502,1598-1603) */
-#define SMR_K_COUNT 7
+/* the kernels of the collide stage where it runs as pair jobs (planet scenes): their times are part of SMR_K_COLLIDE's as well */
+#define SMR_K_KEYS 7      /* (env, body) lanes: frames, table bounds / shortcut, candidate keys, sweep of the contact samples */
+#define SMR_K_ENUMERATE 8 /* the pairs / contact samples that can matter -> job list */
+#define SMR_K_JOBS 9      /* one GJK run per job */
+#define SMR_K_COUNT 10
 
 typedef struct smr_env smr_env_t;   /* opaque */
 

@@ -2643,12 +2643,15 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         if (env->hscene.planets_jobs) {
             const int env_blocks = (B + 255) / 256;
             const dim3 egrid(env_blocks + (env->N > 1 ? 4 * env->job_blocks : 0));      // behind the env blocks: a fixed grid striding over the items
-            if (self) {
-                hipLaunchKernelGGL((keys_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-                hipLaunchKernelGGL((enumerate_kernel<true>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
-            } else {
-                hipLaunchKernelGGL((keys_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-                hipLaunchKernelGGL((enumerate_kernel<false>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
+            {
+                LaunchTimer tk(env, SMR_K_KEYS);
+                if (self) hipLaunchKernelGGL((keys_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+                else hipLaunchKernelGGL((keys_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+            }
+            {
+                LaunchTimer te(env, SMR_K_ENUMERATE);
+                if (self) hipLaunchKernelGGL((enumerate_kernel<true>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
+                else hipLaunchKernelGGL((enumerate_kernel<false>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
             }
         } else if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
@@ -2656,6 +2659,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         if (env->hscene.jobs_on) {
             if (env->hscene.planets_jobs) {
+                LaunchTimer tj(env, SMR_K_JOBS);
                 if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
                 else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
             }

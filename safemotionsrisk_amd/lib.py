@@ -19,8 +19,8 @@ INCLUDE = os.path.join(os.path.dirname(_PKG), "include")
 
 ABI_VERSION = 9
 INFO_N = 15
-K_COUNT = 7
-KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn", "brake", "risk")
+K_COUNT = 10
+KERNEL_NAMES = ("plan", "collide", "finish", "reset", "spawn", "brake", "risk", "keys", "enumerate", "jobs")
 
 #: every symbol include/safemotions_hip.h declares
 EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "smr_last_error", "smr_num_envs",
