@@ -295,7 +295,7 @@ def main():
         # wave-slot occupancy of the dominant kernel: the wavefronts' summed life time against (kernel time x wave slots of the chip)
         slot = None
         if pmc is not None and "SQ_WAVE_CYCLES" in kk and kk.get("SQ_WAVES"):
-            waves_per_simd = {"collide": 4, "brake": 4, "jobs": 4}.get(dominant, 2)
+            waves_per_simd = {"collide": 4, "brake": 4, "jobs": 2}.get(dominant, 2)
             slots = N_SIMD * waves_per_simd
             # SQ_WAVE_CYCLES counts in units of 4 cycles (MI355X_MICROARCH.md, SQ counters "quad-cycles")
             mean_wave_us = kk["SQ_WAVE_CYCLES"] * 4.0 / kk["SQ_WAVES"] / CLOCK_HZ * 1e6

@@ -459,6 +459,9 @@ __global__ __launch_bounds__(256) void self_bounds_kernel(const DScene *__restri
     push_jobs(st, e, bodies, masks, S.checks_per_step, kJobSelf);
 }
 
+// (128 registers: the kernel needs 125.)  The grid is ONE 512-lane block per CU - two wavefronts per SIMD: the runs are latency chains,
+// and with two blocks per CU every wavefront took longer than the kernel gained from the extra lanes (65 536 envs: 0.250 -> 0.235 ms,
+// one contact sample: 0.413 -> 0.398 ms, 4096 envs: 0.146 -> 0.131 ms; the reaching task liked two blocks better by 2 %; measured)
 #ifndef SMR_JOB_WAVES
 #define SMR_JOB_WAVES 4
 #endif
@@ -1052,7 +1055,9 @@ __global__ __launch_bounds__(256) void brake_plan_kernel(const DScene *__restric
 #ifndef SMR_BRAKE_WAVES
 #define SMR_BRAKE_WAVES 4        // wavefronts per SIMD (512 / SMR_BRAKE_WAVES registers each): the blocks are short and many
 #endif
-template <bool SELF>
+// BT: punish_braking_trajectory_min_distance - the smallest distance of the walk is tracked as well (an instantiation of its own: the
+// extra state cost the plain check a quarter of its speed in spilled registers)
+template <bool SELF, bool BT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_WAVES, SMR_BRAKE_WAVES))) void brake_check_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = 256;
@@ -1098,7 +1103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
     const float thr = S.brake_safety;
     // with punish_braking_trajectory_min_distance the smallest distance of the walk is asked for below bt_thr as well: a sample is
     // only skipped when its distance is proven beyond that (get_braking_trajectory_punishment, ctlp.py:2393-2415)
-    const float thr_skip = S.punish_bt_min ? fmaxf(thr, S.bt_thr) : thr;
+    const float thr_skip = BT ? fmaxf(thr, S.bt_thr) : thr;
     float dmin = 3.0e38f;
     float margin = -1.f;                                 // clearance beyond the safety distance found at q_ref (< 0: nothing evaluated yet)
     // consecutive evaluations look at nearly the same configuration: each GJK run starts in the direction the last one ended with
@@ -1130,10 +1135,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
                 for (int sp = 0; sp < S.n_static; ++sp)
                     d = fminf(d, piece_distance<true>(S, S.static_piece[sp], T, LP, hull, T, S.static_max, thr, S.n_static == 1 ? &warm : nullptr));
             }
-            dmin = fminf(dmin, d);
+            if (BT) dmin = fminf(dmin, d);
             if (d < thr) {                                                                // ctlp.py:3307-3312,3364-3368; several lanes of an env may write the same 1
                 st.braked[e] = 1;
-                if (S.punish_bt_min) atomicMin(&st.bt_min[e], dist_bits(dmin));
+                if (BT) atomicMin(&st.bt_min[e], dist_bits(dmin));
                 return;
             }
             margin = d - thr_skip - 1e-5f;
@@ -1147,7 +1152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
             if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
         }
     }
-    if (S.punish_bt_min && dmin <= S.static_max) atomicMin(&st.bt_min[e], dist_bits(dmin));
+    if (BT && dmin <= S.static_max) atomicMin(&st.bt_min[e], dist_bits(dmin));
 }
 
 // adapt_action (ctlp.py:3055-3153, actions.py:340-361): where the braking trajectory of the planned end acceleration is not collision free
@@ -1850,33 +1855,39 @@ __global__ void risk_input_kernel(const DScene *__restrict__ Sp, DState st, cons
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ];
 #pragma unroll
     for (int j = 0; j < SMR_NJ; ++j) { q[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; a[j] = st.a[j * B + e]; }
-    const bool forecast = mode == SMR_RISK_NEXT_KINEMATIC || mode == SMR_RISK_NEXT_FULL;
-    for (int pass = 0; pass < 2; ++pass) {               // 0: the backup policy's row (the current state), 1: the risk network's
-        float *row = pass == 0 ? xb + (size_t)e * ldxb : x + (size_t)e * ldx;
-        const bool next = pass == 1 && forecast, next_all = pass == 1 && mode == SMR_RISK_NEXT_FULL;
+    const bool forecast = mode == SMR_RISK_NEXT_KINEMATIC || mode == SMR_RISK_NEXT_FULL, next_all = mode == SMR_RISK_NEXT_FULL;
+    float *rb = xb + (size_t)e * ldxb, *rx = x + (size_t)e * ldx;
+    // the backup policy's row: the current state; the risk network's row is the same unless it forecasts
 #pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) {
-            float qj = q[j], vj = v[j], aj = a[j];
-            if (next) {
-                const float a1 = st.a1[j * B + e];
-                qj = interp_pos(q[j], v[j], a[j], a1, S.dt, S.dt); vj = interp_vel(v[j], a[j], a1, S.dt, S.dt); aj = a1;
-            }
-            row[j] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (qj - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
-            row[SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, vj / S.vel_max[j]));
-            row[2 * SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, aj / S.acc_max[j]));
+    for (int j = 0; j < SMR_NJ; ++j) {
+        const float pj = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (q[j] - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
+        const float vj = fminf(1.f, fmaxf(-1.f, v[j] / S.vel_max[j])), aj = fminf(1.f, fmaxf(-1.f, a[j] / S.acc_max[j]));
+        rb[j] = pj; rb[SMR_NJ + j] = vj; rb[2 * SMR_NJ + j] = aj;
+        if (!forecast) { rx[j] = pj; rx[SMR_NJ + j] = vj; rx[2 * SMR_NJ + j] = aj; }
+        else {
+            const float a1 = st.a1[j * B + e];
+            const float qn = interp_pos(q[j], v[j], a[j], a1, S.dt, S.dt), vn = interp_vel(v[j], a[j], a1, S.dt, S.dt);
+            rx[j] = fminf(1.f, fmaxf(-1.f, -1.f + 2.f * (qn - S.pos_lo[j]) / (S.pos_hi[j] - S.pos_lo[j])));
+            rx[SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, vn / S.vel_max[j])); rx[2 * SMR_NJ + j] = fminf(1.f, fmaxf(-1.f, a1 / S.acc_max[j]));
         }
-        int o = 3 * SMR_NJ;
-        if (S.use_ball) { write_ball_observation(S, load_ball(st, B, e), st.ball_i[e] + (next_all ? S.updates_per_step : 0), row + o); o += 6; }     // moving object, then planets: obs.py:424-427
-        int idx[SMR_MAX_PLANETS] = {st.planet_idx[e], st.planet_idx[B + e]};
-        if (next_all)
-#pragma unroll
-            for (int p = 0; p < SMR_MAX_PLANETS; ++p) if (p < S.n_planets) idx[p] = (idx[p] + S.updates_per_step) % S.planet[p].n_orbit;
-        write_planet_observation(S, idx, row + o);
-        o += S.obs_num_planets * S.obs_planet_size;
-        if (pass == 1 && mode == SMR_RISK_STATE_ACTION)
-#pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) row[o + j] = actions[(size_t)e * SMR_NJ + j];
     }
+    int o = 3 * SMR_NJ;
+    const int rest = (S.use_ball ? 6 : 0) + S.obs_num_planets * S.obs_planet_size;
+    if (S.use_ball) write_ball_observation(S, load_ball(st, B, e), st.ball_i[e], rb + o);                  // moving object, then planets: obs.py:424-427
+    const int idx[SMR_MAX_PLANETS] = {st.planet_idx[e], st.planet_idx[B + e]};
+    write_planet_observation(S, idx, rb + o + (S.use_ball ? 6 : 0));
+    if (!next_all) for (int c = 0; c < rest; ++c) rx[o + c] = rb[o + c];
+    else {
+        if (S.use_ball) write_ball_observation(S, load_ball(st, B, e), st.ball_i[e] + S.updates_per_step, rx + o);
+        int idn[SMR_MAX_PLANETS] = {idx[0], idx[1]};
+#pragma unroll
+        for (int p = 0; p < SMR_MAX_PLANETS; ++p) if (p < S.n_planets) idn[p] = (idn[p] + S.updates_per_step) % S.planet[p].n_orbit;
+        write_planet_observation(S, idn, rx + o + (S.use_ball ? 6 : 0));
+    }
+    o += rest;
+    if (mode == SMR_RISK_STATE_ACTION)
+#pragma unroll
+        for (int j = 0; j < SMR_NJ; ++j) rx[o + j] = actions[(size_t)e * SMR_NJ + j];
 }
 
 __global__ void risk_apply_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions, const float *__restrict__ risk,
@@ -1930,7 +1941,7 @@ struct smr_env {
     int risk_mode = SMR_RISK_STATE_ACTION;            // the mode in force (state-action when the network takes the action)
     int *risky_buf = nullptr;
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
-    int job_blocks = 0;               // their persistent grid: two 512-lane blocks per CU
+    int job_blocks = 0;               // their persistent grid: one 512-lane block per CU
     bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
     DState st;
@@ -2271,7 +2282,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4) || hipMemset(st.job_next, 0, 4) || hipMemset(st.overflow_env, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
-        env->job_blocks = 2 * std::max(prop.multiProcessorCount, 1);
+        env->job_blocks = std::max(prop.multiProcessorCount, 1);
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         env->self_job_blocks = std::max(8, std::min(env->job_blocks, (int)((B + 1023) / 1024)));      // ~40 jobs per wavefront
     }
@@ -2620,8 +2631,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         LaunchTimer t(env, SMR_K_BRAKE);
         hipLaunchKernelGGL(brake_plan_kernel, dim3(((size_t)B * 8 + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st);
         const dim3 grid((B + 255) / 256, env->hscene.n_bodies + env->hscene.n_self_pairs);
-        if (env->hscene.n_self_pairs > 0) hipLaunchKernelGGL((brake_check_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL((brake_check_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+        const bool bt = env->hscene.punish_bt_min != 0;
+        if (env->hscene.n_self_pairs > 0) {
+            if (bt) hipLaunchKernelGGL((brake_check_kernel<true, true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+            else hipLaunchKernelGGL((brake_check_kernel<true, false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+        } else if (bt) hipLaunchKernelGGL((brake_check_kernel<false, true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((brake_check_kernel<false, false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
         hipLaunchKernelGGL(brake_apply_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st);
         SMR_HIP(hipGetLastError());
     }
@@ -2642,7 +2657,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         }
         if (env->hscene.planets_jobs) {
             const int env_blocks = (B + 255) / 256;
-            const dim3 egrid(env_blocks + (env->N > 1 ? 4 * env->job_blocks : 0));      // behind the env blocks: a fixed grid striding over the items
+            const dim3 egrid(env_blocks + (env->N > 1 ? 8 * env->job_blocks : 0));      // behind the env blocks: a fixed grid (eight 256-lane blocks per CU) striding over the items
             {
                 LaunchTimer tk(env, SMR_K_KEYS);
                 if (self) hipLaunchKernelGGL((keys_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
