@@ -93,6 +93,9 @@ struct DScene {
     int body_parent[SMR_MAX_BODIES], ee_body;
     float body_xyz[SMR_MAX_BODIES][3], body_rot[SMR_MAX_BODIES][9];   // parent link frame -> body frame
     int n_self_pairs, self_pair[SMR_MAX_SELF_PAIRS][2];               // (body, partner body | -(world piece + 1))
+    // the reset-side kernels deal the pairs to the lanes of a group by PARTNER: lane g (= chain link g) tests the pairs whose partner is
+    // link g - its own frame and piece record are at hand -, pairs with a world-fixed partner go to the lanes with the fewest
+    int pair_lane[8][4], pair_lane_max;                                // pair indices (-1: none), and the longest list
     const uint32_t *body_pool;            // image of the reset-side kernels' LDS pool (body_pool_tables)
     int body_pool_dwords;
     // pair-job path of the collide stage ("Pair jobs" below): on / off, and the LDS pool of its first / jobs kernels - like body_pool,
@@ -1249,15 +1252,21 @@ __device__ inline float self_tab_bound(const DScene &S, int i, float q4, float q
 template <bool LANE = false, bool TABLE = true, class HB>
 __device__ inline float self_pair_distance(const DScene &S, int i, const float q[SMR_NJ], const DPiece &LP, const HB &hull,
                                            const Xf &T, float cutoff, float stop_below, const BodyPool *bodies = nullptr, const Trig *trig = nullptr,
-                                           F3 *warm = nullptr, float *lower = nullptr) {
+                                           F3 *warm = nullptr, float *lower = nullptr, const Xf *partner_frame = nullptr) {
+    // partner_frame (the reset-side kernels: the lane that tests the pair IS the partner link's lane and has its frame already)
     const int partner = S.self_pair[i][1];
     const int pa = partner >= 0 ? S.link_piece[partner] : -(partner + 1);
-    const DPiece A = LANE ? load_piece_lane(S.pieces, pa) : load_piece(S.pieces, pa);
+    // (the partner link's record: from the LDS pool where there is one - a per-lane read of 36 dwords from global memory otherwise)
+    const DPiece A = (LANE && bodies && partner >= 0) ? bodies->piece(partner) : LANE ? load_piece_lane(S.pieces, pa) : load_piece(S.pieces, pa);
     const float margins = A.margin + LP.margin;
     const F3 cb = apply(T, F3{LP.cx, LP.cy, LP.cz});
     const auto sb = [&](F3 d, int &hint, bool first) { return apply(T, hull.support(rot_t(T, d), hint, first)); };
     if (partner >= 0) {
-        const Xf XA = trig ? body_frame_sc(S, *trig, partner) : body_frame(S, q, partner);
+        if (TABLE) {                                         // two bytes that settle nine in ten of the near pairs: before any frame
+            const float lbt = trig ? self_tab_bound(S, i, trig->q_last[0], trig->q_last[1], trig->q_last[2]) : self_tab_bound(S, i, q[4], q[5], q[6]);
+            if (lbt > cutoff) return lbt;
+        }
+        const Xf XA = partner_frame ? *partner_frame : trig ? body_frame_sc(S, *trig, partner) : body_frame(S, q, partner);
         const F3 d = apply(XA, F3{A.cx, A.cy, A.cz}) - cb;
         float lb = sqrtf(dot(d, d)) - A.radius - LP.radius - margins;
         if (lb > cutoff) return lb;
@@ -1265,10 +1274,6 @@ __device__ inline float self_pair_distance(const DScene &S, int i, const float q
             const F3 a0 = apply(XA, F3{A.cap_a[0], A.cap_a[1], A.cap_a[2]}), a1 = apply(XA, F3{A.cap_b[0], A.cap_b[1], A.cap_b[2]});
             const F3 b0 = apply(T, F3{LP.cap_a[0], LP.cap_a[1], LP.cap_a[2]}), b1 = apply(T, F3{LP.cap_b[0], LP.cap_b[1], LP.cap_b[2]});
             lb = sqrtf(seg_seg_dist2(a0, a1, b0, b1)) * 0.99999f - 1e-6f - A.cap_r - LP.cap_r - margins;
-            if (lb > cutoff) return lb;
-        }
-        if (TABLE) {
-            lb = trig ? self_tab_bound(S, i, trig->q_last[0], trig->q_last[1], trig->q_last[2]) : self_tab_bound(S, i, q[4], q[5], q[6]);
             if (lb > cutoff) return lb;
         }
         if (bodies) {

@@ -935,12 +935,17 @@ __device__ inline bool body_clear(const DScene &S, const BodyPool &BP, int b, co
     return ok;
 }
 
-// the self-collision pairs dealt round-robin to the lanes of a group: lane g tests pairs g, g + 8, ... (ctlp.py:2170-2208, 1605-1619)
+// the self-collision pairs dealt to the lanes of a group by partner link: lane g tests the pairs whose partner is link g, with its own
+// frame (DScene::pair_lane; ctlp.py:2170-2208, 1605-1619)
 __device__ inline bool lane_self_pairs_clear(const DScene &S, const BodyPool &BP, const Group &G, const Trig &P, float thr_self) {
     bool ok = true;
-    for (int i = G.g; i < S.n_self_pairs; i += 8) {
+    const Xf Tg = body_frame_sc(S, P, G.g);              // this lane's link (the partner of its pairs)
+    for (int k = 0; k < S.pair_lane_max; ++k) {
+        const int i = S.pair_lane[G.g][k];
+        if (i < 0) continue;
         const int a = S.self_pair[i][0];
-        float d = self_pair_distance<true>(S, i, nullptr, BP.piece(a), BP.hull(a), body_frame_sc(S, P, a), thr_self + 0.005f, 0.f, &BP, &P);
+        float d = self_pair_distance<true>(S, i, nullptr, BP.piece(a), BP.hull(a), body_frame_sc(S, P, a), thr_self + 0.005f, 0.f, &BP, &P, nullptr, nullptr,
+                                           S.self_pair[i][1] == G.g ? &Tg : nullptr);
         if (d <= thr_self + 0.005f && d < thr_self) ok = false;
     }
     return ok;
@@ -2069,6 +2074,23 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed,
             const int chain[SMR_NLINK] = {5, 6, 4, 7, 3, 2, 1, 0};
             for (int i = 0; i < SMR_NLINK; ++i) if ((((d.moving_mask >> chain[i]) & 1u) != 0) == want_moving) d.body_order[n++] = chain[i];
         }
+    }
+    {   // the pairs by partner lane (reset-side kernels)
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int g = 0; g < 8; ++g) for (int k = 0; k < 4; ++k) d.pair_lane[g][k] = -1;
+        bool fits = true;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int i = 0; i < d.n_self_pairs; ++i) {
+                const int partner = d.self_pair[i][1];
+                if ((partner >= 0) != (pass == 0)) continue;
+                int g = partner;
+                if (partner < 0) { g = 0; for (int c = 1; c < 8; ++c) if (cnt[c] < cnt[g]) g = c; }      // a world-fixed partner: the emptiest lane
+                if (cnt[g] >= 4) { fits = false; continue; }
+                d.pair_lane[g][cnt[g]++] = i;
+            }
+        if (!fits) { env->err = "more than four self-collision pairs share one partner link"; return SMR_E_INVALID; }
+        d.pair_lane_max = 0;
+        for (int g = 0; g < 8; ++g) d.pair_lane_max = std::max(d.pair_lane_max, cnt[g]);
     }
     {   // ... and of the self-collision pairs: highest partner link (nearest to the mounted bodies) first, the world-fixed piece last
         std::vector<int> order(d.n_self_pairs);
