@@ -296,15 +296,17 @@ def main():
         slot = None
         if pmc is not None and "SQ_WAVE_CYCLES" in kk and kk.get("SQ_WAVES"):
             waves_per_simd = {"collide": 4, "brake": 4, "jobs": 2}.get(dominant, 2)
-            slots = N_SIMD * waves_per_simd
+            # the jobs kernel is a persistent grid (one block of four wavefronts per CU): the wavefronts it launches ARE its slots
+            slots = min(N_SIMD * waves_per_simd, int(kk["SQ_WAVES"])) if dominant == "jobs" else N_SIMD * waves_per_simd
             # SQ_WAVE_CYCLES counts in units of 4 cycles (MI355X_MICROARCH.md, SQ counters "quad-cycles")
             mean_wave_us = kk["SQ_WAVE_CYCLES"] * 4.0 / kk["SQ_WAVES"] / CLOCK_HZ * 1e6
             packed_ms = kk["SQ_WAVES"] * mean_wave_us * 1e-3 / slots
             slot = {"waves_per_launch": kk["SQ_WAVES"], "mean_wave_life_us": mean_wave_us, "wave_slots": slots, "packed_ms": packed_ms,
                     "slot_utilisation": packed_ms / dom_ms,
                     "note": "SQ_WAVE_CYCLES x 4 / SQ_WAVES = mean life of a wavefront; packed_ms = all wavefronts' life time spread evenly over the "
-                            "%d wave slots (%d per SIMD at this kernel's register budget); slot_utilisation = packed_ms / measured kernel time: what "
-                            "is lost to the tail of the block schedule (the kernel is as long as its slowest block)" % (slots, waves_per_simd)}
+                            "%d wave slots (at most %d per SIMD at this kernel's register budget; a persistent grid holds as many as it launched); "
+                            "slot_utilisation = packed_ms / measured kernel time: what is lost to the tail of the schedule (the kernel is as long "
+                            "as its slowest wavefront)" % (slots, waves_per_simd)}
         label = "env-steps/sec at batch 65 536, 7-DoF space scene" if (args.config == "space" and B == 65536) else \
                 "env-steps/sec, %s, %d envs/GPU" % (args.config, B)
         out = {
