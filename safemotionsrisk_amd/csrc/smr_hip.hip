@@ -340,26 +340,30 @@ __global__ __launch_bounds__(256) void keys_kernel(const DScene *__restrict__ Sp
             st.env_best[e] = 1u;                             // some body of the env has a candidate
             if (r.ub <= S.moving_max) atomicMin(&st.env_min[e], dist_bits(r.ub));
         }
-        if (r.static_pending) {                              // the table's GJK run (one lane in a hundred): a job of its own
-            const int slot = atomicAdd(st.job_count, 1);
-            if (slot < st.job_cap) st.jobs[slot] = job_word(e, l, S.auto_static, N, kJobStaticEnd);
-            else st.overflow_env[e] = 1;
-        }
     }
-    if (N > 1) {
-        // the samples k_first .. k_need of every lane go to the global item list, one atomic per wavefront
-        const int n = (valid && r.k_need >= r.k_first) ? r.k_need - r.k_first + 1 : 0;
-        if (__any(n > 0)) {
-            const int lane = (int)__lane_id();
-            int incl = n;
+    // The table's GJK run (one lane in a hundred) becomes a job of its own, the samples k_first .. k_need of every lane go to the global
+    // item list (one atomic per wavefront).  Both counters are asked before either answer is used: an atomic that returns a value is a
+    // round trip of ~10 us to the memory side, and two in a row held every second wavefront's slot for twice that.
+    const bool pending = valid && r.static_pending;
+    int slot = 0;
+    if (pending) slot = atomicAdd(st.job_count, 1);
+    const int n = (N > 1 && valid && r.k_need >= r.k_first) ? r.k_need - r.k_first + 1 : 0;
+    const bool items = __any(n > 0);
+    const int lane = (int)__lane_id();
+    int incl = n, base = 0;
+    if (items) {
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-            const int total = __shfl(incl, 63);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(st.item_count, total);
-            base = __shfl(base, 0);
-            for (int k = 0; k < n; ++k) st.items[(size_t)base + incl - n + k] = job_word(e, l, 0, r.k_first + k, kJobItem);
-        }
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        const int total = __shfl(incl, 63);
+        if (lane == 0) base = atomicAdd(st.item_count, total);
+    }
+    if (pending) {
+        if (slot < st.job_cap) st.jobs[slot] = job_word(e, l, S.auto_static, N, kJobStaticEnd);
+        else st.overflow_env[e] = 1;
+    }
+    if (items) {
+        base = __shfl(base, 0);
+        for (int k = 0; k < n; ++k) st.items[(size_t)base + incl - n + k] = job_word(e, l, 0, r.k_first + k, kJobItem);
     }
 }
 
@@ -391,11 +395,13 @@ __device__ __forceinline__ void job_flags(const DScene &S, const LaneInput &in, 
 }
 
 // the result of a settled job.  Atomic minima on the bits of non-negative floats and stores of 1: independent of the order of the jobs.
-__device__ __forceinline__ void job_result(const DScene &S, const DState &st, const Job &jb, bool mov, bool con, float d) {
+// seen: the env's minimum the job read when it started - a result that does not improve on it changes nothing and is not sent (the
+// atomics execute at the memory side, and a wavefront's next refill waits for every one it has in flight)
+__device__ __forceinline__ void job_result(const DScene &S, const DState &st, const Job &jb, bool mov, bool con, float d, float seen) {
     const int B = S.B;
     if (jb.kind == kJobStaticEnd) { if (d <= S.static_max) atomicMin(&st.env_dstatic[jb.env], dist_bits(d)); return; }
-    if (jb.kind == kJobSelf) { if (d < S.self_cut) atomicMin(&st.env_dself[jb.env], dist_bits(d)); return; }
-    if (mov && d <= S.moving_max) atomicMin(&st.env_min[jb.env], dist_bits(d));
+    if (jb.kind == kJobSelf) { if (d < S.self_cut && d < seen) atomicMin(&st.env_dself[jb.env], dist_bits(d)); return; }
+    if (mov && d <= S.moving_max && d < seen) atomicMin(&st.env_min[jb.env], dist_bits(d));
     if (con && d <= S.contact_dist) st.res[(size_t)jb.body * B + jb.env] = 1.f;
 }
 
@@ -533,35 +539,42 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
 }
 
 // jobs kernel: one lane per job of the list.  The wavefronts of the persistent grid draw their jobs from ONE stream (job_next):
-// whenever SMR_JOB_REFILL of a wavefront's lanes have settled their runs (or all have), it takes as many jobs as it has idle lanes
-// with one atomic, and the idle lanes set their new runs up while the others wait one setup; then every lane with a run advances it
-// by one GJK iteration per trip.  A wavefront that worked its jobs in chunks of 64 ran every chunk as long as its slowest run (a
-// third of the lane-trips were useful) and the kernel as long as the unluckiest wavefront's chunks; with the stream no lane waits
-// for more than one setup and the kernel ends within one run's length of the moment the stream runs dry.  The order in which the
-// jobs are worked does not matter: their results are minima and flags (job_result).
-#ifndef SMR_JOB_REFILL
-#define SMR_JOB_REFILL 64
-#endif
+// when all lanes of a wavefront have settled their runs it takes the next 64 jobs, the lanes set their runs up, then every lane
+// with a run advances it by one GJK iteration per trip.  The stream is what keeps the kernel short beside the reset-side kernels:
+// a block whose CU is held by two of their blocks starts hundreds of microseconds late, and with equal shares per wavefront
+// (no counter at all) the kernel waited for it - 0.52 ms instead of 0.22 (measured).  The order in which the jobs are worked does
+// not matter: their results are minima and flags (job_result).
+// What was measured on the way: refilling as soon as 16 / 32 lanes are idle (slower: a refill stalls the running lanes for a setup),
+// asking for the next chunk when 16 / 32 / 48 lanes have settled so that the counter's round trip runs beside the last trips
+// (slower the earlier it asks: the chunk then waits for the wavefront's longest run while other wavefronts are idle).
 template <bool SELF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
 #ifdef SMR_PROFILE_ROWS
     const unsigned long long pc0 = SMR_DEV_CLOCK();
-    unsigned long long pc_setup = 0, pc_trip = 0;
+    unsigned long long pc_setup = 0, pc_trip = 0, pc_atomic = 0, pc_loads = 0;
     int prof_trips = 0, prof_refills = 0, prof_maxit = 0;
 #endif
-    const JobTables JT = stage_job_tables(S);
+    const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
+    // An agent-scope atomic on the list counter is a round trip to the memory side of ~10 us, more when 2048 wavefronts ask at once
+    // (profile counters: 83 000 of a wavefront's 390 000 cycles at 65 536 envs went into 2.5 of them; a look at the counter before
+    // staging, to let late blocks leave, cost the kernel 4 %; a look before every read-modify-write 30 %).  So the first hand-out
+    // is taken per BLOCK and its round trip hides behind the staging; and when the first hand-outs cover the list nobody asks again.
+    // With fewer jobs than lanes (small batches) the wavefronts share them out thinly: every SIMD gets a few runs instead of a few
+    // CUs getting them all, and a wavefront's chain is the longest of eight runs, not of sixty-four.
+    const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
+    const int quota = min(64, max(8, (n_jobs + n_waves - 1) / n_waves));
+    __shared__ int first_base;
+    if (threadIdx.x == 0) first_base = atomicAdd(st.job_next, (int)(blockDim.x >> 6) * quota);
+    const JobTables JT = stage_job_tables(S);           // (ends with a barrier)
 #ifdef SMR_PROFILE_ROWS
     SMR_DEV_COUNT(26, SMR_DEV_CLOCK() - pc0);
 #endif
     const int lane = (int)__lane_id();
-    const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
-    bool active = false, mov = false, con = false, dry = false;
-    // when there are fewer jobs than lanes (small batches) the wavefronts share them out thinly: every SIMD gets a few runs instead of a
-    // few CUs getting them all, and a wavefront's chain is the longest of eight runs, not of sixty-four
-    const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
-    const int quota = min(64, max(8, (n_jobs + n_waves - 1) / n_waves));
+    bool active = false, mov = false, con = false, first = true;
+    bool dry = (long long)n_waves * quota >= (long long)n_jobs;              // (for every ask after the first hand-out)
     Job jb = {0, 0, 0, 0, 0};
+    float seen = 0.f;
     JobLane J;
     J.g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);               // defined state for the lanes that never get a job
     J.XA = Xf{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, F3{0.f, 0.f, 0.f}}; J.T = J.XA;
@@ -569,16 +582,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
-        if (!dry && (n_idle == 64 || (quota == 64 && n_idle >= SMR_JOB_REFILL))) {
+        if (n_idle == 64 && (first || !dry)) {
 #ifdef SMR_PROFILE_ROWS
             const unsigned long long t0 = SMR_DEV_CLOCK();
             ++prof_refills;
 #endif
-            const int take = min(n_idle, quota);
+            const int take = quota;
             int base = 0;
-            if (lane == 0) base = atomicAdd(st.job_next, take);
-            base = __builtin_amdgcn_readfirstlane(base);
-            dry = base + take >= n_jobs;                   // the stream is exhausted (for every wavefront that asks from now on)
+            if (first) { base = first_base + (int)(threadIdx.x >> 6) * quota; first = false; }
+            else {
+                if (lane == 0) base = atomicAdd(st.job_next, take);
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+            dry = dry || base + take >= n_jobs;                // the stream is exhausted (for every wavefront that asks from now on)
+#ifdef SMR_PROFILE_ROWS
+            const unsigned long long t0a = SMR_DEV_CLOCK();
+            pc_atomic += t0a - t0;
+#endif
             const int rank = __popcll(idle & ((1ull << lane) - 1ull)), j = base + rank;
             if (!active && rank < take && j < n_jobs) {
                 jb = job_unpack(st.jobs[j]);
@@ -586,8 +606,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
                 job_flags(S, in, jb.body, mov, con);
                 if (jb.kind == kJobItem) { mov = false; con = true; }
                 float cutoff, stop;
-                const unsigned *running = (SELF && jb.kind == kJobSelf) ? st.env_dself : st.env_min;      // the env's minimum so far prunes the run
-                job_limits(S, jb, mov, con, __uint_as_float(__hip_atomic_load(&running[jb.env], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)), cutoff, stop);
+                // the env's minimum so far prunes the run.  A plain load: a value another XCD has lowered since is still an upper bound,
+                // and the jobs of one env sit side by side in the list - they start together whatever the load returns
+                const unsigned *running = (SELF && jb.kind == kJobSelf) ? st.env_dself : st.env_min;
+                seen = __uint_as_float(running[jb.env]);
+                job_limits(S, jb, mov, con, seen, cutoff, stop);
+#ifdef SMR_PROFILE_ROWS
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t0b = SMR_DEV_CLOCK();
+                pc_loads += t0b - t0a;
+#endif
                 job_setup<SELF>(S, JT.BP, JT.pv, JT.pd, JT.cyl, in, st.frames, jb, cutoff, stop, J);
                 active = true;
             }
@@ -603,7 +631,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
         float d;
         if (active && job_trip<SELF>(J, d)) {
             active = false;
-            job_result(S, st, jb, mov, con, d);
+            job_result(S, st, jb, mov, con, d, seen);
 #ifdef SMR_PROFILE_ROWS
             prof_maxit = max(prof_maxit, J.g.it + 1);
 #endif
@@ -616,7 +644,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) prof_maxit = max(prof_maxit, __shfl_xor(prof_maxit, d));
     SMR_DEV_COUNT(27, pc_setup); SMR_DEV_COUNT(28, pc_trip); SMR_DEV_COUNT(29, prof_trips); SMR_DEV_MAX(30, prof_maxit);
-    SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc0); SMR_DEV_COUNT(25, prof_refills);
+    SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc0); SMR_DEV_COUNT(25, prof_refills); SMR_DEV_COUNT(19, pc_atomic); SMR_DEV_COUNT(20, pc_loads);
 #endif
 }
 
@@ -1947,6 +1975,7 @@ struct smr_env {
     int *risky_buf = nullptr;
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
     int job_blocks = 0;               // their persistent grid: one 512-lane block per CU
+    int item_blocks = 0;              // enumerate kernel: 256-lane blocks striding over the item list
     bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
     DState st;
@@ -2307,6 +2336,14 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         env->job_blocks = std::max(prop.multiProcessorCount, 1);
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         env->self_job_blocks = std::max(8, std::min(env->job_blocks, (int)((B + 1023) / 1024)));      // ~40 jobs per wavefront
+        // the item part of the enumerate grid: one round for the usual 1.2 items per (env, body) - every round of a wavefront ends with a
+        // round trip to the list counter (SMR_ITEM_BLOCKS: blocks per CU, A/B runs)
+        {
+            const int cu = std::max(prop.multiProcessorCount, 1);
+            const long long want = (3LL * (long long)B * NB / 2 + 255) / 256;
+            env->item_blocks = (int)std::min<long long>(16LL * cu, std::max<long long>(cu, want));
+            if (const char *v = getenv("SMR_ITEM_BLOCKS")) if (atoi(v) > 0) env->item_blocks = atoi(v) * cu;
+        }
     }
     if ((rc = dev_alloc(env, &st.tp, 5 * B)) || (rc = dev_alloc(env, &st.tp_count, B)) || (rc = dev_alloc(env, &st.tp_list, B)) ||
         (rc = dev_alloc(env, &st.tp_list_count, 1)) || (rc = dev_alloc(env, &st.error_flags, 1))) return fail(rc);
@@ -2672,14 +2709,14 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         // scene, by a launch of its own otherwise)
         const bool self_jobs_alone = pairs && !env->hscene.planets_jobs;      // no pair jobs to work them behind
         // (on a stream of their own beside the other distance kernels they finished sooner, but took from the staged refills what they
-        // gained: reaching task 94 -> 86 M env-steps/s, measured)
+        // gained: reaching task 94 -> 86 M env-steps/s; ball scene beside the collide kernel: 63.6 -> 51.8 M; both measured)
         if (pairs) {
             hipLaunchKernelGGL(self_bounds_kernel, dim3((B + 255) / 256, env->hscene.n_self_pairs), dim3(256), 0, env->stream, env->dscene, env->st);
             if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
         }
         if (env->hscene.planets_jobs) {
             const int env_blocks = (B + 255) / 256;
-            const dim3 egrid(env_blocks + (env->N > 1 ? 8 * env->job_blocks : 0));      // behind the env blocks: a fixed grid (eight 256-lane blocks per CU) striding over the items
+            const dim3 egrid(env_blocks + (env->N > 1 ? env->item_blocks : 0));      // behind the env blocks: a fixed grid striding over the items
             {
                 LaunchTimer tk(env, SMR_K_KEYS);
                 if (self) hipLaunchKernelGGL((keys_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);

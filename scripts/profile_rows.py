@@ -47,6 +47,7 @@ def main():
               38: "target point", 40: "job setup: frame of the body", 41: "job setup: piece record + hull pointers", 42: "job setup: planet pose, run start", 
               55: "first kernel: trips per chunk (count, not cycles)", 56: "first kernel: enumeration / job append", 57: "first kernel: item chunk",
               
+              51: "jobs kernel: refill atomic (part of setup)", 52: "jobs kernel: job word + state loads (part of setup, lanes of the first job in the wave)",
               57: "jobs kernel: refills per wavefront (count)",
               58: "jobs kernel: staging", 59: "jobs kernel: job setup (per wavefront)", 60: "jobs kernel: trips (per wavefront)", 61: "jobs kernel: trips per wavefront (count)",
               62: "jobs kernel: MAX iterations of one job", 63: "jobs kernel: MAX cycles of a wavefront"}
