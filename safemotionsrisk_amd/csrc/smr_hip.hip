@@ -277,8 +277,13 @@ __device__ __forceinline__ LaneInput load_lane_input(const DScene &S, const DSta
 // keys kernel: the collide kernel's grid and prologue (one lane per (env, body), the body's hull in LDS for the table shortcut),
 // but no GJK run against a moving piece: keys, best key, items and the pending table run go to the lists the enumerate / jobs
 // kernels work off
+// (128 registers: four blocks per CU - 1280 working blocks over 1024 slots instead of 768; space 0.129 -> 0.117 ms, space + ball machine
+// 0.193 -> 0.153 ms, reaching task 0.147 -> 0.124 ms; measured)
+#ifndef SMR_KEYS_WAVES
+#define SMR_KEYS_WAVES 4
+#endif
 template <bool SELF>
-__global__ __launch_bounds__(256) void keys_kernel(const DScene *__restrict__ Sp, DState st) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_KEYS_WAVES, SMR_KEYS_WAVES))) void keys_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = 256;
     const int l = S.body_order[(int)blockIdx.y];
@@ -2737,6 +2742,8 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
                 if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
                 else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
             }
+            // (beside the jobs kernel on a stream of its own - its flags are final once the lists are written, its results commute with
+            // the jobs' - the step got slower: space 115 -> 109 M, reaching task 92 -> 78 M env-steps/s, measured)
             hipLaunchKernelGGL(overflow_kernel, dim3((B + 63) / 64), dim3(64), 0, env->stream, env->dscene, env->st);
         }
     }
