@@ -990,9 +990,22 @@ __device__ inline bool lane_self_pairs_clear(const DScene &S, const BodyPool &BP
 template <bool EXTRA>
 __device__ inline bool group_table_free(const DScene &S, const BodyPool &BP, const Group &G, const Trig &P, float thr, float thr_self) {
     bool ok = true;
+#ifdef SMR_PROFILE_ROWS
+    const unsigned long long c0 = SMR_DEV_CLOCK();
+#endif
     for (int b = G.g; b < (EXTRA ? S.n_bodies : SMR_NLINK); b += 8) ok = ok && body_clear(S, BP, b, body_frame_sc(S, P, b), thr);
+#ifdef SMR_PROFILE_ROWS
+    const unsigned long long c1 = SMR_DEV_CLOCK();
+    SMR_DEV_COUNT(22, c1 - c0);
+#endif
     if (!G.all(ok)) return false;
-    if (EXTRA) return G.all(lane_self_pairs_clear(S, BP, G, P, thr_self));
+    if (EXTRA) {
+        const bool r = G.all(lane_self_pairs_clear(S, BP, G, P, thr_self));
+#ifdef SMR_PROFILE_ROWS
+        SMR_DEV_COUNT(23, SMR_DEV_CLOCK() - c1);
+#endif
+        return r;
+    }
     return true;
 }
 
@@ -1004,6 +1017,7 @@ __device__ inline bool group_table_free(const DScene &S, const BodyPool &BP, con
 template <bool EXTRA>
 __device__ inline bool group_pose_valid(const DScene &S, const BodyPool &BP, const Group &G, const Trig &P, const float box[3][2], float thr,
                                         float thr_self) {
+    SMR_DEV_COUNT(24, 1);
     const F3 ee = apply(body_frame_sc(S, P, S.ee_body), F3{S.ee_offset[0], S.ee_offset[1], S.ee_offset[2]});
     if (ee.x < box[0][0] || ee.x > box[0][1] || ee.y < box[1][0] || ee.y > box[1][1] || ee.z < box[2][0] || ee.z > box[2][1]) return false;
     return group_table_free<EXTRA>(S, BP, G, P, thr, thr_self);

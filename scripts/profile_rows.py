@@ -44,10 +44,9 @@ def main():
     total = cyc[:32].sum()
     print("config %s: %.1f M wave-cycles per step over %d rows" % (name, total / 1e6, int((waves > 0).sum())))
     phases = {32: "reset: start position", 33: "reset: velocity / acceleration", 34: "reset: planet phase", 36: "staged spawn: launch",
-              38: "target point", 40: "job setup: frame of the body", 41: "job setup: piece record + hull pointers", 42: "job setup: planet pose, run start", 
-              55: "first kernel: trips per chunk (count, not cycles)", 56: "first kernel: enumeration / job append", 57: "first kernel: item chunk",
-              
+              38: "target point", 48: "keys kernel: table queries", 49: "keys kernel: planet keys", 50: "keys kernel: upper bound of the best candidate",
               51: "jobs kernel: refill atomic (part of setup)", 52: "jobs kernel: job word + state loads (part of setup, lanes of the first job in the wave)",
+              54: "candidate poses: table tests (wavefront rounds: sum of cycles, number)", 55: "candidate poses: self-collision pairs (rounds that get there)", 56: "candidate poses: rounds per step (waves column)",
               57: "jobs kernel: refills per wavefront (count)",
               58: "jobs kernel: staging", 59: "jobs kernel: job setup (per wavefront)", 60: "jobs kernel: trips (per wavefront)", 61: "jobs kernel: trips per wavefront (count)",
               62: "jobs kernel: MAX iterations of one job", 63: "jobs kernel: MAX cycles of a wavefront"}
