@@ -1105,19 +1105,23 @@ __global__ __launch_bounds__(256) void brake_plan_kernel(const DScene *__restric
 // have moved far enough since the last evaluation to use up the clearance found there (every value piece_distance returns is a
 // lower bound of the distance; joint travel x lever arms bounds the motion of the body's points).
 #ifndef SMR_BRAKE_WAVES
-#define SMR_BRAKE_WAVES 4        // wavefronts per SIMD (512 / SMR_BRAKE_WAVES registers each): the blocks are short and many
-#endif
+#define SMR_BRAKE_WAVES 3        // wavefronts per SIMD (512 / SMR_BRAKE_WAVES registers each).  With the self pairs' bound tables and the
+#endif                           // trajectory minimum the kernel spilled 169 registers at 128: 4 -> 3: 1.86 -> 1.72 ms; 2: 2.09 ms (measured)
 // BT: punish_braking_trajectory_min_distance - the smallest distance of the walk is tracked as well (an instantiation of its own: the
 // extra state cost the plain check a quarter of its speed in spilled registers)
 template <bool SELF, bool BT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_WAVES, SMR_BRAKE_WAVES))) void brake_check_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = 256;
-    SMR_BRAKE_ROW_CLOCK((int)blockIdx.y);
+    // (Dealing the block ids out so that all rows of an env block run on ONE XCD, one after the other - they all read its 22 x 7
+    // braking accelerations per env, and the kernel moves 3.8 GB through the L2s per launch - was slower, 1.72 -> 2.20 ms: the
+    // heavy-rows-first order of the plain grid is worth more than the locality.)
+    const int env_block = (int)blockIdx.x, row = (int)blockIdx.y;
+    SMR_BRAKE_ROW_CLOCK(row);
     const int n_pair_blocks = SELF ? S.n_self_pairs : 0;
-    const bool pair_block = SELF && (int)blockIdx.y < n_pair_blocks;
-    const int pair = pair_block ? S.pair_order[(int)blockIdx.y] : 0;                       // the pairs with the nearest partners (longest blocks) first
-    const int body = pair_block ? S.self_pair[pair][0] : S.body_order[(int)blockIdx.y - n_pair_blocks];
+    const bool pair_block = SELF && row < n_pair_blocks;
+    const int pair = pair_block ? S.pair_order[row] : 0;                                   // the pairs with the nearest partners (longest blocks) first
+    const int body = pair_block ? S.self_pair[pair][0] : S.body_order[row - n_pair_blocks];
     const int partner = pair_block ? S.self_pair[pair][1] : -1;
     const int l = pair_block ? (partner >= 0 ? partner : body) : body;                    // the body whose hull is staged (see collide_kernel)
     if (!pair_block && !((S.static_mask >> body) & 1u)) return;                            // nothing of this body is observed by a static obstacle
@@ -1140,7 +1144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
     __syncthreads();
     const LocalHull hull{lds_v, lds_ids, (const uint8_t *)lds_start};
     const int B = S.B;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = env_block * (int)blockDim.x + (int)threadIdx.x;
     if (e >= B) return;
     const int steps = st.brake_steps[e];
     if (steps < 0) return;                               // braking timeout: brake_plan_kernel latched braked[e] already (ctlp.py:3201-3203)
