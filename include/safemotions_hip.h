@@ -141,9 +141,11 @@ int smr_get_state(smr_env_t *env, const smr_host_state_t *host_out);   /* synchr
 int smr_set_state(smr_env_t *env, const smr_host_state_t *host_in);    /* synchronises */
 int smr_synchronize(smr_env_t *env);
 
-/* Per-kernel HIP-event timing (events are recorded on the handle's stream around every launch while
+/* Per-kernel HIP-event timing (events are recorded on the handle's stream around the launches of a step while
  * enabled; smr_get_profile synchronises, returns accumulated milliseconds and launch counts per
- * SMR_K_* kernel since the last call and clears them). */
+ * SMR_K_* kernel since the last call and clears them).  enable: 0 off, 1 every step, n > 1 every n-th step -
+ * every pair of events is a pair of barrier packets in the queue, 65 us per step at 65 536 envs when every
+ * launch of every step is timed. */
 int smr_set_profiling(smr_env_t *env, int32_t enable);
 int smr_get_profile(smr_env_t *env, double ms_out[SMR_K_COUNT], int64_t launches_out[SMR_K_COUNT]);
 

@@ -2004,7 +2004,9 @@ struct smr_env {
     DState st;
     std::vector<void *> allocs;
     std::string err;
-    bool profiling = false;
+    bool profiling = false;     // events are recorded around the launches of the current call (smr_set_profiling; every profile_every-th step)
+    int profile_every = 0;      // 0: off, 1: every step, n: every n-th step
+    long long step_seq = 0;
     hipEvent_t ev[SMR_K_COUNT][2];
     bool ev_ok = false;
     struct Pending { int k; hipEvent_t a, b; };
@@ -2422,7 +2424,7 @@ int32_t smr_obs_size(const smr_env_t *env) { return env ? env->obs_size : 0; }
 static hipEvent_t pool_get(smr_env *env) {
     if (!env->event_pool.empty()) { hipEvent_t e = env->event_pool.back(); env->event_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    (void)hipEventCreate(&e);                            // (hipEventReleaseToDevice makes no difference to what a pair costs, measured)
     return e;
 }
 
@@ -2681,6 +2683,9 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     }
     SMR_HIP(hipSetDevice(env->device));
     const int B = env->B;
+    // a pair of timing events is a pair of barrier packets in the queue: around every launch of every step they cost 65 us per step
+    // (0.485 -> 0.550 ms at 65 536 envs, measured) - with a period the timed steps are a sample
+    env->profiling = env->profile_every > 0 && (env->step_seq++ % env->profile_every) == 0;
     if (env->auto_reset && !(env->staged && env->auto_reset)) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));   // staged: unused
     if (env->hscene.use_ball) {
         // this step's spawn list: the side stream may still be re-staging from the other one
@@ -2879,6 +2884,7 @@ int smr_set_profiling(smr_env_t *env, int32_t enable) {
     if (!env) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     int rc = resolve_profile(env);
+    env->profile_every = enable > 0 ? enable : 0;
     env->profiling = enable != 0;
     return rc;
 }

@@ -264,6 +264,15 @@ def test_profiling_counters(built):
     prof = env.get_profile()
     assert all(prof[k]["launches"] == 5 for k in ("plan", "collide", "finish", "reset"))
     assert prof["collide"]["ms"] > 0
+    # a period: the launches of every third step are timed (bench.py: the events around every launch of every step cost the step 12 %)
+    env.set_profiling(3)
+    for _ in range(7):
+        env.step(act)
+    prof = env.get_profile()
+    assert all(prof[k]["launches"] in (2, 3) for k in ("plan", "collide", "finish")) and prof["plan"]["launches"] == prof["finish"]["launches"]
+    env.set_profiling(False)
+    env.step(act)
+    assert env.get_profile()["plan"]["launches"] == 0
     env.close()
 
 
