@@ -559,6 +559,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     const unsigned long long pc0 = SMR_DEV_CLOCK();
     unsigned long long pc_setup = 0, pc_trip = 0, pc_atomic = 0, pc_loads = 0;
     int prof_trips = 0, prof_refills = 0, prof_maxit = 0;
+    const unsigned prof_wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);       // scripts/profile_jobs.py: the schedule of the wavefronts
+    const unsigned long long prof_w0 = wall_clock64();
+    unsigned long long prof_w1 = 0;
 #endif
     const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
     // An agent-scope atomic on the list counter is a round trip to the memory side of ~10 us, more when 2048 wavefronts ask at once
@@ -574,6 +577,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     const JobTables JT = stage_job_tables(S);           // (ends with a barrier)
 #ifdef SMR_PROFILE_ROWS
     SMR_DEV_COUNT(26, SMR_DEV_CLOCK() - pc0);
+    prof_w1 = wall_clock64();
 #endif
     const int lane = (int)__lane_id();
     bool active = false, mov = false, con = false, first = true;
@@ -650,6 +654,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     for (int d = 1; d < 64; d <<= 1) prof_maxit = max(prof_maxit, __shfl_xor(prof_maxit, d));
     SMR_DEV_COUNT(27, pc_setup); SMR_DEV_COUNT(28, pc_trip); SMR_DEV_COUNT(29, prof_trips); SMR_DEV_MAX(30, prof_maxit);
     SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc0); SMR_DEV_COUNT(25, prof_refills); SMR_DEV_COUNT(19, pc_atomic); SMR_DEV_COUNT(20, pc_loads);
+    if (prof_wave < 16384u && (threadIdx.x & 63) == 0) {
+        g_block_times[2 * prof_wave] = prof_w0; g_block_times[2 * prof_wave + 1] = wall_clock64();
+        g_wave_rec[8 * prof_wave] = (unsigned)prof_refills; g_wave_rec[8 * prof_wave + 1] = (unsigned)prof_trips; g_wave_rec[8 * prof_wave + 2] = (unsigned)prof_maxit;
+        g_wave_rec[8 * prof_wave + 3] = (unsigned)(prof_w1 - prof_w0);
+    }
 #endif
 }
 
