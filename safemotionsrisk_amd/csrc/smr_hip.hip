@@ -1180,9 +1180,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
             float qs[SMR_NJ], moved = 0.f;
 #pragma unroll
             for (int j = 0; j < SMR_NJ; ++j) { qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt); moved += fabsf(qs[j] - q_ref[j]) * lever[j]; }
+            // (Letting the whole wavefront evaluate whenever one lane has to - the lanes then fall into step - was measured: 1.57 -> 1.60 ms.
+            // With no evaluation at all (measurement build, SMR_BRAKE_WALK_ONLY) the braking kernels take 0.67 of their 1.56 ms: two fifths
+            // of the time is this walk, repeated in each of the 24 rows.  Walking only the joints that move what the row tests (the
+            // others interpolated when a sample is evaluated) was measured too: 1.57 -> 1.77 ms, 116 -> 132 spilled registers.)
             if (moved * 1.0001f + 1e-6f < margin) continue;
-            float d;
-            if (pair_block) {
+            float d = -kNoBound;
+            // a pair with a bound table (partner iiwa_link_4 / _5: the rows with the smallest clearances, evaluated at nearly every
+            // sample): two bytes indexed by the last joints' angles BEFORE any frame - an evaluation is a chain of seven dependent
+            // joint transforms whatever it ends in, the table read is not.  A bound that clears the threshold is as good as the
+            // distance here: the walk only asks "closer than thr?" and how far the joints may travel before it has to ask again.
+            if (pair_block && partner >= 0) d = self_tab_bound(S, pair, qs[4], qs[5], qs[6]);
+#ifdef SMR_BRAKE_WALK_ONLY                                 // measurement build: what the walk alone costs (no evaluation ever)
+            d = 1.0e30f;
+#endif
+            if (d > thr_skip + 2e-5f) {
+            } else if (pair_block) {
                 const int link_a = body < SMR_NLINK ? body : SMR_NLINK - 1;
                 Xf Ta = fk_base(S), Tp = Ta;
 #pragma unroll

@@ -1,0 +1,118 @@
+"""Soak form of the one-step parity tests: the same state-injection protocol as test_gpu_parity.py (the oracle is restarted from the
+GPU path's float32 state before every step), over more seeds, more steps (past the 20-step episode length, so the length
+termination and the re-sampled start states are inside the loop) and the four obstacle scenes side by side.  What it adds to the
+short tests is a count: how many env-steps were compared, how many decisions differed, how many of those sit on a threshold
+(parity_util.explain_mismatches) - and the assertion that none is left unexplained.
+
+    SMR_SOAK_SEEDS=11,12,13   seeds (default: one seed, so that the suite stays short)
+    SMR_SOAK_STEPS=25         steps per seed
+    SMR_SOAK_ENVS=4096
+    SMR_SOAK_REPORT=path.json the counts as JSON (profiles/round3_soak_parity.json was written this way)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from parity_util import explain_mismatches, relevant
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL = {
+    False: np.concatenate([np.full(7, 2e-6), np.full(7, 1e-5), np.full(7, 2e-5), np.full(2, 1e-6)]),
+    True: np.concatenate([np.full(7, 2e-6), np.full(7, 1e-5), np.full(7, 2e-5), np.full(6, 5e-6)]),
+}
+
+
+def _make(scene_name, B, seed):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG, BALL_ENV_CONFIG
+    cfg = dict(BALL_ENV_CONFIG if scene_name.startswith("ball") else SPACE_ENV_CONFIG)
+    if scene_name.endswith("_bm"):
+        cfg["ball_machine_mode"] = True
+    return VecSafeMotionsEnv(B, device=0, seed=seed, auto_reset=False, **cfg)
+
+
+def _report(name, rec):
+    path = os.environ.get("SMR_SOAK_REPORT")
+    if not path:
+        return
+    data = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            data = json.load(f)
+    data[name] = rec
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("scene_name", ["space", "space_bm", "ball", "ball_bm"])
+def test_soak_rollout_against_oracle(built, scene_name):
+    import torch
+    from oracle.oracle import OracleEnv
+    seeds = [int(x) for x in os.environ.get("SMR_SOAK_SEEDS", "11").split(",")]
+    T = int(os.environ.get("SMR_SOAK_STEPS", "25"))
+    B = int(os.environ.get("SMR_SOAK_ENVS", "4096"))
+    ball = scene_name.startswith("ball")
+    rec = dict(envs=B, steps=T, seeds=seeds, env_steps=0, decisions_differ=0, explained_by_threshold_tie=0, unexplained=0,
+               episodes_ended=0, by_reason={}, max_obs_err=0.0, max_reward_err=0.0, max_distance_err=0.0)
+    for seed in seeds:
+        env = _make(scene_name, B, seed)
+        env.reset()
+        ora = OracleEnv(env.scene, B, seed=seed, num_threads=16)
+        ora1 = OracleEnv(env.scene, 1)
+        keys = env.STATE_KEYS
+        rng = np.random.default_rng(1000 + seed)
+        for t in range(T):
+            st = env.get_state()
+            ora.set_state(**{k: st[k] for k in keys})
+            act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+            obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+            o_obs, o_rew, o_done, o_reason, o_info = ora.step(act.astype(np.float64))
+            obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+            reason = info["termination_reason"].cpu().numpy()
+            st1 = env.get_state()
+            bad = (done != o_done) | (reason != o_reason)
+            if ball:
+                bad |= (st1["ball_i"] != ora.get_state()["ball_i"]).any(axis=1)
+            if bad.any():
+                why = explain_mismatches(ora1, env.scene, st, st1, bad)
+                rec["decisions_differ"] += int(bad.sum())
+                rec["explained_by_threshold_tie"] += int(why.sum())
+                rec["unexplained"] += int((~why).sum())
+            good = ~bad
+            err = np.abs(obs[good] - o_obs[good])
+            assert (err < OBS_TOL[ball]).all()
+            rec["max_obs_err"] = max(rec["max_obs_err"], float(err.max()))
+            rec["max_reward_err"] = max(rec["max_reward_err"], float(np.abs(rew[good] - o_rew[good]).max()))
+            assert rec["max_reward_err"] < 5e-5
+            vals = info["values"].cpu().numpy()
+            near = (np.abs(o_info[:, :3] - 0.001) < 2e-5).any(axis=1)              # below 1 mm the value may be clamped on either side
+            # ... and a moving-obstacle distance ON the end of the query range (getClosestPoints(distance=max), ctlp.py:3263-3277) is either
+            # reported or replaced by the "nothing in range" value max + 0.002 (ctlp.py:3261): seen once in 800 000 env-steps, 0.6000000
+            # against 0.602.  (The static / self columns start from the end of their range itself: no jump there.)
+            mmax = float(env.scene.struct.moving_max_distance)
+            near |= (np.abs(vals[:, 2] - mmax) < 2e-5) | (np.abs(o_info[:, 2] - mmax) < 2e-5)
+            sel = good & ~near
+            derr = np.abs(relevant(vals[:, :3], env.scene)[sel] - relevant(o_info[:, :3], env.scene)[sel])
+            if ball:                                                                # (ball scenes: the moving distance of a retired ball is not defined)
+                derr = derr[:, :2]
+            if derr.size and float(derr.max()) > rec["max_distance_err"]:
+                rec["max_distance_err"] = float(derr.max())
+                n, c = np.unravel_index(int(derr.argmax()), derr.shape)
+                e = int(np.nonzero(sel)[0][n])
+                rec["worst_distance"] = dict(seed=seed, step=t, env=e, column=int(c), product=[float(x) for x in vals[e, :3]],
+                                             oracle=[float(x) for x in o_info[e, :3]], done=bool(o_done[e]), reason=int(o_reason[e]))
+            rec["env_steps"] += B
+            rec["episodes_ended"] += int(o_done.sum())
+            for r in o_reason[o_done.astype(bool)].tolist():
+                rec["by_reason"][str(r)] = rec["by_reason"].get(str(r), 0) + 1
+            if done.any():
+                env.reset(mask=torch.from_numpy(done).cuda())
+        env.close()
+    _report(scene_name, rec)
+    assert rec["unexplained"] == 0, rec
+    assert rec["max_distance_err"] < 5e-6, rec
+    assert rec["episodes_ended"] > 0.5 * B * len(seeds)                             # T > 20: every env ended at least ... most did
