@@ -569,9 +569,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     // staging, to let late blocks leave, cost the kernel 4 %; a look before every read-modify-write 30 %).  So the first hand-out
     // is taken per BLOCK and its round trip hides behind the staging; and when the first hand-outs cover the list nobody asks again.
     // With fewer jobs than lanes (small batches) the wavefronts share them out thinly: every SIMD gets a few runs instead of a few
-    // CUs getting them all, and a wavefront's chain is the longest of eight runs, not of sixty-four.
+    // CUs getting them all, and a wavefront's chain is the longest of four runs, not of sixty-four (a floor of 8 -> 4 with two blocks per
+    // CU: 4096 envs 0.117 -> 0.106 ms; 2: 0.109 ms).
     const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
-    const int quota = min(64, max(8, (n_jobs + n_waves - 1) / n_waves));
+#ifndef SMR_JOB_QUOTA_MIN
+#define SMR_JOB_QUOTA_MIN 4
+#endif
+    const int quota = min(64, max(SMR_JOB_QUOTA_MIN, (n_jobs + n_waves - 1) / n_waves));
     __shared__ int first_base;
     if (threadIdx.x == 0) first_base = atomicAdd(st.job_next, (int)(blockDim.x >> 6) * quota);
     const JobTables JT = stage_job_tables(S);           // (ends with a barrier)
@@ -2020,6 +2024,7 @@ struct smr_env {
     int *risky_buf = nullptr;
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
     int job_blocks = 0;               // their persistent grid: one 512-lane block per CU
+    int job_block_lanes = 512;        // (SMR_JOB_BLOCK_LANES: 256 / 128 for measurements)
     int item_blocks = 0;              // enumerate kernel: 256-lane blocks striding over the item list
     bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
@@ -2380,8 +2385,13 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4) || hipMemset(st.job_next, 0, 4) || hipMemset(st.overflow_env, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
-        env->job_blocks = std::max(prop.multiProcessorCount, 1);
+        // one 512-lane block per CU at the full batch; two up to 32 768 envs, where the kernel is the chain of its longest wavefront and
+        // thinner shares shorten it (measured, blocks per CU 1 -> 2: 4096 envs 0.119 -> 0.106 ms with SMR_JOB_QUOTA_MIN 4, 8192 envs
+        // 0.140 -> 0.128, 16 384 0.171 -> 0.153, 32 768 0.206 -> 0.191; 65 536: 0.217 -> 0.224 ms in the space scene, 0.173 -> 0.162 in the
+        // reaching task; 256-lane blocks - one wavefront per SIMD - at 4096 envs: 0.119 -> 0.142 ms)
+        env->job_blocks = std::max(prop.multiProcessorCount, 1) * (B <= 32768 ? 2 : 1);
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
+        if (const char *v = getenv("SMR_JOB_BLOCK_LANES")) if (atoi(v) == 256 || atoi(v) == 512 || atoi(v) == 128) env->job_block_lanes = atoi(v);
         env->self_job_blocks = std::max(8, std::min(env->job_blocks, (int)((B + 1023) / 1024)));      // ~40 jobs per wavefront
         // the item part of the enumerate grid: one round for the usual 1.2 items per (env, body) - every round of a wavefront ends with a
         // round trip to the list counter (SMR_ITEM_BLOCKS: blocks per CU, A/B runs)
@@ -2784,8 +2794,8 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         if (env->hscene.jobs_on) {
             if (env->hscene.planets_jobs) {
                 LaunchTimer tj(env, SMR_K_JOBS);
-                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
-                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st);
             }
             // (beside the jobs kernel on a stream of its own - its flags are final once the lists are written, its results commute with
             // the jobs' - the step got slower: space 115 -> 109 M, reaching task 92 -> 78 M env-steps/s, measured)
