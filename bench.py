@@ -279,7 +279,8 @@ def main():
         traffic = traffic_step = issue = None
         kk = {}
         if pmc is not None:
-            kname = "smr::%s_kernel" % dominant
+            # ("brake" times brake_plan + brake_check + brake_apply; the counters are those of brake_check, 97 % of it)
+            kname = {"brake": "smr::brake_check_kernel"}.get(dominant, "smr::%s_kernel" % dominant)
             kk = pmc["kernels"].get(kname, {})
             traffic = kk.get("hbm_bytes")
             step_kernels = [k for k in pmc["kernels"] if not any(x in k for x in ("reset", "spawn<staged>", "target<staged>"))]
@@ -298,8 +299,8 @@ def main():
         # wave-slot occupancy of the dominant kernel: the wavefronts' summed life time against (kernel time x wave slots of the chip)
         slot = None
         if pmc is not None and "SQ_WAVE_CYCLES" in kk and kk.get("SQ_WAVES"):
-            waves_per_simd = {"collide": 4, "brake": 4, "jobs": 2}.get(dominant, 2)
-            # the jobs kernel is a persistent grid (one block of four wavefronts per CU): the wavefronts it launches ARE its slots
+            waves_per_simd = {"collide": 4, "brake": 3, "jobs": 4}.get(dominant, 2)
+            # the jobs kernel is a persistent grid (one 512-lane block per CU, two up to 32 768 envs): the wavefronts it launches ARE its slots
             slots = min(N_SIMD * waves_per_simd, int(kk["SQ_WAVES"])) if dominant == "jobs" else N_SIMD * waves_per_simd
             # SQ_WAVE_CYCLES counts in units of 4 cycles (MI355X_MICROARCH.md, SQ counters "quad-cycles")
             mean_wave_us = kk["SQ_WAVE_CYCLES"] * 4.0 / kk["SQ_WAVES"] / CLOCK_HZ * 1e6

@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void brake_plan_kernel(const DScene *__restric
 template <bool SELF, bool BT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_WAVES, SMR_BRAKE_WAVES))) void brake_check_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
-    constexpr int kBlock = 256;
+    const int kBlock = (int)blockDim.x;           // 64 .. 256 lanes (smr_env::brake_block)
     // (Dealing the block ids out so that all rows of an env block run on ONE XCD, one after the other - they all read its 22 x 7
     // braking accelerations per env, and the kernel moves 3.8 GB through the L2s per launch - was slower, 1.72 -> 2.20 ms: the
     // heavy-rows-first order of the plain grid is worth more than the locality.)
@@ -2393,6 +2393,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         if (const char *v = getenv("SMR_JOB_BLOCK_LANES")) if (atoi(v) == 256 || atoi(v) == 512 || atoi(v) == 128) env->job_block_lanes = atoi(v);
         env->self_job_blocks = std::max(8, std::min(env->job_blocks, (int)((B + 1023) / 1024)));      // ~40 jobs per wavefront
+        if (const char *v = getenv("SMR_SELF_JOB_BLOCKS")) if (atoi(v) > 0) env->self_job_blocks = atoi(v);
         // the item part of the enumerate grid: one round for the usual 1.2 items per (env, body) - every round of a wavefront ends with a
         // round trip to the list counter (SMR_ITEM_BLOCKS: blocks per CU, A/B runs)
         {
@@ -2749,13 +2750,15 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (env->hscene.check_braking) {                    // adapt_action: the braking acceleration replaces actions whose braking trajectory collides
         LaunchTimer t(env, SMR_K_BRAKE);
         hipLaunchKernelGGL(brake_plan_kernel, dim3(((size_t)B * 8 + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st);
-        const dim3 grid((B + 255) / 256, env->hscene.n_bodies + env->hscene.n_self_pairs);
+        int bb = 64;         // one wavefront per block: with three wavefronts per SIMD a 4-wavefront block rarely finds its four slots at once (resident blocks 560 of 768; 256 -> 128 -> 64 lanes: 1.58 -> 1.42 -> 1.39 ms)
+        if (const char *v = getenv("SMR_BRAKE_BLOCK")) if (atoi(v) == 64 || atoi(v) == 128 || atoi(v) == 192 || atoi(v) == 256) bb = atoi(v);
+        const dim3 grid((B + bb - 1) / bb, env->hscene.n_bodies + env->hscene.n_self_pairs);
         const bool bt = env->hscene.punish_bt_min != 0;
         if (env->hscene.n_self_pairs > 0) {
-            if (bt) hipLaunchKernelGGL((brake_check_kernel<true, true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-            else hipLaunchKernelGGL((brake_check_kernel<true, false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-        } else if (bt) hipLaunchKernelGGL((brake_check_kernel<false, true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL((brake_check_kernel<false, false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+            if (bt) hipLaunchKernelGGL((brake_check_kernel<true, true>), grid, dim3(bb), 0, env->stream, env->dscene, env->st);
+            else hipLaunchKernelGGL((brake_check_kernel<true, false>), grid, dim3(bb), 0, env->stream, env->dscene, env->st);
+        } else if (bt) hipLaunchKernelGGL((brake_check_kernel<false, true>), grid, dim3(bb), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((brake_check_kernel<false, false>), grid, dim3(bb), 0, env->stream, env->dscene, env->st);
         hipLaunchKernelGGL(brake_apply_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st);
         SMR_HIP(hipGetLastError());
     }
