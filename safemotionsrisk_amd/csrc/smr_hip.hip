@@ -135,6 +135,14 @@ struct PhaseClock {
 #define SMR_SIDE_WAVES 2
 #endif
 #define SMR_SIDE_KERNEL __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_SIDE_WAVES, SMR_SIDE_WAVES)))
+// ... except the staged ball launches on the robot with the ball machine (spawn_kernel_extra): at 256 registers they spill 420-550, with the
+// whole register file (256 + 256 as spill space; any value but 2 gives that at 60 KB of LDS per block) 51-77, and since the self pairs left
+// the collide grid for the jobs kernel the shorter launches are worth more than the SIMDs they hold: ball + ball machine 64.2 -> 73.3 M
+// env-steps/s, ball scene on the plain robot unchanged (measured; the same for reset_kernel: 68 M there, and -3 .. -7 % in the planet scenes)
+#ifndef SMR_SPAWN_WAVES
+#define SMR_SPAWN_WAVES 1
+#endif
+#define SMR_SPAWN_KERNEL __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_SPAWN_WAVES, SMR_SPAWN_WAVES)))
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
@@ -1161,9 +1169,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
     if (e >= B) return;
     const int steps = st.brake_steps[e];
     if (steps < 0) return;                               // braking timeout: brake_plan_kernel latched braked[e] already (ctlp.py:3201-3203)
-    float p[SMR_NJ], v[SMR_NJ], ap[SMR_NJ], an[SMR_NJ], q_ref[SMR_NJ];
+    // the segment's cubic per joint in Horner form, q(t) = p + t (v + t (ha + t j6)) with ha = a0 / 2, j6 = (a1 - a0) / (6 dt): three
+    // multiply-adds per joint and sample (fewer instructions and 8 fewer spilled registers than the monomial form; the kernel's time did not move)
+    const float inv_dt6 = 1.0f / (6.0f * S.dt);
+    float p[SMR_NJ], v[SMR_NJ], ha[SMR_NJ], j6[SMR_NJ], q_ref[SMR_NJ];
 #pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) { p[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; ap[j] = st.a[j * B + e]; an[j] = st.a1[j * B + e]; q_ref[j] = p[j]; }
+    for (int j = 0; j < SMR_NJ; ++j) {
+        const float a0 = st.a[j * B + e], a1 = st.a1[j * B + e];
+        p[j] = st.q[j * B + e]; v[j] = st.v[j * B + e]; ha[j] = 0.5f * a0; j6[j] = (a1 - a0) * inv_dt6; q_ref[j] = p[j];
+    }
     // levers of the joints on the points of what this lane tests.  A pair of bodies on the chain: the joints below the partner link
     // carry both along, only the joints from the partner link on move the body relative to it.
     float lever[SMR_NJ];
@@ -1183,7 +1197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
             const float t = sidx == S.brake_checks ? S.dt : S.dt * (float)sidx / (float)S.brake_checks;
             float qs[SMR_NJ], moved = 0.f;
 #pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) { qs[j] = interp_pos(p[j], v[j], ap[j], an[j], t, S.dt); moved += fabsf(qs[j] - q_ref[j]) * lever[j]; }
+            for (int j = 0; j < SMR_NJ; ++j) { qs[j] = fmaf(t, fmaf(t, fmaf(t, j6[j], ha[j]), v[j]), p[j]); moved += fabsf(qs[j] - q_ref[j]) * lever[j]; }
             // (Letting the whole wavefront evaluate whenever one lane has to - the lanes then fall into step - was measured: 1.57 -> 1.60 ms.
             // With no evaluation at all (measurement build, SMR_BRAKE_WALK_ONLY) the braking kernels take 0.67 of their 1.56 ms: two fifths
             // of the time is this walk, repeated in each of the 24 rows.  Walking only the joints that move what the row tests (the
@@ -1228,10 +1242,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
             for (int j = 0; j < SMR_NJ; ++j) q_ref[j] = qs[j];
         }
 #pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) {
-            const float p1 = interp_pos(p[j], v[j], ap[j], an[j], S.dt, S.dt), v1 = interp_vel(v[j], ap[j], an[j], S.dt, S.dt);
-            p[j] = p1; v[j] = v1; ap[j] = an[j];
-            if (m < steps) an[j] = st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e];
+        for (int j = 0; j < SMR_NJ; ++j) {                                                 // the knot: p(dt), v(dt), a(dt) = a1; the next segment's a1
+            const float dt = S.dt, a_end = fmaf(6.0f * dt, j6[j], 2.0f * ha[j]);
+            p[j] = fmaf(dt, fmaf(dt, fmaf(dt, j6[j], ha[j]), v[j]), p[j]);
+            v[j] = fmaf(dt, fmaf(3.0f * dt, j6[j], 2.0f * ha[j]), v[j]);
+            ha[j] = 0.5f * a_end;
+            // (asked for a segment ahead of its use: 1.39 -> 1.41 ms, seven more registers to spill)
+            j6[j] = m < steps ? (st.brake_acc[((size_t)(m + 1) * SMR_NJ + j) * B + e] - a_end) * inv_dt6 : 0.f;
         }
     }
     if (BT && dmin <= S.static_max) atomicMin(&st.bt_min[e], dist_bits(dmin));
@@ -1481,12 +1498,12 @@ __device__ __forceinline__ void spawn_body(const DScene *__restrict__ Sp, const 
     }
 }
 
-// Two instantiation families with different register budgets: with the ball machine (EXTRA) the kernel is held to 256 registers like
-// the other reset-side kernels (a wavefront with 512 keeps the collide kernel off its SIMD: ball + ball machine 67 against 65 M
-// env-steps/s); on the plain robot its float64 launch arithmetic spills 100-200 registers at 256 and the kernel is short - there it
-// keeps the AGPRs as spill space (ball scene 113 -> 120 M).
+// Two instantiation families.  Round 2 held the one with the ball machine (EXTRA) to 256 registers like the other reset-side kernels
+// (a wavefront with 512 kept the collide kernel off its SIMD: 67 against 65 M env-steps/s then); since the self pairs are jobs it has
+// the whole register file again (SMR_SPAWN_WAVES above: 64 -> 73 M).  On the plain robot the float64 launch arithmetic spills 100-200
+// registers at 256 and the kernel is short - it keeps the AGPRs as spill space (ball scene 113 -> 120 M).
 template <bool STAGE>
-__global__ SMR_SIDE_KERNEL void spawn_kernel_extra(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list, const int *__restrict__ count_ptr,
+__global__ SMR_SPAWN_KERNEL void spawn_kernel_extra(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list, const int *__restrict__ count_ptr,
                                                    int count_fixed, int all_reset, int group_stride, float *__restrict__ obs,
                                                    const unsigned *__restrict__ tags, int tag_offset) {
     spawn_body<true, STAGE>(Sp, st, list, count_ptr, count_fixed, all_reset, group_stride, obs, tags, tag_offset);

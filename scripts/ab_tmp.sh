@@ -1,6 +1,6 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s3
 R=$GRAFT_REPO_ROOT/safemotionsrisk_amd
-for c in space space_bm reach space_n1; do
+for c in ball_bm ball; do
   echo "config=$c"
-  SMR_LIB=$R/libsmr_q4.so SMR_JOB_BLOCK_LANES=512 python scripts/bench_env.py SMR_JOB_BLOCKS 256,512,384,256,512 $c --steps 200
+  python scripts/bench_env.py SMR_LIB $R/libsmr_hip.so,$R/libsmr_A.so,$R/libsmr_B.so,$R/libsmr_hip.so $c --steps 200
 done
