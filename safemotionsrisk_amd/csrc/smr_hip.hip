@@ -142,6 +142,12 @@ struct PhaseClock {
 #ifndef SMR_SPAWN_WAVES
 #define SMR_SPAWN_WAVES 1
 #endif
+// (the staged target points likewise: 200 spilled registers at 256, none with the whole file; reaching task 103.8 -> 105.3 M, with the risk
+// networks 54.8 -> 55.9 M, with the braking layer unchanged - measured)
+#ifndef SMR_TARGET_WAVES
+#define SMR_TARGET_WAVES 1
+#endif
+#define SMR_TARGET_KERNEL __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_TARGET_WAVES, SMR_TARGET_WAVES)))
 #define SMR_SPAWN_KERNEL __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_SPAWN_WAVES, SMR_SPAWN_WAVES)))
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
@@ -1521,7 +1527,7 @@ __global__ __launch_bounds__(256) void spawn_kernel_plain(const DScene *__restri
 // STAGED: the point for the env's CURRENT target count goes to next_tp / next_tp_tag and nothing of the live env is touched
 // tags / tag_offset (STAGED): the target count the point is for - tags[i], or the env's current count + tag_offset
 template <bool EXTRA, bool STAGED>
-__global__ SMR_SIDE_KERNEL void target_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
+__global__ SMR_TARGET_KERNEL void target_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list,
                                                     const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                     float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
