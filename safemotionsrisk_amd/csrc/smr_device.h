@@ -133,6 +133,7 @@ struct DScene {
     // sum_j |qdot_j| sweep_R[b][j]; no point of planet p moves farther than planet_step[p] per orbit index; the ball stays inside
     // the sphere of radius ball_bound_radius (margin included) about its frame origin
     float sweep_R[SMR_MAX_BODIES][SMR_NJ];
+    float ee_R[SMR_NJ];               // the same for the target link point (A14: its reach test at the 24 updates of a step, finish_kernel)
     float planet_step[SMR_MAX_PLANETS];
     float ball_bound_radius;
     const float *auto_verts;   // the planet pieces' vertices, every piece padded to a multiple of 4 with its last vertex

@@ -416,6 +416,22 @@ inline void sweep_tables(const smr_scene_t &s, const HostGeometry &G, DScene &d)
             d.sweep_R[b][j] = j < chain ? (float)(R * 1.00001 + 1e-6) : 0.f;
         }
     }
+    {   // the target link point: ee_offset in the frame of ee_body (a chain link, or a body mounted on the last one)
+        const int b = s.ee_body;
+        double x[3] = {s.ee_offset[0], s.ee_offset[1], s.ee_offset[2]};
+        if (b >= SMR_NLINK) {
+            double y[3];
+            for (int r = 0; r < 3; ++r) y[r] = s.body_xyz[b][r] + s.body_rot[b][3 * r] * x[0] + s.body_rot[b][3 * r + 1] * x[1] + s.body_rot[b][3 * r + 2] * x[2];
+            for (int r = 0; r < 3; ++r) x[r] = y[r];
+        }
+        const double rho = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        const int chain = (b >= 0 && b < SMR_NLINK) ? b : SMR_NLINK - 1;
+        for (int j = 0; j < SMR_NJ; ++j) {
+            double R = rho;
+            for (int i = j + 1; i < chain; ++i) R += std::sqrt(s.joint_xyz[i][0] * s.joint_xyz[i][0] + s.joint_xyz[i][1] * s.joint_xyz[i][1] + s.joint_xyz[i][2] * s.joint_xyz[i][2]);
+            d.ee_R[j] = j < chain ? (float)(R * 1.00001 + 1e-6) : 0.f;
+        }
+    }
     d.ball_bound_radius = 0.f;
     if (s.use_ball && s.ball_piece >= 0 && s.ball_piece < s.n_pieces) {
         const DPiece &P = G.pieces[s.ball_piece];
