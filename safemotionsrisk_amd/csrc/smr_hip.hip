@@ -773,25 +773,54 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         tp_last = st.tp[3 * B + e]; tp_init = st.tp[4 * B + e];
         // The literal test looks at every update (24 forward kinematics per env-step: 20 000 of this kernel's 21 000 instructions per
         // wavefront).  The point moves no farther per update than sum_j max|qdot_j| ee_R[j] dt / U (contact sweep, smr_device.h), so an
-        // update at distance d rules out the next (d - radius) / that many: each lane visits the updates it cannot rule out and the
-        // last one (whose point the reward and the observation read); a wavefront takes as many rounds as its busiest lane.
+        // update at distance d rules out the next (d - radius) / that many.  Every lane evaluates the last update (its point is what
+        // the reward and the observation read) and walks from the first one over the updates it cannot rule out - two evaluations
+        // settle all but the lanes near their target.  Those are then taken one at a time by the whole wavefront: the lane's cubic is
+        // handed round and every lane evaluates one of its remaining updates (the same test at the same updates: nothing changes but who
+        // computes it).  The kernel is one wavefront per SIMD, so its length is the wavefront with the most rounds: 24 -> 3 + one per such lane.
         const int U = S.updates_per_step;
-        float step_u = 0.f;
+        float c_q[SMR_NJ], c_v[SMR_NJ], c_a[SMR_NJ], c_a1[SMR_NJ], step_u = 0.f;
 #pragma unroll
-        for (int j = 0; j < SMR_NJ; ++j) step_u += cubic_speed_bound(st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], S.dt) * S.ee_R[j];
+        for (int j = 0; j < SMR_NJ; ++j) {
+            c_q[j] = st.q[j * B + e]; c_v[j] = st.v[j * B + e]; c_a[j] = st.a[j * B + e]; c_a1[j] = st.a1[j * B + e];
+            step_u += cubic_speed_bound(c_v[j], c_a[j], c_a1[j], S.dt) * S.ee_R[j];
+        }
         step_u *= S.dt / (float)U;
-        for (int u = 1;;) {
+        const auto point_at = [&](const float (&Q)[SMR_NJ], const float (&V)[SMR_NJ], const float (&A)[SMR_NJ], const float (&A1)[SMR_NJ], int u) {
             const float t = u == U ? S.dt : S.dt * (float)u / (float)U;
             float qu[SMR_NJ];
 #pragma unroll
-            for (int j = 0; j < SMR_NJ; ++j) qu[j] = interp_pos(st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], st.a1[j * B + e], t, S.dt);
-            ee_end = ee_point(S, qu);
-            const F3 d = F3{tp[0], tp[1], tp[2]} - ee_end;
-            const float dist = sqrtf(dot(d, d));
-            if (dist < S.target_radius) tp_reached = true;
-            if (u >= U) break;
-            const int next = tp_reached ? U : u + 1 + sweep_skip(dist, S.target_radius, step_u);
-            u = next < U ? next : U;
+            for (int j = 0; j < SMR_NJ; ++j) qu[j] = interp_pos(Q[j], V[j], A[j], A1[j], t, S.dt);
+            return ee_point(S, qu);
+        };
+        const auto dist_to = [&](const F3 &p, float x, float y, float z) { const F3 d = F3{x, y, z} - p; return sqrtf(dot(d, d)); };
+        ee_end = point_at(c_q, c_v, c_a, c_a1, U);
+        tp_reached = dist_to(ee_end, tp[0], tp[1], tp[2]) < S.target_radius;
+        int u_next = 1;
+        bool pending = !tp_reached && U > 1;
+        for (int it = 0; it < 2 && __any(pending); ++it) {
+            if (pending) {
+                const float dist = dist_to(point_at(c_q, c_v, c_a, c_a1, u_next), tp[0], tp[1], tp[2]);
+                if (dist < S.target_radius) { tp_reached = true; pending = false; }
+                else { u_next += 1 + sweep_skip(dist, S.target_radius, step_u); pending = u_next < U; }
+            }
+        }
+        const unsigned long long here = __ballot(true);
+        const int lane = (int)__lane_id(), n_here = __popcll(here), rank = __popcll(here & ((1ull << lane) - 1ull));
+        for (unsigned long long m = __ballot(pending); m; m &= m - 1ull) {
+            const int L = __ffsll((long long)m) - 1;
+            float b_q[SMR_NJ], b_v[SMR_NJ], b_a[SMR_NJ], b_a1[SMR_NJ];
+#pragma unroll
+            for (int j = 0; j < SMR_NJ; ++j) { b_q[j] = __shfl(c_q[j], L); b_v[j] = __shfl(c_v[j], L); b_a[j] = __shfl(c_a[j], L); b_a1[j] = __shfl(c_a1[j], L); }
+            const float bx = __shfl(tp[0], L), by = __shfl(tp[1], L), bz = __shfl(tp[2], L);
+            const int u0 = __shfl(u_next, L);
+            bool found = false;
+            for (int base = u0; base < U && !found; base += n_here) {
+                const int u = base + rank;
+                const bool mine = u < U && dist_to(point_at(b_q, b_v, b_a, b_a1, u), bx, by, bz) < S.target_radius;
+                found = __any(mine);
+            }
+            if (lane == L && found) tp_reached = true;
         }
     }
 #pragma unroll
