@@ -2090,6 +2090,9 @@ struct smr_env {
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
     int job_blocks = 0;               // their persistent grid: one 512-lane block per CU
     int job_block_lanes = 512;        // (SMR_JOB_BLOCK_LANES: 256 / 128 for measurements)
+    // lanes per block of brake_check: one wavefront - with three wavefronts per SIMD a 4-wavefront block rarely finds its four slots at
+    // once (560 of 768 blocks resident; 256 -> 128 -> 64 lanes: 1.58 -> 1.42 -> 1.39 ms).  SMR_BRAKE_BLOCK, read at smr_create
+    int brake_block = 64;
     int item_blocks = 0;              // enumerate kernel: 256-lane blocks striding over the item list
     bool primed = false;              // staged start states exist (a reset, or state injection with reset counters, has run)
     DScene *dscene = nullptr;
@@ -2434,6 +2437,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4) ? hipErrorUnknown : hipMemset(st.start_attempts, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (const char *v = getenv("SMR_BRAKE_BLOCK")) if (atoi(v) == 64 || atoi(v) == 128 || atoi(v) == 192 || atoi(v) == 256) env->brake_block = atoi(v);
     if (env->hscene.jobs_on) {
         const size_t NB = (size_t)scene->n_bodies, N = (size_t)scene->collision_checks_per_step;
         const bool pj = env->hscene.planets_jobs != 0;
@@ -2815,8 +2819,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     if (env->hscene.check_braking) {                    // adapt_action: the braking acceleration replaces actions whose braking trajectory collides
         LaunchTimer t(env, SMR_K_BRAKE);
         hipLaunchKernelGGL(brake_plan_kernel, dim3(((size_t)B * 8 + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st);
-        int bb = 64;         // one wavefront per block: with three wavefronts per SIMD a 4-wavefront block rarely finds its four slots at once (resident blocks 560 of 768; 256 -> 128 -> 64 lanes: 1.58 -> 1.42 -> 1.39 ms)
-        if (const char *v = getenv("SMR_BRAKE_BLOCK")) if (atoi(v) == 64 || atoi(v) == 128 || atoi(v) == 192 || atoi(v) == 256) bb = atoi(v);
+        const int bb = env->brake_block;
         const dim3 grid((B + bb - 1) / bb, env->hscene.n_bodies + env->hscene.n_self_pairs);
         const bool bt = env->hscene.punish_bt_min != 0;
         if (env->hscene.n_self_pairs > 0) {
