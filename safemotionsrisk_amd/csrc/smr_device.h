@@ -1012,6 +1012,9 @@ struct GjkRun {
     F3 w0, w1, w2, w3, v;
     float vv, cutoff2, stop2;
     int n, it, stalls, hint_a, hint_b;
+#ifdef SMR_PROFILE_ROWS
+    unsigned long long pc_sa = 0, pc_sb = 0, pc_rest = 0;      // wavefront cycles inside the two support calls / the rest of gjk_iterate
+#endif
     __device__ __forceinline__ void start(F3 v0, float cutoff, float stop_below) {
         w0 = {0, 0, 0}; w1 = w0; w2 = w0; w3 = w0;
         v = v0; vv = dot(v0, v0);
@@ -1030,7 +1033,18 @@ __device__ __forceinline__ bool gjk_iterate(GjkRun &g, const SA &sa, const SB &s
     SMR_CNT(3);
     SMR_CNT(4);
     const bool first = g.it == 0;
+#ifdef SMR_PROFILE_ROWS
+    const unsigned long long pt0 = SMR_DEV_CLOCK();
+    const F3 wa = sa(neg(g.v), g.hint_a, first);
+    const unsigned long long pt1 = SMR_DEV_CLOCK();
+    const F3 wb = sb(g.v, g.hint_b, first);
+    const unsigned long long pt2 = SMR_DEV_CLOCK();
+    g.pc_sa += pt1 - pt0; g.pc_sb += pt2 - pt1;
+    struct RestClock { GjkRun &g; unsigned long long t; __device__ ~RestClock() { g.pc_rest += SMR_DEV_CLOCK() - t; } } rest_clock_{g, pt2};
+    const F3 w = wa - wb;
+#else
     const F3 w = sa(neg(g.v), g.hint_a, first) - sb(g.v, g.hint_b, first);
+#endif
     const float vw = dot(g.v, w);
     if (vw > 0.f && vw * vw > g.cutoff2 * g.vv) { dist = vw / sqrtf(g.vv); return true; }
     bool settled = g.n > 0 && (g.vv - vw) <= 1e-6f * g.vv;
@@ -1961,13 +1975,21 @@ __device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, co
 // ---------------------------------------------------------------------------------------------
 // kJobSelf: self-collision pair `piece` of the env at the end of the step (the job word's piece field holds the pair index)
 enum { kJobPlanetEnd = 0, kJobItem = 1, kJobStaticEnd = 2, kJobSelf = 3 };
+// job word: env 0..31 | body 32..35 | piece 36..41 | sample k 42..49 | kind 50..52.  k runs to checks_per_step (the end-of-step jobs carry
+// k = N), which check_scene bounds by kMaxChecksPerStep - the lane form's item queue packs (lane << 5 | k) and holds N - 1 items per lane.
+constexpr int kMaxChecksPerStep = 24;
+constexpr int kJobBodyBits = 4, kJobPieceBits = 6, kJobKBits = 8, kJobKindBits = 3;
+constexpr int kJobBodyShift = 32, kJobPieceShift = kJobBodyShift + kJobBodyBits, kJobKShift = kJobPieceShift + kJobPieceBits, kJobKindShift = kJobKShift + kJobKBits;
+static_assert(kMaxChecksPerStep < (1 << kJobKBits) && kMaxChecksPerStep < 32, "sample index does not fit the job word / the item queue entry");
+static_assert(SMR_MAX_BODIES <= (1 << kJobBodyBits) && SMR_MAX_SELF_PAIRS <= (1 << kJobPieceBits) && kJobKindShift + kJobKindBits <= 64, "job word fields");
 __device__ __forceinline__ unsigned long long job_word(int env, int body, int piece, int k, int kind) {
-    return (unsigned long long)(unsigned)env | ((unsigned long long)body << 32) | ((unsigned long long)piece << 36) |
-           ((unsigned long long)k << 42) | ((unsigned long long)kind << 47);
+    return (unsigned long long)(unsigned)env | ((unsigned long long)body << kJobBodyShift) | ((unsigned long long)piece << kJobPieceShift) |
+           ((unsigned long long)k << kJobKShift) | ((unsigned long long)kind << kJobKindShift);
 }
 struct Job { int env, body, piece, k, kind; };
 __device__ __forceinline__ Job job_unpack(unsigned long long w) {
-    return {(int)(unsigned)(w & 0xFFFFFFFFull), (int)((w >> 32) & 15ull), (int)((w >> 36) & 63ull), (int)((w >> 42) & 31ull), (int)((w >> 47) & 7ull)};
+    return {(int)(unsigned)(w & 0xFFFFFFFFull), (int)((w >> kJobBodyShift) & ((1ull << kJobBodyBits) - 1)), (int)((w >> kJobPieceShift) & ((1ull << kJobPieceBits) - 1)),
+            (int)((w >> kJobKShift) & ((1ull << kJobKBits) - 1)), (int)((w >> kJobKindShift) & ((1ull << kJobKindBits) - 1))};
 }
 __device__ __forceinline__ unsigned dist_bits(float d) { return (unsigned)__float_as_int(fmaxf(d, 0.f)); }   // below 1 mm only "d < 0.001" is defined
 

@@ -152,7 +152,7 @@ struct PhaseClock {
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
-constexpr int kMaxItemsPerLane = 23;   // N - 1 <= 23 intermediate samples (N divides the 24 updates of a step)
+constexpr int kMaxItemsPerLane = kMaxChecksPerStep - 1;   // N - 1 intermediate samples (check_scene: N <= kMaxChecksPerStep)
 // SELF: the scene has self-collision pairs (ball machine); the plain robot runs the instantiation without that code
 // AUTO: lane-autonomous planet queries (planet_queries_auto); four wavefronts then share the LDS copies
 template <bool SELF, bool AUTO>
@@ -571,8 +571,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     const DScene &S = *Sp;
 #ifdef SMR_PROFILE_ROWS
     const unsigned long long pc0 = SMR_DEV_CLOCK();
-    unsigned long long pc_setup = 0, pc_trip = 0, pc_atomic = 0, pc_loads = 0;
-    int prof_trips = 0, prof_refills = 0, prof_maxit = 0;
+    unsigned long long pc_setup = 0, pc_trip = 0, pc_atomic = 0, pc_loads = 0, pc_sa = 0, pc_sb = 0, pc_rest = 0;
+    int prof_trips = 0, prof_refills = 0, prof_maxit = 0, prof_lanes = 0, prof_hist[5] = {0, 0, 0, 0, 0}, prof_n[3] = {0, 0, 0};
     const unsigned prof_wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);       // scripts/profile_jobs.py: the schedule of the wavefronts
     const unsigned long long prof_w0 = wall_clock64();
     unsigned long long prof_w1 = 0;
@@ -656,15 +656,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
         ++prof_trips;
 #endif
         float d;
+#ifdef SMR_PROFILE_ROWS
+        int prof_its = 0;
+        prof_lanes += __popcll(__ballot(active));
+        const int prof_src = __ffsll((long long)__ballot(active)) - 1;      // a lane that takes part in this trip: its clock deltas are the wavefront's
+        const unsigned long long sa0 = __shfl(J.g.pc_sa, prof_src), sb0 = __shfl(J.g.pc_sb, prof_src), rest0 = __shfl(J.g.pc_rest, prof_src);
+        { const int nn = J.g.n; prof_n[0] += __popcll(__ballot(active && nn <= 1)); prof_n[1] += __popcll(__ballot(active && nn == 2)); prof_n[2] += __popcll(__ballot(active && nn == 3)); }
+#endif
         if (active && job_trip<SELF>(J, d)) {
             active = false;
             job_result(S, st, jb, mov, con, d, seen);
 #ifdef SMR_PROFILE_ROWS
             prof_maxit = max(prof_maxit, J.g.it + 1);
+            prof_its = J.g.it + 1;
 #endif
         }
 #ifdef SMR_PROFILE_ROWS
         pc_trip += SMR_DEV_CLOCK() - t1;
+        pc_sa += __shfl(J.g.pc_sa, prof_src) - sa0; pc_sb += __shfl(J.g.pc_sb, prof_src) - sb0; pc_rest += __shfl(J.g.pc_rest, prof_src) - rest0;
+        prof_hist[0] += __popcll(__ballot(prof_its == 1)); prof_hist[1] += __popcll(__ballot(prof_its == 2));
+        prof_hist[2] += __popcll(__ballot(prof_its == 3 || prof_its == 4)); prof_hist[3] += __popcll(__ballot(prof_its >= 5 && prof_its <= 8));
+        prof_hist[4] += __popcll(__ballot(prof_its >= 9));
 #endif
     }
 #ifdef SMR_PROFILE_ROWS
@@ -672,6 +684,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     for (int d = 1; d < 64; d <<= 1) prof_maxit = max(prof_maxit, __shfl_xor(prof_maxit, d));
     SMR_DEV_COUNT(27, pc_setup); SMR_DEV_COUNT(28, pc_trip); SMR_DEV_COUNT(29, prof_trips); SMR_DEV_MAX(30, prof_maxit);
     SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc0); SMR_DEV_COUNT(25, prof_refills); SMR_DEV_COUNT(19, pc_atomic); SMR_DEV_COUNT(20, pc_loads);
+    // anatomy of the trips (scripts/profile_rows.py): cycles inside the two support calls and the rest of gjk_iterate (every lane of a
+    // wavefront reads the same clock: lane 0's sums are the wavefront's), lanes with a run per trip, iterations per job, simplex sizes
+    SMR_DEV_COUNT(7, pc_sa); SMR_DEV_COUNT(8, pc_sb); SMR_DEV_COUNT(9, pc_rest); SMR_DEV_COUNT(10, prof_lanes);
+    SMR_DEV_COUNT(11, prof_hist[0]); SMR_DEV_COUNT(12, prof_hist[1]); SMR_DEV_COUNT(13, prof_hist[2]); SMR_DEV_COUNT(14, prof_hist[3]); SMR_DEV_COUNT(15, prof_hist[4]);
+    SMR_DEV_COUNT(3, prof_n[0]); SMR_DEV_COUNT(5, prof_n[1]); SMR_DEV_COUNT(21, prof_n[2]);
     if (prof_wave < 16384u && (threadIdx.x & 63) == 0) {
         g_block_times[2 * prof_wave] = prof_w0; g_block_times[2 * prof_wave + 1] = wall_clock64();
         g_wave_rec[8 * prof_wave] = (unsigned)prof_refills; g_wave_rec[8 * prof_wave + 1] = (unsigned)prof_trips; g_wave_rec[8 * prof_wave + 2] = (unsigned)prof_maxit;
@@ -2362,6 +2379,9 @@ static int check_scene(const smr_scene_t *s, int32_t num_envs, std::string &err)
     if (num_envs <= 0 || num_envs > (1 << 26)) { err = "num_envs must be in 1 .. 2^26"; return SMR_E_INVALID; }
     if (s->collision_checks_per_step <= 0 || s->updates_per_step <= 0 || s->updates_per_step % s->collision_checks_per_step) {
         err = "collision_checks_per_step must divide updates_per_step"; return SMR_E_INVALID;
+    }
+    if (s->collision_checks_per_step > kMaxChecksPerStep) {      // the sample index of job words / item queue entries, the items per lane
+        err = "collision_checks_per_step > 24 is not supported (trajectory_time_step > 0.1 s: pass a divisor of updates_per_step that is <= 24)"; return SMR_E_INVALID;
     }
     if (s->use_ball && s->n_planets > 0) { err = "ball and planets in one scene are not supported"; return SMR_E_INVALID; }
     if (!s->verts || !s->pieces || s->n_verts <= 0 || s->n_pieces <= 0) { err = "scene has no geometry"; return SMR_E_INVALID; }

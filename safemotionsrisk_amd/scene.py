@@ -540,6 +540,10 @@ def _link_mask(names):
     return mask
 
 
+#: largest N the kernels take (csrc/smr_device.h: kMaxChecksPerStep; smr_create rejects more)
+MAX_COLLISION_CHECKS_PER_STEP = 24
+
+
 def build_scene(env_config, collision_checks_per_step=None, contact_distance=BULLET_CONTACT_BREAKING_THRESHOLD,
                 auto_reset=True, assets_path=_DATA, trained_networks_dir=None):
     """Build the scene description for ``Env(**env_config)`` of the reference (train.py:620).
@@ -570,6 +574,13 @@ def build_scene(env_config, collision_checks_per_step=None, contact_distance=BUL
     if collision_checks_per_step < 1 or s.updates_per_step % collision_checks_per_step:
         raise ValueError("collision_checks_per_step=%d must divide the %d obstacle updates per step"
                          % (collision_checks_per_step, s.updates_per_step))
+    if collision_checks_per_step > MAX_COLLISION_CHECKS_PER_STEP:
+        # the kernels pack the sample index into job words and item-queue entries and hold N - 1 items per lane (csrc/smr_device.h:
+        # kMaxChecksPerStep); a trajectory_time_step above 0.1 s has more than 24 obstacle updates per step
+        raise ValueError("collision_checks_per_step=%d is not supported (at most %d): with trajectory_time_step=%g there are %d obstacle updates "
+                         "per step - pass collision_checks_per_step=<a divisor of %d that is <= %d>"
+                         % (collision_checks_per_step, MAX_COLLISION_CHECKS_PER_STEP, dt, s.updates_per_step, s.updates_per_step,
+                            MAX_COLLISION_CHECKS_PER_STEP))
     s.collision_checks_per_step = int(collision_checks_per_step)
     s.auto_reset = int(bool(auto_reset))
 

@@ -45,6 +45,10 @@ def main():
     print("config %s: %.1f M wave-cycles per step over %d rows" % (name, total / 1e6, int((waves > 0).sum())))
     phases = {32: "reset: start position", 33: "reset: velocity / acceleration", 34: "reset: planet phase", 36: "staged spawn: launch",
               38: "target point", 48: "keys kernel: table queries", 49: "keys kernel: planet keys", 50: "keys kernel: upper bound of the best candidate",
+              39: "jobs kernel: trips, inside the scanned side's support (per wavefront)", 40: "jobs kernel: trips, inside the hull climb (per wavefront)",
+              41: "jobs kernel: trips, rest of gjk_iterate (per wavefront)", 42: "jobs kernel: lanes with a run, summed over the trips (per wavefront)",
+              43: "jobs kernel: jobs settled after 1 iteration (per wavefront)", 44: "jobs kernel: ... after 2", 45: "jobs kernel: ... after 3-4", 46: "jobs kernel: ... after 5-8",
+              47: "jobs kernel: ... after 9+", 35: "jobs kernel: lane-trips entered with a simplex of <= 1 points", 37: "jobs kernel: ... of 2 points", 53: "jobs kernel: ... of 3 points",
               51: "jobs kernel: refill atomic (part of setup)", 52: "jobs kernel: job word + state loads (part of setup, lanes of the first job in the wave)",
               54: "candidate poses: table tests (wavefront rounds: sum of cycles, number)", 55: "candidate poses: self-collision pairs (rounds that get there)", 56: "candidate poses: rounds per step (waves column)",
               57: "jobs kernel: refills per wavefront (count)",

@@ -772,7 +772,11 @@ PLANET_VARIANTS = {
     "uncoupled": dict(planet_two_time_shift=None, planet_two_period=4.0),
     "no_termination": dict(terminate_on_collision_with_moving_obstacle=False),
     "pos_obs": dict(obs_planet_size_per_planet=3),
+    # 48 obstacle updates per step: N = 48 exceeds what the job words / item queues carry (rejected, tests/test_scene_config.py), 24 samples of
+    # two updates each is the explicit choice - the sample index of end-of-step jobs (k = N) must survive the job word's packing
+    "time_step_0p2": dict(trajectory_time_step=0.2, trajectory_duration=4.0),
 }
+PLANET_VARIANT_KW = {"time_step_0p2": dict(collision_checks_per_step=24)}
 
 
 @pytest.mark.gpu
@@ -785,7 +789,7 @@ def test_planet_scene_variants_against_oracle(built, variant):
     from safemotionsrisk_amd import VecSafeMotionsEnv, SPACE_ENV_CONFIG
     B, T = 1024, 8
     cfg = dict(SPACE_ENV_CONFIG, **PLANET_VARIANTS[variant])
-    env = VecSafeMotionsEnv(B, device=0, seed=8, auto_reset=False, **cfg)
+    env = VecSafeMotionsEnv(B, device=0, seed=8, auto_reset=False, **PLANET_VARIANT_KW.get(variant, {}), **cfg)
     o0 = env.reset().cpu().numpy()
     ora = OracleEnv(env.scene, B, seed=8, num_threads=16)
     ora1 = OracleEnv(env.scene, 1)

@@ -212,3 +212,18 @@ def test_shipped_task_params_json_builds():
     b = build_scene(dict(cfg, risk_check_initial_backup_trajectory=False), trained_networks_dir="/root/reference/safemotions/trained_networks")
     assert b.risk == dict(observation_size=23, action_size=7, checkpoint="backup_networks/space/checkpoint/checkpoint", risk_threshold=0.065, risk_state_config=0)
     assert b.struct.use_target_points and b.struct.n_bodies == 10 and b.obs_size - 6 == 23
+
+
+def test_more_than_24_contact_samples_per_step_are_rejected():
+    """trajectory_time_step = 0.2 s has 48 obstacle updates per step; the kernels carry the sample index in job words and
+    item-queue entries sized for at most 24 samples (csrc/smr_device.h: kMaxChecksPerStep): the default N = 48 must be
+    refused loudly - it used to alias the end-of-step jobs' sample index - and a divisor <= 24 is the explicit choice."""
+    from safemotionsrisk_amd import SPACE_ENV_CONFIG, build_scene
+    from safemotionsrisk_amd.scene import MAX_COLLISION_CHECKS_PER_STEP
+    cfg = dict(SPACE_ENV_CONFIG, trajectory_time_step=0.2, trajectory_duration=4.0)
+    with pytest.raises(ValueError, match="collision_checks_per_step"):
+        build_scene(cfg)
+    b = build_scene(cfg, collision_checks_per_step=24)
+    assert b.struct.updates_per_step == 48 and b.struct.collision_checks_per_step == 24 == MAX_COLLISION_CHECKS_PER_STEP
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safemotionsrisk_amd", "csrc", "smr_device.h")).read()
+    assert "constexpr int kMaxChecksPerStep = %d;" % MAX_COLLISION_CHECKS_PER_STEP in src
