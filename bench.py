@@ -143,21 +143,50 @@ def launch_ranks(args):
     sys.stdout.flush()
 
 
-def load_pmc(config_name, B, n_checks):
+CSRC_FILES = ("smr_hip.hip", "smr_device.h", "smr_tables.h", "smr_mlp.h")
+
+
+def csrc_sha256():
+    """one hash over the four kernel sources (safemotionsrisk_amd/csrc): what scripts/make_pmc_json.py records with a counter file and
+    what load_pmc() demands of it - counters of other kernels than the ones that ran are not reported"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in CSRC_FILES:
+        h.update(name.encode() + b"\0")
+        h.update(open(os.path.join(ROOT, "safemotionsrisk_amd", "csrc", name), "rb").read())
+    return h.hexdigest()
+
+
+def load_pmc(config_name, B, n_checks, profiles_dir=None):
     """profiles/round<R>_pmc_<config>.json of the latest round that has one (scripts/make_pmc_json.py from separate rocprofv3 --pmc
-    passes of this command)"""
-    for rnd in (3, 2):
-        path = os.path.join(ROOT, "profiles", "round%d_pmc_%s.json" % (rnd, config_name))
+    passes of this command).  The file must have been collected from THESE kernel sources (run.csrc_sha256) at this batch size and
+    contact cadence; anything else gives (None, why) and the bench line carries traffic: null - never another build's counters."""
+    profiles_dir = profiles_dir or os.path.join(ROOT, "profiles")
+    for rnd in range(9, 1, -1):
+        path = os.path.join(profiles_dir, "round%d_pmc_%s.json" % (rnd, config_name))
         if os.path.exists(path):
             break
     else:
         return None, "no profiles/round*_pmc_%s.json" % config_name
     pmc = json.load(open(path))
     meta = pmc.get("run", {})
+    rel = os.path.join("profiles", os.path.basename(path))
     if meta.get("envs_per_gpu") != B or meta.get("collision_checks_per_step") != n_checks:
-        return None, "%s was collected at %s envs / %s checks, this run has %d / %d" % (os.path.relpath(path, ROOT), meta.get("envs_per_gpu"),
+        return None, "%s was collected at %s envs / %s checks, this run has %d / %d" % (rel, meta.get("envs_per_gpu"),
                                                                                      meta.get("collision_checks_per_step"), B, n_checks)
-    return pmc, os.path.relpath(path, ROOT)
+    have = csrc_sha256()
+    if meta.get("csrc_sha256") != have:
+        return None, "%s was collected from other kernel sources (csrc sha256 %s, this tree %s): counters withheld" % (
+            rel, str(meta.get("csrc_sha256"))[:12], have[:12])
+    return pmc, rel
+
+
+def multi_gpu_report(world, devices, mismatches, overlap):
+    """the keys of the bench line that describe the N > 1 exchange (and the self-check that ran before the timed region)"""
+    return {"rccl_world": int(world), "devices": list(devices),
+            "gather_check": {"steps": 2, "mode": "overlapped" if overlap else "synchronous", "mismatches": [list(m) for m in mismatches],
+                             "what": "before the timed region: every rank's int64 checksums of its local (obs, reward, done) bytes against "
+                                     "the slice every rank gathered (one all-gather of 3 x int64 per rank and step); a mismatch ends the run"}}
 
 
 def main():
@@ -232,32 +261,51 @@ def main():
         else:
             env.step(actions[i % 8])
 
+    gather_report = None
+    if rollout is not None:
+        # the exchange checks itself before anything is timed: a broken overlap is an error, not a silently wrong number
+        bad = rollout.verify([actions[0], actions[1]])
+        names = [None] * world
+        dist.all_gather_object(names, "%s:%d" % (torch.cuda.get_device_name(local_rank), local_rank))
+        flags = [None] * world
+        dist.all_gather_object(flags, bad)
+        gather_report = multi_gpu_report(dist.get_world_size(), names, [m for f in flags for m in f], rollout.overlap)
+        if any(flags):
+            raise SystemExit("rank %d: all-gather self-check failed, (step, rank) slices that differ from what their rank wrote, per rank: %s" % (rank, flags))
     for i in range(args.warmup):
         one_step(i)
     # HIP events around the launches of every `period`-th timed step: a pair of events is a pair of barrier packets in the queue, and around
     # every launch of every step they cost the step 12 % (0.485 -> 0.550 ms at 65 536 envs, measured)
     period = max(1, min(8, args.steps // 4))
     env.set_profiling(period)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_step(i)
-    if rollout is not None:
-        rollout.wait()                                  # every gather of the timed steps has landed before the clock stops
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # A short run (the driver's 20 steps after 5 warm-up steps) is timed `repeats` times back to back and the MEDIAN region is reported:
+    # a single 10 ms region right after reset() holds the burst in which every surviving env ends its first episode (39 577 of
+    # 65 536 at step 20) and reads 8 % low.  Every region is exactly --steps steps between barrier + synchronize.
+    repeats = 1 if args.steps >= 100 else 5
+    regions = []
+    for rep in range(repeats):
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(rep * args.steps + i)
+        if rollout is not None:
+            rollout.wait()                              # every gather of the timed steps has landed before the clock stops
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if distributed:
+            tmax = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        regions.append(el)
+    elapsed = sorted(regions)[len(regions) // 2]
     env.synchronize()                                   # raises if a device-side error condition was latched during the run
     prof = env.get_profile()
     env.set_profiling(False)
-    if distributed:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     if rank == 0:
         s = env.scene.struct
@@ -320,6 +368,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "repeats": repeats,
+            "region_ms": [round(r * 1e3, 4) for r in regions],
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -348,6 +398,8 @@ def main():
                               "note": "HIP events on the stream each kernel is launched on, around its launches in every n-th of the timed steps"},
             "overlapped_kernels": overlapped,
         }
+        if gather_report is not None:
+            out.update(gather_report)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(out))

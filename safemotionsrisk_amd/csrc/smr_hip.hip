@@ -697,6 +697,123 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #endif
 }
 
+// jobs kernel, round 4: prepared runs in an LDS pool (smr_device.h, "prepared runs").  The stream, the tables and the results are those of
+// jobs_kernel above; what changes is who iterates what.  A wavefront that runs out of prepared runs draws the next `quota` jobs and ALL its
+// lanes set them up into its pool (pool_off: dword offset of the pools behind the tables, 64 x kRunWords per wavefront); a lane whose run
+// has settled takes the next prepared run at once.  refill_idle: how many lanes must be without a run before an empty pool is refilled
+// (1: at once - the wavefront then holds up to 64 prepared runs nobody else can take when the stream dries up; 64: as jobs_kernel).
+#ifndef SMR_JOB_POOL_WAVES
+#define SMR_JOB_POOL_WAVES 2          // one 512-lane block per CU: two wavefronts per SIMD, 256 registers each
+#endif
+template <bool SELF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_POOL_WAVES, SMR_JOB_POOL_WAVES))) void jobs_pool_kernel(const DScene *__restrict__ Sp, DState st, int pool_off, int refill_idle) {
+    const DScene &S = *Sp;
+#ifdef SMR_PROFILE_ROWS
+    const unsigned long long pc0 = SMR_DEV_CLOCK();
+    unsigned long long pc_setup = 0, pc_trip = 0;
+    int prof_trips = 0, prof_refills = 0, prof_maxit = 0, prof_lanes = 0;
+    const unsigned prof_wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const unsigned long long prof_w0 = wall_clock64();
+    unsigned long long prof_w1 = 0;
+#endif
+    const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
+    const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
+    const int quota = min(64, max(SMR_JOB_QUOTA_MIN, (n_jobs + n_waves - 1) / n_waves));
+    __shared__ int first_base;
+    if (threadIdx.x == 0) first_base = atomicAdd(st.job_next, (int)(blockDim.x >> 6) * quota);      // (its round trip hides behind the staging)
+    const JobTables JT = stage_job_tables(S);           // (ends with a barrier)
+#ifdef SMR_PROFILE_ROWS
+    SMR_DEV_COUNT(26, SMR_DEV_CLOCK() - pc0);
+    prof_w1 = wall_clock64();
+#endif
+    const float *lds0 = (const float *)job_lds;
+    float *pool = (float *)job_lds + pool_off + (int)(threadIdx.x >> 6) * 64 * kRunWords;
+    const int lane = (int)__lane_id();
+    bool active = false, mov = false, con = false, first = true;
+    bool dry = (long long)n_waves * quota >= (long long)n_jobs;
+    int stock = 0;                                        // prepared runs in this wavefront's pool (wave uniform)
+    Job jb = {0, 0, 0, 0, 0};
+    float seen = 0.f;
+    PoolLane J;
+    J.g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);
+    J.X = Xf{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, F3{0.f, 0.f, 0.f}};
+    J.hull = JT.BP.hull(0); J.av = JT.pv; J.ac = 0; J.margins = 0.f; J.is_static = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        if (stock == 0 && n_idle >= refill_idle && (first || !dry)) {
+#ifdef SMR_PROFILE_ROWS
+            const unsigned long long t0 = SMR_DEV_CLOCK();
+            ++prof_refills;
+#endif
+            int base = 0;
+            if (first) { base = first_base + (int)(threadIdx.x >> 6) * quota; first = false; }
+            else {
+                if (lane == 0) base = atomicAdd(st.job_next, quota);
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+            dry = dry || base + quota >= n_jobs;
+            const int j = base + lane;
+            if (lane < quota && j < n_jobs) {
+                const unsigned long long word = st.jobs[j];
+                const Job nj = job_unpack(word);
+                const LaneInput in = load_lane_input(S, st, nj.env);
+                bool m2, c2;
+                job_flags(S, in, nj.body, m2, c2);
+                if (nj.kind == kJobItem) { m2 = false; c2 = true; }
+                const unsigned *running = (SELF && nj.kind == kJobSelf) ? st.env_dself : st.env_min;
+                const float sn = __uint_as_float(running[nj.env]);       // a plain load: a stale value is still an upper bound
+                float cutoff, stop;
+                job_limits(S, nj, m2, c2, sn, cutoff, stop);
+                run_prepare<SELF>(S, JT.BP, JT.pv, JT.pd, JT.cyl, lds0, in, st.frames, nj, m2, c2, cutoff, stop, sn, word, pool, lane);
+            }
+            stock = max(0, min(quota, n_jobs - base));
+#ifdef SMR_PROFILE_ROWS
+            pc_setup += SMR_DEV_CLOCK() - t0;
+#endif
+        }
+        if (n_idle > 0 && stock > 0) {                    // (the pool is this wavefront's own: written and read in program order, no barrier)
+            const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+            if (!active && rank < stock) {
+                run_take(JT.BP, lds0, pool, stock - 1 - rank, J, jb, mov, con, seen);
+                active = true;
+            }
+            stock -= min(n_idle, stock);
+        }
+        if (!__any(active)) {
+            if (stock == 0 && dry && !first) break;
+            continue;
+        }
+#ifdef SMR_PROFILE_ROWS
+        const unsigned long long t1 = SMR_DEV_CLOCK();
+        ++prof_trips;
+        prof_lanes += __popcll(__ballot(active));
+#endif
+        float d;
+        if (active && pool_trip<SELF>(J, d)) {
+            active = false;
+            job_result(S, st, jb, mov, con, d, seen);
+#ifdef SMR_PROFILE_ROWS
+            prof_maxit = max(prof_maxit, J.g.it + 1);
+#endif
+        }
+#ifdef SMR_PROFILE_ROWS
+        pc_trip += SMR_DEV_CLOCK() - t1;
+#endif
+    }
+#ifdef SMR_PROFILE_ROWS
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) prof_maxit = max(prof_maxit, __shfl_xor(prof_maxit, d));
+    SMR_DEV_COUNT(27, pc_setup); SMR_DEV_COUNT(28, pc_trip); SMR_DEV_COUNT(29, prof_trips); SMR_DEV_MAX(30, prof_maxit);
+    SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc0); SMR_DEV_COUNT(25, prof_refills); SMR_DEV_COUNT(10, prof_lanes);
+    if (prof_wave < 16384u && (threadIdx.x & 63) == 0) {
+        g_block_times[2 * prof_wave] = prof_w0; g_block_times[2 * prof_wave + 1] = wall_clock64();
+        g_wave_rec[8 * prof_wave] = (unsigned)prof_refills; g_wave_rec[8 * prof_wave + 1] = (unsigned)prof_trips; g_wave_rec[8 * prof_wave + 2] = (unsigned)prof_maxit;
+        g_wave_rec[8 * prof_wave + 3] = (unsigned)(prof_w1 - prof_w0);
+    }
+#endif
+}
+
 // env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
 __device__ inline void commit_staged(const DScene &S, const DState &st, int e, float *row) {
     const int B = S.B;
@@ -2107,6 +2224,8 @@ struct smr_env {
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
     int job_blocks = 0;               // their persistent grid: one 512-lane block per CU
     int job_block_lanes = 512;        // (SMR_JOB_BLOCK_LANES: 256 / 128 for measurements)
+    bool job_pool = false;            // jobs_pool_kernel (prepared runs in LDS) instead of jobs_kernel for the pair jobs (SMR_JOB_POOL)
+    int job_refill_idle = 16;         // ... its refill threshold (SMR_JOB_REFILL_IDLE)
     // lanes per block of brake_check: one wavefront - with three wavefronts per SIMD a 4-wavefront block rarely finds its four slots at
     // once (560 of 768 blocks resident; 256 -> 128 -> 64 lanes: 1.58 -> 1.42 -> 1.39 ms).  SMR_BRAKE_BLOCK, read at smr_create
     int brake_block = 64;
@@ -2481,6 +2600,14 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         env->job_blocks = std::max(prop.multiProcessorCount, 1) * (B <= 32768 ? 2 : 1);
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         if (const char *v = getenv("SMR_JOB_BLOCK_LANES")) if (atoi(v) == 256 || atoi(v) == 512 || atoi(v) == 128) env->job_block_lanes = atoi(v);
+        if (const char *v = getenv("SMR_JOB_POOL")) env->job_pool = atoi(v) != 0;
+        if (const char *v = getenv("SMR_JOB_REFILL_IDLE")) if (atoi(v) >= 1 && atoi(v) <= 64) env->job_refill_idle = atoi(v);
+        if (env->job_pool) {          // tables + one pool per wavefront: more than the 64 KB a kernel gets without asking
+            const int lds = (int)(env->job_lds_bytes + 8 * 64 * kRunWords * 4);
+            if (hipFuncSetAttribute((const void *)jobs_pool_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+                hipFuncSetAttribute((const void *)jobs_pool_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { env->err = "hipFuncSetAttribute failed"; return fail(SMR_E_HIP); }
+            if (!getenv("SMR_JOB_BLOCKS")) env->job_blocks = std::max(prop.multiProcessorCount, 1);      // the pools leave room for one block per CU
+        }
         env->self_job_blocks = std::max(8, std::min(env->job_blocks, (int)((B + 1023) / 1024)));      // ~40 jobs per wavefront
         if (const char *v = getenv("SMR_SELF_JOB_BLOCKS")) if (atoi(v) > 0) env->self_job_blocks = atoi(v);
         // the item part of the enumerate grid: one round for the usual 1.2 items per (env, body) - every round of a wavefront ends with a
@@ -2885,7 +3012,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         if (env->hscene.jobs_on) {
             if (env->hscene.planets_jobs) {
                 LaunchTimer tj(env, SMR_K_JOBS);
-                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                if (env->job_pool) {
+                    const size_t lds = env->job_lds_bytes + (size_t)(env->job_block_lanes >> 6) * 64 * kRunWords * 4;
+                    const int off = (int)(env->job_lds_bytes / 4);
+                    if (self) hipLaunchKernelGGL((jobs_pool_kernel<true>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
+                    else hipLaunchKernelGGL((jobs_pool_kernel<false>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
+                } else if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st);
                 else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st);
             }
             // (beside the jobs kernel on a stream of its own - its flags are final once the lists are written, its results commute with

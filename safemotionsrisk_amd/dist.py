@@ -146,6 +146,43 @@ class ShardedRollout:
                 if w is not None:
                     w.wait()
 
+    def _checksums(self, obs, rew, done):
+        """exact, order-independent sums of the raw bytes of one shard's (obs, reward, done): int64 [3]"""
+        t = self.torch
+        return t.stack([obs.contiguous().view(t.int32).sum(dtype=t.int64), rew.contiguous().view(t.int32).sum(dtype=t.int64),
+                        done.sum(dtype=t.int64)])
+
+    def verify(self, actions):
+        """Self-check of the exchange, meant to run before anything is timed or consumed: two steps (in overlap mode the gather of the
+        first is in flight while the second runs), then every rank's checksums of its LOCAL (obs, reward, done) are exchanged in one small
+        all-gather of 3 x int64 per rank and compared with the checksums of the slice every other rank received.  Returns the list of
+        (step, rank) pairs whose slice on THIS rank differs from what that rank wrote (empty: the exchange is sound).  A broken
+        overlap - a slot written while its collective still reads it, a gather that has not landed when it is read - shows up here
+        as a mismatch instead of as a silently wrong batch."""
+        t, bad = self.torch, []
+        pending = []
+        for a in actions[:2]:
+            loc = self._locals[self._slot] if self.overlap else self.local
+            pending.append((self.step(a), loc))
+            if not self.overlap:                        # (synchronous mode re-uses one buffer: check each step before the next overwrites it)
+                bad += self._compare(len(pending) - 1, *pending[-1])
+        if self.overlap:
+            self.wait()
+            for k, (batch, loc) in enumerate(pending):
+                bad += self._compare(k, batch, loc)
+        return bad
+
+    def _compare(self, k, batch, loc):
+        t = self.torch
+        parts = batch.wait() if isinstance(batch, GatheredBatch) else batch
+        mine = self._checksums(loc.obs, loc.reward, loc.done)
+        if self.host_gather:
+            mine = mine.cpu()
+        theirs = t.zeros(self.world * 3, dtype=t.int64, device=mine.device)
+        self.dist.all_gather_into_tensor(theirs, mine, group=self.group)
+        theirs = theirs.view(self.world, 3).cpu()
+        return [(k, r) for r in range(self.world) if not t.equal(self._checksums(*parts[r]).cpu(), theirs[r])]
+
     def concatenated(self, parts):
         t = self.torch
         return (t.cat([p[0] for p in parts]), t.cat([p[1] for p in parts]), t.cat([p[2] for p in parts]))

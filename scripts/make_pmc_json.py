@@ -2,7 +2,9 @@
 hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM section: rocprofv3 reports KiB and gfx950 counts a 128-B
 fetch as 64 B); lane_utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) (the share of the issued VALU lanes switched on).
 usage: make_pmc_json.py out.json config envs_per_gpu checks dir1 [dir2 ...]"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (csrc_sha256: the kernel sources these counters belong to; bench.load_pmc refuses any other)
 out, config, envs, checks, roots = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5:]
 
 
@@ -46,7 +48,7 @@ for k in sorted(acc):
     kernels[k] = d
 json.dump({"command": "rocprofv3 --kernel-trace --output-format csv --pmc <counters> -- python3 bench.py --config %s --steps 40 --warmup 5 --no-cpu-baseline "
                       "(one pass per counter group)" % config,
-           "run": {"config": config, "envs_per_gpu": envs, "collision_checks_per_step": checks},
+           "run": {"config": config, "envs_per_gpu": envs, "collision_checks_per_step": checks, "csrc_sha256": bench.csrc_sha256()},
            "units": "mean per launch; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                     "(gfx950: FETCH_SIZE counts 128-B requests at 64 B, MI355X_MICROARCH.md \"HBM\"); SQ_*_CYCLES in quad-cycles",
            "kernels": kernels}, open(out, "w"), indent=1)

@@ -80,6 +80,31 @@ def _worker(rank, world, port, q):
             ok &= torch.equal(batch[r][0], ref.obs) and torch.equal(batch[r][2], ref.done)
         ok &= batch.work is None                        # consumed by the read
         ok &= env2.obs.data_ptr() in (roll2._locals[0].flat.data_ptr(), roll2._locals[1].flat.data_ptr())
+        # the self-check bench.py runs before its timed region: sound exchanges pass in both modes ...
+        for overlap in (False, True):
+            env3 = StubEnv(rank, hi - lo, 23)
+            roll3 = ShardedRollout(env3, overlap=overlap)
+            roll3.reset()
+            ok &= roll3.verify([torch.zeros(env3.num_envs, 7)] * 2) == []
+        # ... and a rank whose gathered copy of rank 1's slice differs from what rank 1 wrote is reported (here: rank 0 corrupts its copy)
+        env4 = StubEnv(rank, hi - lo, 23)
+        roll4 = ShardedRollout(env4, overlap=True)
+        roll4.reset()
+        orig = roll4.dist.all_gather_into_tensor
+
+        class Corrupting:
+            def __init__(self, d): self.d = d
+            def __getattr__(self, k): return getattr(self.d, k)
+            def all_gather_into_tensor(self, out, inp, group=None, async_op=False):
+                w = orig(out, inp, group=group, async_op=False)
+                if rank == 0 and out.dtype == torch.uint8:
+                    out[inp.numel() + 5] ^= 0x40                       # one bit of rank 1's observations, as received by rank 0
+                class Done:
+                    def wait(self): return True
+                return Done() if async_op else w
+        roll4.dist = Corrupting(roll4.dist)
+        found = roll4.verify([torch.zeros(env4.num_envs, 7)] * 2)
+        ok &= (found == [(0, 1), (1, 1)]) if rank == 0 else (found == [])
         obs, rew, done = roll.concatenated(parts)
         ok &= obs.shape == (world * env.num_envs, 23) and rew.shape == (world * env.num_envs,) and done.dtype == torch.uint8
         # the env writes straight into the packed buffer (no staging copy)

@@ -203,6 +203,8 @@ def _overlap_worker(port, out_path):
             held = (parts, expect)
         roll.wait(); torch.cuda.synchronize()
         ok &= bool(torch.equal(held[0][0][0], held[1][0]))
+        # the self-check bench.py --gpus N runs before its timed region (checksums through RCCL, int64 on the device)
+        ok &= roll.verify([acts[0], acts[1]]) == []
         env.synchronize(); ref.synchronize()
         env.close(); ref.close()
         with open(out_path, "w") as f:
