@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SMR_ABI_VERSION 9
+#define SMR_ABI_VERSION 10
 
 #define SMR_OK 0
 #define SMR_E_INVALID (-1)      /* bad argument / unsupported scene            */
@@ -176,7 +176,8 @@ int smr_mlp_forward(smr_mlp_t *mlp, const float *x_dev, int32_t ldx, float *y_de
  * planned, risk = risk_network([risk observation, action]); where risk >= threshold the deterministic action of the backup
  * policy for the risk observation (the first 7 outputs) replaces it.  The risk observation is the observation without the
  * target-point columns (obs.py:419-431).  risk: input obs_size - target columns + 7, one output; backup: input obs_size - target
- * columns, >= 7 outputs.  Pass NULL networks to switch it off.  The handles must outlive the env's use of them. */
+ * columns, >= 7 outputs.  Pass NULL networks to switch it off (risk alone may be NULL for SMR_RISK_SIMULATE_BACKUP_TRAJECTORY, which
+ * rates by simulation only).  The handles must outlive the env's use of them. */
 int smr_set_risk_networks(smr_env_t *env, smr_mlp_t *risk, smr_mlp_t *backup, float risk_threshold);
 /* A risk network WITHOUT an action input (risk_config.json "action_size": null; its input is the risk observation alone) rates a
  * state; risk_state_config (base.py:73-83,174) says which: */
@@ -185,8 +186,31 @@ int smr_set_risk_networks(smr_env_t *env, smr_mlp_t *risk, smr_mlp_t *backup, fl
 #define SMR_RISK_NEXT_KINEMATIC 1     /* RISK_CHECK_NEXT_STATE_KINEMATIC_FORECASTING: the next step's kinematic columns for the requested
                                          action, the rest as now (base.py:1507-1517, obs.py:192-231) */
 #define SMR_RISK_NEXT_FULL 2          /* RISK_CHECK_NEXT_STATE_FULL_FORECASTING: the planets / the ball one step on as well */
-/* (3, 4 - RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP[_AND_BACKUP_TRAJECTORY], a background copy of the env stepped ahead - are refused) */
+#define SMR_RISK_SIMULATE_NEXT_STEP 3  /* RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP: a background copy of the env is stepped with the action; a
+                                         collision there is risk 1, else the network rates the copy's risk observation (base.py:1520-1556) */
+#define SMR_RISK_SIMULATE_BACKUP_TRAJECTORY 4 /* RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP_AND_BACKUP_TRAJECTORY: ... then `backup_steps` actions of
+                                         the backup policy; risk 1 if the copy ends in a collision, else 0 - no risk network (base.py:1529-1577) */
+/* (3 and 4 need the background copy: smr_set_risk_rollout) */
 int smr_set_risk_state_config(smr_env_t *env, int32_t risk_state_config);
+/* The background copy of the env - the reference's "backup client" (switch_to_backup_client / switch_back_to_main_client,
+ * base.py:1801-1842; its uses base.py:1518-1577 and 1605-1650).  `shadow` is a second handle of the SAME scene with auto_reset = 0 and
+ * episode_steps = backup_steps + 1 (the copy's trajectory_length = backup_steps + 2, base.py:1819), created by the caller with the same
+ * num_envs, seed, env_index_base, device and stream; smr_step(env) then, on the device and before the action is planned:
+ *   copies the envs' state into the shadow (step counter 0), steps the shadow with the requested action and - mode 4, or ground truth -
+ *   `backup_steps` more times with the backup policy's action for the shadow's risk observation, and notes per env whether the copy
+ *   ended in a collision (a termination other than the trajectory length); the env itself is not touched.
+ * Every random draw of the library is keyed by (seed, env, counter), so the copy sees the balls and target points the env itself will
+ * see: the reference's risk_state_deterministic_backup_trajectory = True; with False the reference draws independent ones.
+ * ignore_probability: risk_ignore_estimation_probability, base.py:1652-1655 - a risky rating is dropped with this probability (a draw
+ *   keyed by the env's reset and step counters).
+ * Ground truth (risk_store_ground_truth, base.py:1567-1586,1605-1650; NULL: off), written by every smr_step, rows float32:
+ *   gt_state_action_dev [B][R + 7 + 3]: risk observation before the step | requested action | risk label | risk prediction | valid
+ *       (mode 4: the reference's "state_action_risk" table; modes -1 .. 3: its single table - state-risk networks of modes 1 - 3 carry
+ *       the copy's risk observation after the first simulated step instead, valid only if that step did not end the copy's episode)
+ *   gt_state_dev [B][R + 2] (mode 4 only, "state_risk"): the copy's risk observation after the first simulated step | risk label | valid
+ * R = obs_size - target-point columns.  shadow = NULL switches the copy off (modes 3 / 4 then fail at smr_step). */
+int smr_set_risk_rollout(smr_env_t *env, smr_env_t *shadow, int32_t backup_steps, float ignore_probability,
+                         float *gt_state_action_dev, float *gt_state_dev);
 
 /* ---- component entry points (parity tests): each runs the same device functions the step kernels
  * use on n host-provided inputs and copies the results back; all synchronise ---- */

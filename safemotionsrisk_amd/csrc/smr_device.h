@@ -245,6 +245,9 @@ struct DState {
     int *job_next;                     // [1] the next job of the list nobody has taken yet (jobs_kernel), cleared by plan_kernel
     int job_cap;                       // capacity of jobs[]
     int *overflow_env;                 // [B] 1: a job of this env found the list full - overflow_kernel evaluates ALL its queries itself
+    float *defer;                      // [defer_cap][kDeferWords] runs that left their lane unsettled ("deferred runs"): jobs_kernel -> jobs_coop_kernel
+    int *defer_count;                  // [1] cleared by plan_kernel
+    int defer_cap;
 };
 
 enum { kSamplingStart = 1, kSamplingPlanetPhase = 2, kSamplingBallLaunch = 4, kSamplingBallTarget = 8, kSamplingTargetPoint = 16,
@@ -1012,7 +1015,7 @@ struct GjkRun {
     F3 w0, w1, w2, w3, v;
     float vv, cutoff2, stop2;
     int n, it, stalls, hint_a, hint_b;
-#ifdef SMR_PROFILE_ROWS
+#ifdef SMR_PROFILE_TRIP
     unsigned long long pc_sa = 0, pc_sb = 0, pc_rest = 0;      // wavefront cycles inside the two support calls / the rest of gjk_iterate
 #endif
     __device__ __forceinline__ void start(F3 v0, float cutoff, float stop_below) {
@@ -1033,7 +1036,7 @@ __device__ __forceinline__ bool gjk_iterate(GjkRun &g, const SA &sa, const SB &s
     SMR_CNT(3);
     SMR_CNT(4);
     const bool first = g.it == 0;
-#ifdef SMR_PROFILE_ROWS
+#ifdef SMR_PROFILE_TRIP
     const unsigned long long pt0 = SMR_DEV_CLOCK();
     const F3 wa = sa(neg(g.v), g.hint_a, first);
     const unsigned long long pt1 = SMR_DEV_CLOCK();
@@ -2031,6 +2034,7 @@ struct JobLane {
     const float *av; int ac;     // the scanned side: padded vertex list in LDS (ac == 0: a world-fixed cylinder, av = centre xyz, radius, half length)
     float margins;
     bool is_static;
+    int hull_body;               // whose hull `hull` is (deferred runs name it)
 };
 
 // Lower bound of the distance of self-collision pair i (wave uniform) at joint vector q from its bound table, bounding spheres and
@@ -2090,7 +2094,7 @@ __device__ inline void self_job_setup(const DScene &S, const BodyPool &BP, const
         const DPiece LA = BP.piece(a);
         if (partner >= 0) {
             const DPiece LP = BP.piece(partner);
-            J.hull = BP.hull(partner);
+            J.hull = BP.hull(partner); J.hull_body = partner;
             J.XA = inv_compose(Tp, Ta);
             J.T = Tp;
             J.av = (const float *)BP.pool + BP.pool[kBodyPoolHead * a];
@@ -2100,7 +2104,7 @@ __device__ inline void self_job_setup(const DScene &S, const BodyPool &BP, const
             J.g.start(apply(J.XA, F3{LA.cx, LA.cy, LA.cz}) - F3{LP.cx, LP.cy, LP.cz}, cutoff + J.margins, stop_below + J.margins);
         } else {
             const float *c = cyl + 8 * S.self_cyl_slot[pair];
-            J.hull = BP.hull(a);
+            J.hull = BP.hull(a); J.hull_body = a;
             J.T = Ta;
 #pragma unroll
             for (int i = 0; i < 9; ++i) J.XA.r[i] = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
@@ -2136,7 +2140,7 @@ __device__ inline void job_setup(const DScene &S, const BodyPool &BP, const floa
         J.T.r[8] = f2[0]; J.T.t = F3{f2[1], f2[2], f2[3]};
     }
     const DPiece LP = BP.piece(jb.body);
-    J.hull = BP.hull(jb.body);
+    J.hull = BP.hull(jb.body); J.hull_body = jb.body;
     const float *d = pd + kPlanetDescDwords * jb.piece;
     J.av = pv + 4 * __float_as_int(d[0]);
     J.ac = __float_as_int(d[1]);
@@ -2196,6 +2200,118 @@ __device__ __forceinline__ bool job_trip(JobLane &J, float &dist) {
     return true;
 }
 
+// ---- deferred runs (round 4): the long runs leave the lanes ---------------------------------------
+// A run that has not settled after `defer_after` iterations in its lane is written out as a record and finished by jobs_coop_kernel,
+// where a GROUP OF 16 LANES (one DPP row) works one run: every lane tests a sixteenth of each side's vertices (no hill climb: 252 vertices
+// are sixteen per lane, read at consecutive addresses), two row reductions give the support points, and the sub-simplex solve runs on
+// values the 16 lanes hold alike - the loops have fixed trip counts and every lane has work, so sixteen wavefronts per CU hide each
+// other's latencies, which the lane form's 15 000-cycle trips of 64 unrelated runs never could.  The lanes that drew short runs no
+// longer wait for the one in twenty that needs 6 to 18 iterations: the lane form's span is bounded by `defer_after` trips per hand-out.  Which form computes an iteration is a function of the run alone (its iteration count), not of what
+// its neighbours in the wavefront do: the step stays deterministic.
+// Record: kDeferWords dwords, 16-byte aligned:
+//   0..11 frame (scanned side seen from the hull's frame; world-frame runs: the hull body's world frame)   12..14 v   15 cutoff^2   16 stop^2
+//   17 margins   18 the env's minimum when the job was drawn   19 meta (run_meta)   20..21 job word   22..33 simplex   34 n | it << 8 | stalls << 16
+constexpr int kDeferWords = 36;
+__device__ __forceinline__ unsigned run_meta(int av_off, int ac, int hull_body, bool is_static, bool mov, bool con) {
+    return (unsigned)av_off | ((unsigned)ac << 16) | ((unsigned)hull_body << 25) | ((unsigned)is_static << 29) | ((unsigned)mov << 30) | ((unsigned)con << 31);
+}
+#ifndef SMR_HOST_EMUL
+__device__ inline void defer_write(SMR_GLOBAL V4 *rec, const JobLane &J, const float *lds0, unsigned long long word, bool mov, bool con, float seen) {
+    const Xf &X = J.is_static ? J.T : J.XA;
+    const GjkRun &g = J.g;
+    rec[0] = V4{X.r[0], X.r[1], X.r[2], X.r[3]}; rec[1] = V4{X.r[4], X.r[5], X.r[6], X.r[7]}; rec[2] = V4{X.r[8], X.t.x, X.t.y, X.t.z};
+    rec[3] = V4{g.v.x, g.v.y, g.v.z, g.cutoff2};
+    rec[4] = V4{g.stop2, J.margins, seen, __int_as_float((int)run_meta((int)(J.av - lds0), J.ac, J.hull_body, J.is_static, mov, con))};
+    rec[5] = V4{__int_as_float((int)(unsigned)(word & 0xFFFFFFFFull)), __int_as_float((int)(unsigned)(word >> 32)), g.w0.x, g.w0.y};
+    rec[6] = V4{g.w0.z, g.w1.x, g.w1.y, g.w1.z};
+    rec[7] = V4{g.w2.x, g.w2.y, g.w2.z, g.w3.x};
+    rec[8] = V4{g.w3.y, g.w3.z, __int_as_float(g.n | (g.it << 8) | (g.stalls << 16)), 0.f};
+}
+
+// arg max over the 16 lanes of a DPP row (a quarter wavefront): every lane brings its best (value, index) and gets the index of the largest
+// value back, ties to the lowest index.  Four rotations each for the maximum and for the smallest index that attains it: v_max_f32 /
+// v_min_i32 with a DPP operand, no LDS crossbar, ~8 dependent VALU instructions.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false)); }
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int row_argmax(float best, int bi) {
+    float m = best;
+    m = fmaxf(m, dpp_f<0x128>(m)); m = fmaxf(m, dpp_f<0x124>(m)); m = fmaxf(m, dpp_f<0x122>(m)); m = fmaxf(m, dpp_f<0x121>(m));     // row_ror:8, 4, 2, 1
+    int k = best == m ? bi : 0x7FFFFFFF;
+    k = min(k, dpp_i<0x128>(k)); k = min(k, dpp_i<0x124>(k)); k = min(k, dpp_i<0x122>(k)); k = min(k, dpp_i<0x121>(k));
+    return k;
+}
+
+// One iteration of a deferred run, worked by a GROUP of 16 lanes (gjk_iterate's tests in gjk_iterate's order on group-uniform values):
+// every lane tests a sixteenth of each side's vertices, two row reductions give the support points, the sub-simplex solve runs on
+// values all 16 lanes hold alike.  Returns true when the run has settled; dist as gjk_iterate reports it (margins not subtracted).
+template <bool SELF>
+__device__ __forceinline__ bool coop_iterate(GjkRun &g, const Xf &X, bool is_static, const float *av, int ac, const float *hv, int hcount, float &dist) {
+    const int l16 = (int)__lane_id() & 15;
+    const F3 nv = neg(g.v);
+    F3 pa;
+    if (SELF && ac == 0) {                               // btCylinderShapeZ::localGetSupportingVertexWithoutMargin, world frame (job_trip)
+        const float sxy = sqrtf(nv.x * nv.x + nv.y * nv.y), r = av[3];
+        pa = sxy > 0.f ? F3{av[0] + r * nv.x / sxy, av[1] + r * nv.y / sxy, av[2]} : F3{av[0] + r, av[1], av[2]};
+        pa.z += nv.z < 0.f ? -av[4] : av[4];
+    } else {
+        const F3 dl = is_static ? nv : rot_t(X, nv);
+        float best = -3.0e38f;
+        int bi = 0;
+        for (int i = l16; i < ac; i += 16) {
+            const float *q = av + 4 * i;
+            const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
+            if (sq > best) { best = sq; bi = i; }
+        }
+        const int ia = row_argmax(best, bi);
+        const F3 p = {av[4 * ia], av[4 * ia + 1], av[4 * ia + 2]};
+        pa = is_static ? p : apply(X, p);
+    }
+    F3 pb;
+    {
+        const F3 dl = is_static ? rot_t(X, g.v) : g.v;
+        float best = -3.0e38f;
+        int bi = 0;
+        for (int i = l16; i < hcount; i += 16) {
+            const float *q = hv + 4 * i;
+            const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
+            if (sq > best) { best = sq; bi = i; }
+        }
+        const int ib = row_argmax(best, bi);
+        const F3 p = {hv[4 * ib], hv[4 * ib + 1], hv[4 * ib + 2]};
+        pb = is_static ? apply(X, p) : p;
+    }
+    const F3 w = pa - pb;
+    const float vw = dot(g.v, w);
+    if (vw > 0.f && vw * vw > g.cutoff2 * g.vv) { dist = vw / sqrtf(g.vv); return true; }
+    bool settled = g.n > 0 && (g.vv - vw) <= 1e-6f * g.vv;
+    if (!settled) {
+        const F3 e0 = w - g.w0, e1 = w - g.w1, e2 = w - g.w2;
+        const float tiny = 1e-12f * fmaxf(dot(w, w), 1e-6f);
+        settled = (g.n > 0 && dot(e0, e0) <= tiny) || (g.n > 1 && dot(e1, e1) <= tiny) || (g.n > 2 && dot(e2, e2) <= tiny);
+    }
+    if (!settled) {
+        const int slot = g.n;
+        g.w0 = sel3(slot == 0, w, g.w0); g.w1 = sel3(slot == 1, w, g.w1); g.w2 = sel3(slot == 2, w, g.w2); g.w3 = sel3(slot >= 3, w, g.w3);
+        ++g.n;
+        F3 vn;
+        if (simplex_solve(g.w0, g.w1, g.w2, g.w3, g.n, vn)) { dist = 0.f; return true; }
+        const float vvn = dot(vn, vn);
+        if (!(vvn == vvn)) settled = true;
+        else if (g.it > 0 && vvn >= g.vv && (vvn > g.vv * (1.0f + 4e-7f) || ++g.stalls > 3)) settled = true;
+        else {
+            g.v = vn;
+            g.vv = vvn;
+            if (g.vv <= g.stop2) settled = true;
+            else if (g.n == 4) { dist = 0.f; return true; }
+        }
+    }
+    if (settled || ++g.it >= 32) { dist = sqrtf(g.vv); return true; }
+    return false;
+}
+#endif
+
 // ---- prepared runs (jobs kernel, round 4) -----------------------------------------------------
 // A job is SET UP by whichever lane draws it - all 64 lanes of a wavefront set up 64 jobs at once, whatever their own runs are doing -
 // and the result waits in the wavefront's LDS pool until a lane whose run has settled takes it.  Setting up (state loads, the body's
@@ -2215,9 +2331,6 @@ struct PoolLane {
     float margins;
     bool is_static;
 };
-__device__ __forceinline__ unsigned run_meta(int av_off, int ac, int hull_body, bool is_static, bool mov, bool con) {
-    return (unsigned)av_off | ((unsigned)ac << 16) | ((unsigned)hull_body << 25) | ((unsigned)is_static << 29) | ((unsigned)mov << 30) | ((unsigned)con << 31);
-}
 // lds0: base of the block's dynamic LDS (what the av offsets are relative to)
 template <bool SELF>
 __device__ inline void run_prepare(const DScene &S, const BodyPool &BP, const float *pv, const float *pd, const float *cyl, const float *lds0,

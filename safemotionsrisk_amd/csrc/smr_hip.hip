@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
         }
         st.env_dself[e] = dist_bits(S.static_max);
         st.overflow_env[e] = 0;
-        if (e == 0) { *st.item_count = 0; *st.job_count = 0; *st.job_next = 0; }
+        if (e == 0) { *st.item_count = 0; *st.job_count = 0; *st.job_next = 0; *st.defer_count = 0; }
     }
     float u = actions[(size_t)e * SMR_NJ + j];
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
 // asking for the next chunk when 16 / 32 / 48 lanes have settled so that the counter's round trip runs beside the last trips
 // (slower the earlier it asks: the chunk then waits for the wavefront's longest run while other wavefronts are idle).
 template <bool SELF>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st, int defer_after) {
     const DScene &S = *Sp;
 #ifdef SMR_PROFILE_ROWS
     const unsigned long long pc0 = SMR_DEV_CLOCK();
@@ -601,11 +601,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     bool active = false, mov = false, con = false, first = true;
     bool dry = (long long)n_waves * quota >= (long long)n_jobs;              // (for every ask after the first hand-out)
     Job jb = {0, 0, 0, 0, 0};
+    unsigned long long jword = 0ull;
     float seen = 0.f;
     JobLane J;
     J.g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);               // defined state for the lanes that never get a job
     J.XA = Xf{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, F3{0.f, 0.f, 0.f}}; J.T = J.XA;
-    J.hull = JT.BP.hull(0); J.av = JT.pv; J.ac = 0; J.margins = 0.f; J.is_static = false;
+    J.hull = JT.BP.hull(0); J.av = JT.pv; J.ac = 0; J.margins = 0.f; J.is_static = false; J.hull_body = 0;
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         const int n_idle = __popcll(idle);
@@ -628,7 +629,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #endif
             const int rank = __popcll(idle & ((1ull << lane) - 1ull)), j = base + rank;
             if (!active && rank < take && j < n_jobs) {
-                jb = job_unpack(st.jobs[j]);
+                jword = st.jobs[j];
+                jb = job_unpack(jword);
                 const LaneInput in = load_lane_input(S, st, jb.env);
                 job_flags(S, in, jb.body, mov, con);
                 if (jb.kind == kJobItem) { mov = false; con = true; }
@@ -659,8 +661,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #ifdef SMR_PROFILE_ROWS
         int prof_its = 0;
         prof_lanes += __popcll(__ballot(active));
+#ifdef SMR_PROFILE_TRIP      // (-DSMR_PROFILE_ROWS -DSMR_PROFILE_TRIP: clocks around the two support calls of every iteration - they double the trip)
         const int prof_src = __ffsll((long long)__ballot(active)) - 1;      // a lane that takes part in this trip: its clock deltas are the wavefront's
         const unsigned long long sa0 = __shfl(J.g.pc_sa, prof_src), sb0 = __shfl(J.g.pc_sb, prof_src), rest0 = __shfl(J.g.pc_rest, prof_src);
+#endif
         { const int nn = J.g.n; prof_n[0] += __popcll(__ballot(active && nn <= 1)); prof_n[1] += __popcll(__ballot(active && nn == 2)); prof_n[2] += __popcll(__ballot(active && nn == 3)); }
 #endif
         if (active && job_trip<SELF>(J, d)) {
@@ -671,9 +675,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
             prof_its = J.g.it + 1;
 #endif
         }
+        // a run that has used up its iterations in the lane form leaves as a record for jobs_coop_kernel (smr_device.h, "deferred runs"):
+        // one atomic per wavefront and trip that has such runs, i.e. one per hand-out
+        {
+            const bool leave = active && defer_after > 0 && J.g.it >= defer_after;
+            const unsigned long long lm = __ballot(leave);
+            if (lm) {
+                const int src = __ffsll((long long)lm) - 1;
+                int base = 0;
+                if (lane == src) base = atomicAdd(st.defer_count, __popcll(lm));
+                base = __builtin_amdgcn_readlane(base, src);
+                const int slot = base + __popcll(lm & ((1ull << lane) - 1ull));
+                if (leave && slot < st.defer_cap) {          // (a full list: the run simply stays where it is)
+                    defer_write((SMR_GLOBAL V4 *)st.defer + (size_t)slot * (kDeferWords / 4), J, (const float *)job_lds, jword, mov, con, seen);
+                    active = false;
+                }
+            }
+        }
 #ifdef SMR_PROFILE_ROWS
         pc_trip += SMR_DEV_CLOCK() - t1;
+#ifdef SMR_PROFILE_TRIP
         pc_sa += __shfl(J.g.pc_sa, prof_src) - sa0; pc_sb += __shfl(J.g.pc_sb, prof_src) - sb0; pc_rest += __shfl(J.g.pc_rest, prof_src) - rest0;
+#endif
         prof_hist[0] += __popcll(__ballot(prof_its == 1)); prof_hist[1] += __popcll(__ballot(prof_its == 2));
         prof_hist[2] += __popcll(__ballot(prof_its == 3 || prof_its == 4)); prof_hist[3] += __popcll(__ballot(prof_its >= 5 && prof_its <= 8));
         prof_hist[4] += __popcll(__ballot(prof_its >= 9));
@@ -695,6 +718,62 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
         g_wave_rec[8 * prof_wave + 3] = (unsigned)(prof_w1 - prof_w0);
     }
 #endif
+}
+
+// jobs_coop kernel: the deferred runs, one group of 16 lanes per run (smr_device.h, "deferred runs").  The grid is persistent - one
+// 1024-lane block per CU, sixteen wavefronts = 64 groups - and stages the tables of the jobs kernel at the same LDS offsets (the records
+// name the scanned side by offset).  Group g takes the records g, g + G, g + 2 G ...: when its run has settled it loads the next record
+// (all 16 lanes read the same 144 bytes) while the other groups of its wavefront go on iterating.  No counter: a run costs 1 to 13
+// iterations, a few runs per group even out.
+template <bool SELF>
+__global__ __launch_bounds__(1024) void jobs_coop_kernel(const DScene *__restrict__ Sp, DState st) {
+    const DScene &S = *Sp;
+    const int count = *st.defer_count, n_def = count < st.defer_cap ? count : st.defer_cap;
+    if (n_def <= 0) return;                                // (block uniform: no barrier is skipped by part of a block)
+    const JobTables JT = stage_job_tables(S);
+    const float *lds0 = (const float *)job_lds;
+    const int G = (int)gridDim.x * (int)(blockDim.x >> 4);
+    int next = (int)blockIdx.x * (int)(blockDim.x >> 4) + (int)(threadIdx.x >> 4);
+    const bool head = (threadIdx.x & 15) == 0;
+    bool active = false, is_static = false, mov = false, con = false;
+    GjkRun g;
+    g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);
+    Xf X = Xf{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, F3{0.f, 0.f, 0.f}};
+    const float *av = lds0, *hv = lds0;
+    int ac = 0, hcount = 0;
+    float margins = 0.f, seen = 0.f;
+    Job jb = {0, 0, 0, 0, 0};
+    for (;;) {
+        if (!active && next < n_def) {
+            const SMR_GLOBAL V4 *src = (const SMR_GLOBAL V4 *)st.defer + (size_t)next * (kDeferWords / 4);
+            V4 r[kDeferWords / 4];
+#pragma unroll
+            for (int i = 0; i < kDeferWords / 4; ++i) r[i] = src[i];
+            next += G;
+            X.r[0] = r[0][0]; X.r[1] = r[0][1]; X.r[2] = r[0][2]; X.r[3] = r[0][3]; X.r[4] = r[1][0]; X.r[5] = r[1][1]; X.r[6] = r[1][2]; X.r[7] = r[1][3];
+            X.r[8] = r[2][0]; X.t = F3{r[2][1], r[2][2], r[2][3]};
+            g.v = F3{r[3][0], r[3][1], r[3][2]}; g.vv = dot(g.v, g.v); g.cutoff2 = r[3][3]; g.stop2 = r[4][0];
+            margins = r[4][1]; seen = r[4][2];
+            const unsigned meta = (unsigned)__float_as_int(r[4][3]);
+            jb = job_unpack((unsigned long long)(unsigned)__float_as_int(r[5][0]) | ((unsigned long long)(unsigned)__float_as_int(r[5][1]) << 32));
+            g.w0 = F3{r[5][2], r[5][3], r[6][0]}; g.w1 = F3{r[6][1], r[6][2], r[6][3]}; g.w2 = F3{r[7][0], r[7][1], r[7][2]}; g.w3 = F3{r[7][3], r[8][0], r[8][1]};
+            const int packed = __float_as_int(r[8][2]);
+            g.n = packed & 255; g.it = (packed >> 8) & 255; g.stalls = (packed >> 16) & 255;
+            av = lds0 + (meta & 0xFFFFu); ac = (int)((meta >> 16) & 0x1FFu);
+            const int hb = (int)((meta >> 25) & 15u);
+            is_static = (meta >> 29) & 1u; mov = (meta >> 30) & 1u; con = (meta >> 31) & 1u;
+            const uint32_t *head_w = JT.BP.pool + kBodyPoolHead * hb;
+            hv = (const float *)JT.BP.pool + head_w[0];
+            hcount = (int)JT.BP.pool[head_w[3] + 1];         // DPiece::count: the record's second dword
+            active = true;
+        }
+        if (!__any(active)) break;
+        float d;
+        if (active && coop_iterate<SELF>(g, X, is_static, av, ac, hv, hcount, d)) {
+            active = false;
+            if (head) job_result(S, st, jb, mov, con, d - margins, seen);
+        }
+    }
 }
 
 // jobs kernel, round 4: prepared runs in an LDS pool (smr_device.h, "prepared runs").  The stream, the tables and the results are those of
@@ -2171,16 +2250,95 @@ __global__ void risk_input_kernel(const DScene *__restrict__ Sp, DState st, cons
         for (int j = 0; j < SMR_NJ; ++j) rx[o + j] = actions[(size_t)e * SMR_NJ + j];
 }
 
+// threshold test of the rating (base.py:1602-1603), the backup policy's action where it objects (actions.py:327-335), and - where asked for -
+// risk_ignore_estimation_probability (base.py:1652-1655): a risky rating is dropped with probability ignore_p; the draw is keyed by the
+// env's reset and step counters (the reference draws from the global numpy stream)
+constexpr unsigned S_RISK_IGNORE = 15;
 __global__ void risk_apply_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions, const float *__restrict__ risk,
-                                  const float *__restrict__ backup, int ldb, float threshold, float *__restrict__ actions_out) {
+                                  const float *__restrict__ backup, int ldb, float threshold, float ignore_p, float *__restrict__ actions_out) {
     const DScene &S = *Sp;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= S.B) return;
-    const bool risky = risk[e] >= threshold;                                                // base.py:1602-1603
+    bool risky = risk[e] >= threshold;                                                      // base.py:1602-1603
+    if (risky && ignore_p > 0.f) {
+        const Rng rng{S.seed_lo, S.seed_hi, S.env_base + (unsigned)e, st.reset_count[e]};
+        if (rng.uniform01(S_RISK_IGNORE, (unsigned)st.step_count[e]) < ignore_p) risky = false;
+    }
     st.risky[e] = risky ? 1 : 0;
 #pragma unroll
     for (int j = 0; j < SMR_NJ; ++j)
         actions_out[(size_t)e * SMR_NJ + j] = risky ? fminf(1.f, fmaxf(-1.f, backup[(size_t)e * ldb + j])) : actions[(size_t)e * SMR_NJ + j];
+}
+
+// ---- the background copy of the env (base.py:1518-1577,1605-1650; include/safemotions_hip.h: smr_set_risk_rollout) ----
+// the envs' state -> the shadow handle's (switch_to_backup_client, base.py:1801-1823: the copy starts with _episode_length = 0)
+__global__ void rollout_snapshot_kernel(const DScene *__restrict__ Sp, DState src, DState dst, int *__restrict__ alive, int *__restrict__ outcome) {
+    const DScene &S = *Sp;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, B = S.B;
+    if (e >= B) return;
+#pragma unroll
+    for (int j = 0; j < SMR_NJ; ++j) { dst.q[j * B + e] = src.q[j * B + e]; dst.v[j * B + e] = src.v[j * B + e]; dst.a[j * B + e] = src.a[j * B + e]; }
+    dst.planet_idx[e] = src.planet_idx[e]; dst.planet_idx[B + e] = src.planet_idx[B + e];
+    dst.step_count[e] = 0;
+    dst.moving_hit[e] = src.moving_hit[e];
+    dst.reset_count[e] = src.reset_count[e]; dst.start_attempts[e] = src.start_attempts[e];
+    for (int l = 0; l < S.n_bodies; ++l) dst.lb_moving[(size_t)l * B + e] = -1.f;              // (no bound of a previous step)
+    if (S.use_ball) {
+        for (int c = 0; c < 10; ++c) dst.ball[c * B + e] = src.ball[c * B + e];
+        for (int c = 0; c < 5; ++c) dst.ball_i[c * B + e] = src.ball_i[c * B + e];
+    }
+    if (S.use_target) {
+        for (int c = 0; c < 5; ++c) dst.tp[c * B + e] = src.tp[c * B + e];
+        dst.tp_count[e] = src.tp_count[e];
+    }
+    alive[e] = 1; outcome[e] = 0;
+}
+// after simulated step i of the copy: an env whose copy is done leaves the rollout (the reference breaks out of its loop), risky unless
+// the copy's trajectory length ended it.  outcome bits: 1 the copy collided (at any step), 2 its FIRST step ended it, 4 ... by a collision
+__global__ void rollout_track_kernel(int B, int first, const uint8_t *__restrict__ done, const int8_t *__restrict__ reason, int *__restrict__ alive,
+                                     int *__restrict__ outcome) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B || !alive[e] || !done[e]) return;
+    const bool collided = reason[e] != SMR_TERMINATION_TRAJECTORY_LENGTH;
+    alive[e] = 0;
+    outcome[e] |= (collided ? 1 : 0) | (first ? 2 : 0) | ((first && collided) ? 4 : 0);
+}
+// the backup policy's deterministic action (_get_action_from_backup_action: its first 7 outputs, clipped)
+__global__ void rollout_action_kernel(int B, const float *__restrict__ backup, int ldb, float *__restrict__ actions) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * SMR_NJ) return;
+    actions[i] = fminf(1.f, fmaxf(-1.f, backup[(size_t)(i / SMR_NJ) * ldb + (i % SMR_NJ)]));
+}
+// the rating of the simulating modes (base.py:1548-1566): mode 4: 1 where the copy collided, else 0; mode 3: 1 where the copy's first step
+// collided, the network's rating of the copy's next risk observation where that step did not end the copy's episode, else no rating (0)
+__global__ void rollout_rating_kernel(int B, int mode, const int *__restrict__ outcome, const float *__restrict__ net, float *__restrict__ rating) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    const int o = outcome[e];
+    if (mode == SMR_RISK_SIMULATE_BACKUP_TRAJECTORY) rating[e] = (o & 1) ? 1.f : 0.f;
+    else rating[e] = (o & 4) ? 1.f : ((o & 2) ? 0.f : net[e]);
+}
+// risk_store_ground_truth (base.py:1567-1586,1605-1650): rows of the two tables, see smr_set_risk_rollout
+__global__ void rollout_ground_truth_kernel(int B, int R, int mode, const float *__restrict__ actions, const float *__restrict__ obs_now,
+                                            const float *__restrict__ obs_first, const int *__restrict__ outcome, const float *__restrict__ rating,
+                                            float *__restrict__ gt_sa, float *__restrict__ gt_s) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B) return;
+    const int o = outcome[e];
+    const float label = (o & 1) ? 1.f : 0.f;
+    const bool first_ok = !(o & 2);                          // the first simulated step did not end the copy's episode
+    // whose state the single table carries: the current one for a state-action network and mode 0, the copy's next one for modes 1 - 3
+    const bool next_state = mode == SMR_RISK_NEXT_KINEMATIC || mode == SMR_RISK_NEXT_FULL || mode == SMR_RISK_SIMULATE_NEXT_STEP;
+    float *row = gt_sa + (size_t)e * (R + SMR_NJ + 3);
+    const float *state = next_state ? obs_first + (size_t)e * R : obs_now + (size_t)e * R;
+    for (int c = 0; c < R; ++c) row[c] = state[c];
+    for (int j = 0; j < SMR_NJ; ++j) row[R + j] = actions[(size_t)e * SMR_NJ + j];
+    row[R + SMR_NJ] = label; row[R + SMR_NJ + 1] = rating[e]; row[R + SMR_NJ + 2] = (!next_state || first_ok) ? 1.f : 0.f;
+    if (gt_s && mode == SMR_RISK_SIMULATE_BACKUP_TRAJECTORY) {
+        float *r2 = gt_s + (size_t)e * (R + 2);
+        for (int c = 0; c < R; ++c) r2[c] = obs_first[(size_t)e * R + c];
+        r2[R] = label; r2[R + 1] = first_ok ? 1.f : 0.f;
+    }
 }
 
 }  // namespace smr
@@ -2221,9 +2379,19 @@ struct smr_env {
     int risk_state_config = SMR_RISK_CURRENT_STATE;   // what a risk network WITHOUT an action input looks at (smr_set_risk_state_config)
     int risk_mode = SMR_RISK_STATE_ACTION;            // the mode in force (state-action when the network takes the action)
     int *risky_buf = nullptr;
+    // the background copy (smr_set_risk_rollout): a second handle of the same scene that smr_step steps ahead
+    struct smr_env *shadow = nullptr;
+    int rollout_steps = 0;            // risk_state_backup_trajectory_steps
+    float risk_ignore_p = 0.f;        // risk_ignore_estimation_probability
+    float *gt_sa = nullptr, *gt_s = nullptr;                 // caller-owned ground-truth rows (or null)
+    int *ro_alive = nullptr, *ro_outcome = nullptr;
+    float *ro_first = nullptr, *ro_rollx = nullptr, *ro_riskx = nullptr, *ro_actions = nullptr, *ro_obs = nullptr, *ro_reward = nullptr, *ro_rating = nullptr;
+    uint8_t *ro_done = nullptr; int8_t *ro_reason = nullptr;
     size_t job_lds_bytes = 0;         // dynamic LDS of the first / jobs kernels (pair-job path)
     int job_blocks = 0;               // their persistent grid: one 512-lane block per CU
     int job_block_lanes = 512;        // (SMR_JOB_BLOCK_LANES: 256 / 128 for measurements)
+    int defer_after = 0;              // jobs_kernel: a run leaves its lane after this many iterations for jobs_coop_kernel (0: never; SMR_JOB_DEFER)
+    int coop_blocks = 0;              // ... whose grid is one 1024-lane block per CU
     bool job_pool = false;            // jobs_pool_kernel (prepared runs in LDS) instead of jobs_kernel for the pair jobs (SMR_JOB_POOL)
     int job_refill_idle = 16;         // ... its refill threshold (SMR_JOB_REFILL_IDLE)
     // lanes per block of brake_check: one wavefront - with three wavefronts per SIMD a 4-wavefront block rarely finds its four slots at
@@ -2589,7 +2757,10 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if ((rc = dev_alloc(env, &st.keyw, pj ? 7 * NB * B : 1)) || (rc = dev_alloc(env, &st.env_best, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_min, pj ? B : 1)) ||
             (rc = dev_alloc(env, &st.env_dstatic, pj ? B : 1)) || (rc = dev_alloc(env, &st.frames, pj ? 12 * NB * B : 4)) || (rc = dev_alloc(env, &st.env_dself, B)) || (rc = dev_alloc(env, &st.items, (pj && N > 1) ? B * NB * (N - 1) : 1)) ||
             (rc = dev_alloc(env, &st.jobs, std::max<size_t>(cap, 1))) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) || (rc = dev_alloc(env, &st.job_next, 1)) ||
-            (rc = dev_alloc(env, &st.overflow_env, B))) return fail(rc);
+            (rc = dev_alloc(env, &st.overflow_env, B)) || (rc = dev_alloc(env, &st.defer_count, 1))) return fail(rc);
+        st.defer_cap = (int)std::min<size_t>(4 * B + 4096, 1u << 22);      // up to ~2 deferred runs per env when every run leaves after its first iteration; a full list defers no more
+        if ((rc = dev_alloc(env, &st.defer, (size_t)st.defer_cap * kDeferWords))) return fail(rc);
+        if (hipMemset(st.defer_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4) || hipMemset(st.job_next, 0, 4) || hipMemset(st.overflow_env, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
@@ -2600,6 +2771,9 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         env->job_blocks = std::max(prop.multiProcessorCount, 1) * (B <= 32768 ? 2 : 1);
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         if (const char *v = getenv("SMR_JOB_BLOCK_LANES")) if (atoi(v) == 256 || atoi(v) == 512 || atoi(v) == 128) env->job_block_lanes = atoi(v);
+        if (const char *v = getenv("SMR_JOB_DEFER")) env->defer_after = std::max(0, std::min(31, atoi(v)));
+        env->coop_blocks = std::max(prop.multiProcessorCount, 1);
+        if (const char *v = getenv("SMR_COOP_BLOCKS")) if (atoi(v) > 0) env->coop_blocks = atoi(v);
         if (const char *v = getenv("SMR_JOB_POOL")) env->job_pool = atoi(v) != 0;
         if (const char *v = getenv("SMR_JOB_REFILL_IDLE")) if (atoi(v) >= 1 && atoi(v) <= 64) env->job_refill_idle = atoi(v);
         if (env->job_pool) {          // tables + one pool per wavefront: more than the 64 KB a kernel gets without asking
@@ -2943,18 +3117,62 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     }
     if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
     const float *planned_actions = actions_dev;         // what the plan kernel maps into the safe range
-    if (env->risk_net) {                                // actions.py:303-340: the backup policy's action where the risk network objects
+    if (env->backup_net) {                              // actions.py:303-340: the backup policy's action where the risk rating objects
         LaunchTimer t(env, SMR_K_RISK);
         const int robs = env->obs_size - env->hscene.obs_target_size, ldx = robs + SMR_NJ, ldb = env->backup_net->d.out_size;
-        if (env->risk_mode == SMR_RISK_NEXT_KINEMATIC || env->risk_mode == SMR_RISK_NEXT_FULL)      // the forecast needs the requested action's end acceleration
+        const int mode = env->risk_mode;
+        const bool simulate = mode == SMR_RISK_SIMULATE_NEXT_STEP || mode == SMR_RISK_SIMULATE_BACKUP_TRAJECTORY;
+        const bool want_gt = env->gt_sa != nullptr;
+        if ((simulate || want_gt) && !env->shadow) { env->err = "smr_step: this risk mode steps a background copy of the env - smr_set_risk_rollout first"; return SMR_E_INVALID; }
+        if (!simulate && !env->risk_net) { env->err = "smr_step: no risk network"; return SMR_E_INVALID; }
+        const dim3 egrid((B + 255) / 256), mgrid((B + kMlpRows - 1) / kMlpRows);
+        if (mode == SMR_RISK_NEXT_KINEMATIC || mode == SMR_RISK_NEXT_FULL)      // the forecast needs the requested action's end acceleration
             hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
-        hipLaunchKernelGGL(risk_input_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, env->risk_x, ldx, env->backup_x, robs,
-                           env->risk_mode);
-        const dim3 mgrid((B + kMlpRows - 1) / kMlpRows);
-        hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->risk_net->d, (const float *)env->risk_x, ldx, env->risk_y, 1, B);
+        // the network rows of the CURRENT state: the backup policy's (what replaces a risky action), and the risk network's unless it rates a simulated state
+        hipLaunchKernelGGL(risk_input_kernel, egrid, dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, env->risk_x, ldx, env->backup_x, robs,
+                           simulate ? SMR_RISK_CURRENT_STATE : mode);
+        const float *rating = env->risk_y;
+        if (simulate || want_gt) {
+            // The background copy.  What it is stepped with (base.py:1529-1541,1611-1632): the requested action first - except where the
+            // ground truth of a current-state network is asked for - then the backup policy's actions; a rating by simulation needs the first
+            // step (mode 3) or all of them (mode 4), the ground truth label always all of them.
+            smr_env *sh = env->shadow;
+            const bool first_action = !(want_gt && !simulate && mode == SMR_RISK_CURRENT_STATE);
+            const int K = (want_gt || mode == SMR_RISK_SIMULATE_BACKUP_TRAJECTORY) ? env->rollout_steps : 0;
+            const int n_steps = (first_action ? 1 : 0) + K;
+            hipLaunchKernelGGL(rollout_snapshot_kernel, egrid, dim3(256), 0, env->stream, env->dscene, env->st, sh->st, env->ro_alive, env->ro_outcome);
+            const float *src = env->backup_x;             // the copy's risk observation before its next step (at first: the env's own)
+            for (int i = 0; i < n_steps; ++i) {
+                const float *act = actions_dev;
+                if (!(i == 0 && first_action)) {
+                    hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->backup_net->d, src, robs, env->backup_y, ldb, B);
+                    hipLaunchKernelGGL(rollout_action_kernel, dim3((B * SMR_NJ + 255) / 256), dim3(256), 0, env->stream, B, (const float *)env->backup_y, ldb, env->ro_actions);
+                    act = env->ro_actions;
+                }
+                const int rc = smr_step(sh, act, env->ro_obs, env->ro_reward, env->ro_done, env->ro_reason, nullptr);
+                if (rc) { env->err = "background copy: " + sh->err; return rc; }
+                hipLaunchKernelGGL(rollout_track_kernel, egrid, dim3(256), 0, env->stream, B, i == 0 ? 1 : 0, (const uint8_t *)env->ro_done, (const int8_t *)env->ro_reason,
+                                   env->ro_alive, env->ro_outcome);
+                if (i + 1 < n_steps || i == 0) {          // the copy's risk observation after this step: the backup policy's next input / the state the tables carry
+                    float *dst = i == 0 ? env->ro_first : env->ro_rollx;
+                    hipLaunchKernelGGL(risk_input_kernel, egrid, dim3(256), 0, env->stream, sh->dscene, sh->st, actions_dev, env->ro_riskx, ldx, dst, robs, SMR_RISK_CURRENT_STATE);
+                    src = dst;
+                }
+            }
+            if (simulate) {
+                if (mode == SMR_RISK_SIMULATE_NEXT_STEP)  // the network rates the copy's next risk observation (base.py:1553-1555,1598-1603)
+                    hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->risk_net->d, (const float *)env->ro_first, robs, env->risk_y, 1, B);
+                hipLaunchKernelGGL(rollout_rating_kernel, egrid, dim3(256), 0, env->stream, B, mode, (const int *)env->ro_outcome, (const float *)env->risk_y, env->ro_rating);
+                rating = env->ro_rating;
+            }
+        }
+        if (!simulate) hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->risk_net->d, (const float *)env->risk_x, ldx, env->risk_y, 1, B);
         hipLaunchKernelGGL(mlp_forward_kernel, mgrid, dim3(64), 0, env->stream, env->backup_net->d, (const float *)env->backup_x, robs, env->backup_y, ldb, B);
-        hipLaunchKernelGGL(risk_apply_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, (const float *)env->risk_y,
-                           (const float *)env->backup_y, ldb, env->risk_threshold, env->actions_eff);
+        if (want_gt)
+            hipLaunchKernelGGL(rollout_ground_truth_kernel, egrid, dim3(256), 0, env->stream, B, robs, mode, actions_dev, (const float *)env->backup_x, (const float *)env->ro_first,
+                               (const int *)env->ro_outcome, rating, env->gt_sa, env->gt_s);
+        hipLaunchKernelGGL(risk_apply_kernel, egrid, dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, rating,
+                           (const float *)env->backup_y, ldb, env->risk_threshold, env->risk_ignore_p, env->actions_eff);
         SMR_HIP(hipGetLastError());
         planned_actions = env->actions_eff;
     }
@@ -2990,7 +3208,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         // gained: reaching task 94 -> 86 M env-steps/s; ball scene beside the collide kernel: 63.6 -> 51.8 M; both measured)
         if (pairs) {
             hipLaunchKernelGGL(self_bounds_kernel, dim3((B + 255) / 256, env->hscene.n_self_pairs), dim3(256), 0, env->stream, env->dscene, env->st);
-            if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st);
+            if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st, 0);
         }
         if (env->hscene.planets_jobs) {
             const int env_blocks = (B + 255) / 256;
@@ -3017,8 +3235,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
                     const int off = (int)(env->job_lds_bytes / 4);
                     if (self) hipLaunchKernelGGL((jobs_pool_kernel<true>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
                     else hipLaunchKernelGGL((jobs_pool_kernel<false>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
-                } else if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st);
-                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                } else if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after);
+                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after);
+                if (env->defer_after > 0 && !env->job_pool) {
+                    if (self) hipLaunchKernelGGL((jobs_coop_kernel<true>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                    else hipLaunchKernelGGL((jobs_coop_kernel<false>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                }
             }
             // (beside the jobs kernel on a stream of its own - its flags are final once the lists are written, its results commute with
             // the jobs' - the step got slower: space 115 -> 109 M, reaching task 92 -> 78 M env-steps/s, measured)
@@ -3223,9 +3445,10 @@ int smr_set_risk_networks(smr_env_t *env, smr_mlp_t *risk, smr_mlp_t *backup, fl
     SMR_HIP(hipStreamSynchronize(env->stream));
     if (!risk && !backup) { env->risk_net = env->backup_net = nullptr; env->st.risky = nullptr; return SMR_OK; }
     const int robs = env->obs_size - env->hscene.obs_target_size;                         // obs.py:419-431: no target-point columns
-    if (!risk || !backup) { env->err = "smr_set_risk_networks: both networks are needed"; return SMR_E_INVALID; }
-    if (risk->device != env->device || backup->device != env->device) { env->err = "smr_set_risk_networks: networks live on another device"; return SMR_E_INVALID; }
-    if ((risk->d.in_size != robs + SMR_NJ && risk->d.in_size != robs) || risk->d.out_size != 1) {
+    const bool by_simulation = env->risk_state_config == SMR_RISK_SIMULATE_BACKUP_TRAJECTORY;          // rates without a network (base.py:1560-1566)
+    if (!backup || (!risk && !by_simulation)) { env->err = "smr_set_risk_networks: both networks are needed (the risk network may be NULL with risk_state_config 4 only)"; return SMR_E_INVALID; }
+    if ((risk && risk->device != env->device) || backup->device != env->device) { env->err = "smr_set_risk_networks: networks live on another device"; return SMR_E_INVALID; }
+    if (risk && ((risk->d.in_size != robs + SMR_NJ && risk->d.in_size != robs) || risk->d.out_size != 1)) {
         env->err = "smr_set_risk_networks: the risk network must map (risk observation, action) or the risk observation alone to one value"; return SMR_E_INVALID;
     }
     if (backup->d.in_size != robs || backup->d.out_size < SMR_NJ) { env->err = "smr_set_risk_networks: the backup policy must map the risk observation to >= 7 outputs"; return SMR_E_INVALID; }
@@ -3235,21 +3458,60 @@ int smr_set_risk_networks(smr_env_t *env, smr_mlp_t *risk, smr_mlp_t *backup, fl
                          (rc = dev_alloc(env, &env->backup_y, B * SMR_MLP_MAX_WIDTH)) || (rc = dev_alloc(env, &env->actions_eff, B * SMR_NJ)) ||
                          (rc = dev_alloc(env, &env->risky_buf, B)))) return rc;
     SMR_HIP(hipMemset(env->risky_buf, 0, B * 4));
+    SMR_HIP(hipMemset(env->risk_y, 0, B * 4));
     env->st.risky = env->risky_buf;
     env->risk_net = risk; env->backup_net = backup; env->risk_threshold = risk_threshold;
-    env->risk_mode = risk->d.in_size == robs + SMR_NJ ? SMR_RISK_STATE_ACTION : env->risk_state_config;      // base.py:609-617: action_size decides
+    env->risk_mode = (risk && risk->d.in_size == robs + SMR_NJ) ? SMR_RISK_STATE_ACTION : env->risk_state_config;      // base.py:609-617: action_size decides
     return SMR_OK;
 }
 
 int smr_set_risk_state_config(smr_env_t *env, int32_t config) {
     if (!env) return SMR_E_INVALID;
-    if (config != SMR_RISK_CURRENT_STATE && config != SMR_RISK_NEXT_KINEMATIC && config != SMR_RISK_NEXT_FULL) {
-        env->err = "smr_set_risk_state_config: only RISK_CHECK_CURRENT_STATE (0), NEXT_STATE_KINEMATIC_FORECASTING (1) and NEXT_STATE_FULL_FORECASTING (2); "
-                   "the modes that simulate the next step in a background copy of the env (3, 4) are not built";
+    if (config < SMR_RISK_CURRENT_STATE || config > SMR_RISK_SIMULATE_BACKUP_TRAJECTORY) {
+        env->err = "smr_set_risk_state_config: 0 .. 4 (safe_motions_base.py:73-83)";
         return SMR_E_INVALID;
     }
+    if (env->backup_net && !env->risk_net && config != SMR_RISK_SIMULATE_BACKUP_TRAJECTORY) { env->err = "smr_set_risk_state_config: this mode needs a risk network"; return SMR_E_INVALID; }
     env->risk_state_config = config;
-    if (env->risk_net && env->risk_mode != SMR_RISK_STATE_ACTION) env->risk_mode = config;
+    if (env->backup_net && env->risk_mode != SMR_RISK_STATE_ACTION) env->risk_mode = config;
+    return SMR_OK;
+}
+
+int smr_set_risk_rollout(smr_env_t *env, smr_env_t *shadow, int32_t backup_steps, float ignore_probability, float *gt_state_action_dev, float *gt_state_dev) {
+    if (!env) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    if (!(ignore_probability >= 0.f && ignore_probability <= 1.f)) { env->err = "smr_set_risk_rollout: ignore_probability must lie in [0, 1]"; return SMR_E_INVALID; }
+    env->risk_ignore_p = ignore_probability;
+    if (!shadow) {
+        if (gt_state_action_dev || gt_state_dev) { env->err = "smr_set_risk_rollout: the ground truth comes from the background copy"; return SMR_E_INVALID; }
+        env->shadow = nullptr; env->gt_sa = env->gt_s = nullptr;
+        return SMR_OK;
+    }
+    const DScene &a = env->hscene, &b = shadow->hscene;
+    if (shadow == env || shadow->shadow) { env->err = "smr_set_risk_rollout: the background copy must be a handle of its own without a copy of its own"; return SMR_E_INVALID; }
+    if (backup_steps < 0 || shadow->B != env->B || shadow->device != env->device || shadow->stream != env->stream || shadow->obs_size != env->obs_size ||
+        a.n_bodies != b.n_bodies || a.n_self_pairs != b.n_self_pairs || a.use_ball != b.use_ball || a.use_target != b.use_target || a.n_planets != b.n_planets ||
+        a.checks_per_step != b.checks_per_step || a.seed_lo != b.seed_lo || a.seed_hi != b.seed_hi || a.env_base != b.env_base || a.dt != b.dt ||
+        a.check_braking != b.check_braking) {
+        env->err = "smr_set_risk_rollout: the background copy must be a handle of the same scene, batch, seed, env_index_base, device and stream"; return SMR_E_INVALID;
+    }
+    if (shadow->auto_reset || b.auto_reset || b.episode_steps != backup_steps + 1) {
+        env->err = "smr_set_risk_rollout: the background copy needs auto_reset = 0 and episode_steps = backup_steps + 1 (trajectory_length = backup_steps + 2, safe_motions_base.py:1819)";
+        return SMR_E_INVALID;
+    }
+    if (gt_state_dev && !gt_state_action_dev) { env->err = "smr_set_risk_rollout: gt_state_dev without gt_state_action_dev"; return SMR_E_INVALID; }
+    const size_t B = (size_t)env->B;
+    const int robs = env->obs_size - a.obs_target_size;
+    int rc;
+    if (!env->ro_alive && ((rc = dev_alloc(env, &env->ro_alive, B)) || (rc = dev_alloc(env, &env->ro_outcome, B)) || (rc = dev_alloc(env, &env->ro_first, B * robs)) ||
+                           (rc = dev_alloc(env, &env->ro_rollx, B * robs)) || (rc = dev_alloc(env, &env->ro_riskx, B * (robs + SMR_NJ))) ||
+                           (rc = dev_alloc(env, &env->ro_actions, B * SMR_NJ)) || (rc = dev_alloc(env, &env->ro_obs, B * (size_t)env->obs_size)) ||
+                           (rc = dev_alloc(env, &env->ro_reward, B)) || (rc = dev_alloc(env, &env->ro_rating, B)) || (rc = dev_alloc(env, &env->ro_done, B)) ||
+                           (rc = dev_alloc(env, &env->ro_reason, B)))) return rc;
+    SMR_HIP(hipMemset(env->ro_first, 0, B * robs * 4));
+    SMR_HIP(hipMemset(env->ro_outcome, 0, B * 4));
+    env->shadow = shadow; env->rollout_steps = backup_steps; env->gt_sa = gt_state_action_dev; env->gt_s = gt_state_dev;
     return SMR_OK;
 }
 

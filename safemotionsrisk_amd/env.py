@@ -76,12 +76,15 @@ class VecSafeMotionsEnv:
         if self._env_index_base < 0 or self._env_index_base + self.num_envs > 0xFFFFFFFF:
             raise ValueError("env_index_base + num_envs must fit 32 bits")
         self._h = None
+        self._shadow_h, self._rollout = None, None    # the background copy of the env (set_risk_rollout)
+        self.risk_ground_truth = None
+        self._scene_kw, self._trained_networks_dir = dict(kw, collision_checks_per_step=collision_checks_per_step), trained_networks_dir
         self._risk_nets, self._risk_threshold, self._risk_state_config, self._profiling = None, 0.05, 0, False
         self.risk_config = self.scene.risk            # the env_config's risk network description (observation_size, action_size, ...) or None
         if self.risk_config is not None:
             self._risk_threshold, self._risk_state_config = self.risk_config["risk_threshold"], self.risk_config["risk_state_config"]
         self._create()
-        if self.risk_config is not None and self.risk_config["observation_size"] != self.risk_observation_size:
+        if self.risk_config is not None and self.risk_config["observation_size"] not in (None, self.risk_observation_size):
             raise ValueError("risk_config.json: observation_size %d, the env's risk observation has %d columns (safe_motions_base.py:542-571)"
                              % (self.risk_config["observation_size"], self.risk_observation_size))
         B, O = self.num_envs, self.observation_size
@@ -112,8 +115,12 @@ class VecSafeMotionsEnv:
         self._create()
         self.episode_counter = 0
         # the fresh handle knows nothing of what was configured on the old one: put it back (risk-aware stepping, profiling)
-        if self._risk_nets is not None and self._risk_nets[0] is not None:
+        rollout = self._rollout
+        self._rollout = None
+        if self._risk_nets is not None and self._risk_nets[1] is not None:
             self.set_risk_networks(*self._risk_nets, risk_threshold=self._risk_threshold, risk_state_config=self._risk_state_config)
+        if rollout is not None:
+            self.set_risk_rollout(**rollout)
         if self._profiling:
             self.set_profiling(self._profiling)
 
@@ -136,7 +143,7 @@ class VecSafeMotionsEnv:
         a = action.to(device=self.device, dtype=t.float32).contiguous()
         if a.shape != (self.num_envs, NJ):
             raise ValueError("action must have shape (%d, %d), got %s" % (self.num_envs, NJ, tuple(a.shape)))
-        if self.risk_config is not None and (self._risk_nets is None or self._risk_nets[0] is None):
+        if self.risk_config is not None and (self._risk_nets is None or self._risk_nets[1] is None):
             raise RuntimeError("this env_config names a risk network (%s): call set_risk_networks(risk, backup) with the weights as arrays "
                                "(policy.Mlp / Mlp.from_npz) before the first step - checkpoints and SavedModels are never deserialised here"
                                % self.risk_config["checkpoint"])
@@ -156,14 +163,17 @@ class VecSafeMotionsEnv:
         step(), where the risk network's rating reaches risk_threshold the backup policy's deterministic action replaces the
         action.  A network over [risk observation, action] rates the state-action pair; one over the risk observation alone rates
         the state ``risk_state_config`` names: 0 the current one, 1 the next one with its kinematic columns forecast for the
-        requested action, 2 with the planets / the ball forecast as well (3, 4 - a background copy of the env stepped ahead - are
-        not built).  risk / backup: policy.Mlp objects on this env's device (None, None switches it off); info column
-        ``risky_action`` reports it per step.  Defaults: what the env_config's risk keys said, else 0.05 and 0."""
+        requested action, 2 with the planets / the ball forecast as well, 3 the state a background copy of the env reaches when it
+        is stepped with the action (a collision there is risk 1), 4 no network at all: risk 1 if the copy, stepped with the action
+        and then ``backup_trajectory_steps`` actions of the backup policy, ends in a collision (``risk`` may be None).  Modes 3 / 4
+        and the ground truth need ``set_risk_rollout`` (an env_config that asks for them gets it here).  risk / backup: policy.Mlp
+        objects on this env's device (None, None switches it off); info column ``risky_action`` reports it per step.  Defaults: what
+        the env_config's risk keys said, else 0.05 and 0."""
         if risk_threshold is None:
             risk_threshold = self._risk_threshold
         if risk_state_config is None:
             risk_state_config = self._risk_state_config
-        if risk is not None and self.risk_config is not None:
+        if risk is not None and self.risk_config is not None and self.risk_config["observation_size"] is not None:
             want = self.risk_observation_size + (NJ if self.risk_config["action_size"] is not None else 0)
             if risk.sizes[0] != want:
                 raise ValueError("risk_config.json describes a risk network with %d inputs, the one given has %d" % (want, risk.sizes[0]))
@@ -173,6 +183,60 @@ class VecSafeMotionsEnv:
         rc = self._L.smr_set_risk_networks(self._h, None if risk is None else risk._h, None if backup is None else backup._h,
                                            C.c_float(float(risk_threshold)))
         _lib.check(self._L, self._h, rc, "smr_set_risk_networks")
+        rc_cfg = self.risk_config or {}
+        wants_copy = "backup_trajectory_steps" in rc_cfg or (int(risk_state_config) >= 3 and (risk is None or risk.sizes[0] == self.risk_observation_size))
+        if backup is not None and wants_copy and self._rollout is None:
+            self.set_risk_rollout(backup_steps=rc_cfg.get("backup_trajectory_steps"), store_ground_truth=rc_cfg.get("store_ground_truth", False),
+                                  ignore_probability=rc_cfg.get("ignore_probability", 0.0))
+
+    def set_risk_rollout(self, backup_steps=None, store_ground_truth=False, ignore_probability=0.0):
+        """The background copy of the env (the reference's backup client, safe_motions_base.py:1518-1577,1605-1655,1801-1842): a second
+        handle of the same scene, batch, seed and stream whose episodes are ``backup_steps + 1`` steps long; step() copies the envs'
+        state into it and steps it ahead on the device - with the requested action, then ``backup_steps``
+        (``risk_state_backup_trajectory_steps``; default: the length of this env's own episodes, as base.py:573-576 takes the backup
+        policy's) actions of the backup policy.  ``store_ground_truth`` (``risk_store_ground_truth``): every step() then leaves
+        ``self.risk_ground_truth`` = dict(state_action=[B, R + 7 + 3] rows (risk observation | action | risk | prediction | valid),
+        state=[B, R + 2] rows (mode 4: the copy's next risk observation | risk | valid)) on the device (include/safemotions_hip.h,
+        smr_set_risk_rollout; metrics.RiskGroundTruthLog collects them into the reference's tables).  ``ignore_probability``:
+        ``risk_ignore_estimation_probability``.  backup_steps=False switches the copy off."""
+        torch = self._torch
+        if backup_steps is False:
+            _lib.check(self._L, self._h, self._L.smr_set_risk_rollout(self._h, None, 0, C.c_float(float(ignore_probability)), None, None), "smr_set_risk_rollout")
+            self._close_shadow()
+            self._rollout, self.risk_ground_truth = None, None
+            return
+        s = self.scene.struct
+        K = int(s.episode_steps) if backup_steps is None else int(backup_steps)
+        if K < 0:
+            raise ValueError("backup_steps must be >= 0")
+        self._close_shadow()
+        # the scene as resolve_risk_config left it (the backup policy's scene parameters put in, the risk keys taken out), episodes of K + 1 steps
+        cfg = dict(self.scene.env_config, trajectory_duration=(K + 1) * float(s.dt))      # trajectory_length = backup_steps + 2, base.py:1819
+        self._shadow_scene = build_scene(cfg, auto_reset=False, trained_networks_dir=self._trained_networks_dir, **self._scene_kw)
+        assert int(self._shadow_scene.struct.episode_steps) == K + 1 and self._shadow_scene.obs_size == self.observation_size
+        with torch.cuda.device(self.device):
+            handle = C.c_void_p()
+            rc = self._L.smr_create(C.cast(self._shadow_scene.pointer(), C.c_void_p), self.num_envs, C.c_uint32(self._env_index_base),
+                                    self._device_index, C.c_uint64(self._seed & 0xFFFFFFFFFFFFFFFF), C.c_void_p(self._stream.cuda_stream), C.byref(handle))
+            _lib.check(self._L, None, rc, "smr_create (background copy)")
+        self._shadow_h = handle
+        gt = None
+        if store_ground_truth:
+            R = self.risk_observation_size
+            gt = dict(state_action=torch.zeros((self.num_envs, R + NJ + 3), dtype=torch.float32, device=self.device),
+                      state=torch.zeros((self.num_envs, R + 2), dtype=torch.float32, device=self.device))
+        rc = self._L.smr_set_risk_rollout(self._h, self._shadow_h, K, C.c_float(float(ignore_probability)),
+                                          None if gt is None else C.c_void_p(gt["state_action"].data_ptr()), None if gt is None else C.c_void_p(gt["state"].data_ptr()))
+        _lib.check(self._L, self._h, rc, "smr_set_risk_rollout")
+        self.risk_ground_truth = gt
+        self._rollout = dict(backup_steps=K, store_ground_truth=bool(store_ground_truth), ignore_probability=float(ignore_probability))   # re-applied by set_seed()
+
+    def _close_shadow(self):
+        if getattr(self, "_shadow_h", None):
+            if getattr(self, "_h", None):
+                self._L.smr_set_risk_rollout(self._h, None, 0, C.c_float(0.0), None, None)
+            self._L.smr_destroy(self._shadow_h)
+            self._shadow_h = None
 
     @property
     def risk_observation_size(self):
@@ -186,6 +250,7 @@ class VecSafeMotionsEnv:
         return self.obs
 
     def close(self):
+        self._close_shadow()
         if getattr(self, "_h", None):
             self._L.smr_destroy(self._h)
             self._h = None

@@ -239,3 +239,64 @@ class RllibVectorEnv:
                           trajectory_successful=0.0 if reason[e] == TERMINATION_JOINT_LIMITS else 1.0)
             infos.append(ie)
         return list(o), r.tolist(), d.tolist(), infos
+
+
+class RiskGroundTruthLog:
+    """The tables of ``risk_store_ground_truth`` (safe_motions_base.py:1567-1586,1605-1650) and their files
+    (``_store_risk_ground_truth_data``, safe_motions_base.py:1413-1458) for a batched env: ``add()`` after every step() takes the valid rows
+    of ``env.risk_ground_truth`` (include/safemotions_hip.h, smr_set_risk_rollout), ``write()`` stores what has been collected the way
+    the reference does - one CSV per table under ``<evaluation_dir>/state_action_risk`` and ``/state_risk`` (risk_state_config 4) or
+    ``/ground_truth_risk`` (a risk network; columns state, [action,] risk, risk_prediction), named
+    ``episodes_<a>_to_<b>_risk_<mean>_prediction_<mean>_pid_<pid>.csv``, list-valued cells as pandas writes the reference's dict of lists
+    - and ``risk_config.json`` beside them.  This is what the reference's ``train_risk_network.py`` reads.  Host logic only."""
+
+    def __init__(self, risk_observation_size, simulate_backup_trajectory, state_action_network=False):
+        self.R, self.mode4, self.with_action = int(risk_observation_size), bool(simulate_backup_trajectory), bool(state_action_network) or bool(simulate_backup_trajectory)
+        self.reset()
+
+    def reset(self):
+        self.tables = {"state_action_risk": dict(state=[], action=[], risk=[]), "state_risk": dict(state=[], risk=[])} if self.mode4 else \
+                      {"ground_truth_risk": dict(state=[], **({"action": []} if self.with_action else {}), risk=[], risk_prediction=[])}
+
+    def add(self, ground_truth):
+        R = self.R
+        sa = ground_truth["state_action"].detach().cpu().numpy()
+        sa = sa[sa[:, R + 9] > 0.5]
+        t = self.tables["state_action_risk" if self.mode4 else "ground_truth_risk"]
+        t["state"] += sa[:, :R].tolist(); t["risk"] += sa[:, R + 7].tolist()
+        if "action" in t:
+            t["action"] += sa[:, R:R + 7].tolist()
+        if "risk_prediction" in t:
+            t["risk_prediction"] += sa[:, R + 8].tolist()
+        if self.mode4:
+            s = ground_truth["state"].detach().cpu().numpy()
+            s = s[s[:, R + 1] > 0.5]
+            self.tables["state_risk"]["state"] += s[:, :R].tolist(); self.tables["state_risk"]["risk"] += s[:, R].tolist()
+
+    def __len__(self):
+        return len(next(iter(self.tables.values()))["risk"])
+
+    def write(self, evaluation_dir, start_episode, end_episode, pid=None, risk_config=None):
+        """returns the paths written; the tables are emptied"""
+        import json
+        import os
+        import pandas as pd
+        pid = os.getpid() if pid is None else pid
+        paths = []
+        for name, table in self.tables.items():
+            if not table["risk"]:
+                continue
+            d = os.path.join(evaluation_dir, name)
+            os.makedirs(d, exist_ok=True)
+            mean_risk = float(np.mean(table["risk"]))
+            mean_pred = float(np.mean(table["risk_prediction"])) if "risk_prediction" in table else 0.0
+            path = os.path.join(d, "episodes_{}_to_{}_risk_{:.2f}_prediction_{:.2f}_pid_{}.csv".format(start_episode, end_episode, mean_risk, mean_pred, pid))
+            with open(path, "w") as f:
+                pd.DataFrame(table).to_csv(path_or_buf=f)
+            paths.append(path)
+        cfg_path = os.path.join(evaluation_dir, "risk_config.json")
+        if risk_config is not None and not os.path.isfile(cfg_path):
+            with open(cfg_path, "w") as f:
+                f.write(json.dumps({k: v for k, v in risk_config.items() if k != "config"}, sort_keys=True))
+        self.reset()
+        return paths

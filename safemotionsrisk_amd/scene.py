@@ -225,7 +225,7 @@ _DEFAULTS = dict(
 _UNSUPPORTED_TRUE = ("use_real_robot", "punish_end_max_torque", "punish_braking_trajectory_max_torque",
                      "target_point_use_actual_position",
                      "check_braking_trajectory_torque_limits", "use_gui", "render_video",
-                     "risk_check_initial_backup_trajectory", "risk_store_ground_truth", "static_robot",
+                     "risk_check_initial_backup_trajectory", "static_robot",
                      "moving_object_aim_at_current_robot_position", "normalize_reward_to_frequency",
                      "obstacle_use_computed_actual_values", "always_use_collision_avoidance_starting_point_sampling")
 _UNSUPPORTED_NOT_NONE = ("human_network_checkpoint",
@@ -248,6 +248,8 @@ RISK_ERROR_PARAMETERS = ("robot_scene", "trajectory_time_step", "acc_limit_facto
 RISK_WARNING_PARAMETERS = ("obstacle_scene", "closest_point_safety_distance", "starting_point_cartesian_range_scene",
                            "use_controller_target_velocities")
 RISK_CHECK_CURRENT_STATE, RISK_CHECK_NEXT_STATE_KINEMATIC_FORECASTING, RISK_CHECK_NEXT_STATE_FULL_FORECASTING = 0, 1, 2   # base.py:73-77
+RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP, RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP_AND_BACKUP_TRAJECTORY = 3, 4             # base.py:78-83
+RISK_GROUND_TRUTH_EPISODES_PER_FILE = 100                                                                                    # base.py:38
 
 
 def resolve_risk_config(config, trained_networks_dir=None):
@@ -300,21 +302,36 @@ def resolve_risk_config(config, trained_networks_dir=None):
                 k, backup_env_config[k], config[k]))
     state_config = config.pop("risk_state_config", None)
     state_config = RISK_CHECK_CURRENT_STATE if state_config is None else int(state_config)
-    if risk.get("action_size") is None and state_config not in (RISK_CHECK_CURRENT_STATE, RISK_CHECK_NEXT_STATE_KINEMATIC_FORECASTING,
-                                                                 RISK_CHECK_NEXT_STATE_FULL_FORECASTING):
-        raise NotImplementedError("risk_state_config=%d: the modes that step a background copy of the env (3, 4) are outside the batched hot path" % state_config)
+    if not RISK_CHECK_CURRENT_STATE <= state_config <= RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP_AND_BACKUP_TRAJECTORY:
+        raise ValueError("risk_state_config=%d (safe_motions_base.py:73-83 knows 0 .. 4)" % state_config)
     if risk.get("action_size") is not None and int(risk["action_size"]) != NJ:
         raise ValueError("The action size of the risk network does not match with num_manip_joints")    # base.py:611-614
     threshold = config.pop("risk_threshold", None)
-    for k, ok in (("risk_ignore_estimation_probability", (None, 0, 0.0)), ("risk_use_backup_agent_for_initial_backup_trajectory_only", (None, False)),
-                  ("risk_state_deterministic_backup_trajectory", (None, False))):
-        if config.get(k) not in ok:
-            raise NotImplementedError("env_config[%r]=%r is outside the batched hot path" % (k, config[k]))
-        config.pop(k, None)
-    for k in ("risk_state_backup_trajectory_steps", "risk_state_initial_backup_trajectory_steps", "risk_ground_truth_episodes_per_file"):
-        config.pop(k, None)                                  # only read by the initial-backup-trajectory / ground-truth code (out of scope)
-    return config, dict(observation_size=int(risk["observation_size"]), action_size=risk.get("action_size"), checkpoint=risk["checkpoint"],
-                        risk_threshold=0.05 if threshold is None else float(threshold), risk_state_config=state_config)   # base.py:222-223
+    if config.get("risk_use_backup_agent_for_initial_backup_trajectory_only") not in (None, False):
+        raise NotImplementedError("env_config['risk_use_backup_agent_for_initial_backup_trajectory_only'] belongs to the initial-backup-trajectory loop "
+                                  "(observations.py:155-185), outside the batched hot path")
+    config.pop("risk_use_backup_agent_for_initial_backup_trajectory_only", None)
+    # The background copy of the env (safe_motions_base.py:1518-1577,1605-1655): its length, the ground truth it labels, the probability with
+    # which a risky rating is ignored.  risk_state_deterministic_backup_trajectory: the copy here always sees the balls / target points
+    # the env itself will see (every draw is keyed by seed, env and counter) - the reference's True; with False it draws independent ones.
+    steps = config.pop("risk_state_backup_trajectory_steps", None)
+    if steps is None:                                        # "trajectory steps as during the training of the backup agent", base.py:573-576
+        steps = int(round(float(backup_env_config["trajectory_duration"]) / float(_cfg(config, "trajectory_time_step"))))
+    ignore_p = config.pop("risk_ignore_estimation_probability", None)
+    ignore_p = 0.0 if ignore_p is None else float(ignore_p)
+    if not 0.0 <= ignore_p <= 1.0:
+        raise ValueError("risk_ignore_estimation_probability=%r" % ignore_p)
+    per_file = config.pop("risk_ground_truth_episodes_per_file", None)
+    out = dict(observation_size=None if risk.get("observation_size") is None else int(risk["observation_size"]), action_size=risk.get("action_size"),
+               checkpoint=risk["checkpoint"], risk_threshold=0.05 if threshold is None else float(threshold), risk_state_config=state_config)   # base.py:222-223
+    extra = dict(backup_trajectory_steps=int(steps), store_ground_truth=bool(config.pop("risk_store_ground_truth", False)), ignore_probability=ignore_p,
+                 ground_truth_episodes_per_file=RISK_GROUND_TRUTH_EPISODES_PER_FILE if per_file is None else int(per_file),
+                 deterministic_backup_trajectory=bool(config.pop("risk_state_deterministic_backup_trajectory", False)))
+    config.pop("risk_state_initial_backup_trajectory_steps", None)      # only read by the initial-backup-trajectory loop (out of scope)
+    uses_copy = state_config >= RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP and risk.get("action_size") is None
+    if uses_copy or extra["store_ground_truth"] or ignore_p != 0.0:
+        out.update(extra)                                    # (kept out of the description of a plain network config: it is compared as a whole)
+    return config, out
 
 
 def _cfg(config, key):

@@ -148,10 +148,148 @@ def test_state_risk_network_modes(built, mode):
         if done.any():
             env.reset(mask=done)
     assert 0.05 * B * T < n_risky < 0.95 * B * T
-    from safemotionsrisk_amd.lib import SmrError
-    with pytest.raises(SmrError):                                # the modes that step a background copy of the env are refused
-        env.set_risk_networks(risk, backup, risk_state_config=3)
     env.close(); shadow.close()
+
+
+def _explained(ora1, scene, trace, e, tie):
+    """a label of env e that differs between the copy on the GPU and the oracle's copy: is one of the decisions of the oracle's
+    rollout of that env (while it was alive) a threshold tie?  The later steps of a rollout start from float32 / float64 states
+    that have drifted apart, so their ties are judged with a wider band."""
+    for i, (s0, s1, alive, done, reason) in enumerate(trace):
+        if not alive[e]:
+            break
+        one = np.zeros(len(alive), bool); one[e] = True
+        if explain_mismatches(ora1, scene, s0, s1, one, tie=tie if i == 0 else 20 * tie)[0]:
+            return True
+    return False
+
+
+@pytest.mark.parametrize("mode,config", [(3, "space"), (4, "space"), (4, "ball"), (4, "reach")])
+def test_risk_modes_that_step_a_background_copy(built, mode, config):
+    """RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP (3) and ..._AND_BACKUP_TRAJECTORY (4), safe_motions_base.py:1518-1577: the env copies its
+    state into a second handle, steps that with the requested action (3: the network then rates the copy's next risk observation unless the
+    step collided) and, mode 4, with `backup_steps` more actions of the backup policy - risky if the copy ends in a collision.  Against
+    oracle/risk_rollout.py, which drives two OracleEnv objects the same way with the same networks in numpy: the decision (info column
+    risky_action), the executed action and the ground-truth rows; a label that differs must sit on a threshold tie of the oracle's rollout.
+    The env itself is not touched by the copy: its step equals the step of an env without the rollout fed with the executed action."""
+    import torch
+    from oracle.oracle import OracleEnv
+    from oracle.risk_rollout import is_action_risky
+    from parity_util import TIE
+    from safemotionsrisk_amd import BALL_ENV_CONFIG, REACH_ENV_CONFIG, SPACE_ENV_CONFIG, VecSafeMotionsEnv, backup_policy, build_scene, risk_network
+    cfg = dict(space=SPACE_ENV_CONFIG, ball=BALL_ENV_CONFIG, reach=REACH_ENV_CONFIG)[config]
+    B, T, K, thr = 1024, 5, 3, 0.5
+    env = VecSafeMotionsEnv(B, device=0, seed=6, auto_reset=False, **cfg)
+    plain = VecSafeMotionsEnv(B, device=0, seed=6, auto_reset=False, **cfg)            # the same env without risk-aware stepping
+    R = env.risk_observation_size
+    cols = np.r_[0:21, (env.observation_size - (R - 21)):env.observation_size]          # obs.py:419-431: no target-point columns
+    rng = np.random.default_rng(20 + mode)
+    risk = risk_network(*_weights(rng, [R, 256, 128, 1], scale=3.0)) if mode == 3 else None
+    backup = backup_policy(*_weights(rng, [R, 256, 128, 14], scale=2.0))
+    env.set_risk_networks(risk, backup, risk_threshold=thr, risk_state_config=mode)
+    env.set_risk_rollout(backup_steps=K, store_ground_truth=True)
+    assert env.risk_ground_truth["state_action"].shape == (B, R + 10) and env.risk_ground_truth["state"].shape == (B, R + 2)
+    env.reset()
+    ora = OracleEnv(env.scene, B, seed=6, num_threads=16)
+    ora1 = OracleEnv(env.scene, 1)
+    sh_scene = build_scene(dict(env.scene.env_config, trajectory_duration=(K + 1) * float(env.scene.struct.dt)), auto_reset=False)
+    ora_sh = OracleEnv(sh_scene, B, seed=6, num_threads=16)
+    keys = env.STATE_KEYS
+    n_risky = n_label = unexplained = 0
+    for t in range(T):
+        st = env.get_state()
+        ora.set_state(**{k: st[k] for k in keys})
+        act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+        if t % 2:                                             # half of the steps push towards the table so that copies collide
+            act[: B // 2, 1] = 1.0; act[: B // 2, 3] = -1.0
+        want = is_action_risky(ora, ora_sh, act, None if risk is None else risk.reference, backup.reference, cols, mode, K, thr, store_ground_truth=True, seed=6)
+        plain.set_state(**{k: st[k] for k in keys})
+        _, _, done, info = env.step(torch.from_numpy(act).cuda())
+        got = info["values"][:, 11].cpu().numpy() > 0.5
+        gt_sa, gt_s = env.risk_ground_truth["state_action"].cpu().numpy(), env.risk_ground_truth["state"].cpu().numpy()
+        # labels: exact, threshold ties of the oracle's rollout aside
+        diff = gt_sa[:, R + 7] != want["state_action"][:, R + 7]
+        for e in np.nonzero(diff)[0]:
+            unexplained += 0 if _explained(ora1, sh_scene, want["trace"], e, TIE) else 1
+        same = ~diff
+        assert diff.sum() <= 0.01 * B
+        near = np.abs(want["rating"] - thr) < 2e-4           # (mode 3: the network's rating on the threshold)
+        first_same = gt_sa[:, R + 9] == want["state_action"][:, R + 9]
+        ok = same & ~near & first_same
+        assert np.array_equal(got[ok], want["risky"][ok])
+        assert np.abs(gt_sa[ok][:, :R + 7] - want["state_action"][ok][:, :R + 7]).max() < 3e-5           # state (current, or mode 3: the copy's next one) | action
+        assert np.array_equal(gt_sa[ok][:, R + 9], want["state_action"][ok][:, R + 9])
+        assert np.abs(gt_sa[ok][:, R + 8] - want["state_action"][ok][:, R + 8]).max() < 2e-4              # the rating
+        if mode == 4:
+            v = ok & (gt_s[:, R + 1] > 0.5)
+            assert np.array_equal(gt_s[ok][:, R + 1], want["state"][ok][:, R + 1]) and np.array_equal(gt_s[ok][:, R], want["state"][ok][:, R])
+            assert np.abs(gt_s[v][:, :R] - want["state"][v][:, :R]).max() < 3e-5
+        # the env's own step: that of an env without the copy, fed with the action the decision leaves
+        robs_now = ora.observe()[:, cols]
+        executed = np.where(got[:, None], np.clip(backup.reference(robs_now.astype(np.float32))[:, :7], -1, 1), act).astype(np.float32)
+        p_obs, p_rew, p_done, _ = plain.step(torch.from_numpy(executed).cuda())
+        A = np.array(env.scene.struct.acc_max)
+        s1, p1 = env.get_state(), plain.get_state()
+        assert np.abs((s1["a"] - p1["a"]) / A).max() < 1e-4 and np.abs(s1["q"] - p1["q"]).max() < 1e-6
+        assert np.array_equal(done.cpu().numpy(), p_done.cpu().numpy()) or np.abs((s1["a"] - p1["a"]) / A).max() > 0
+        n_risky += int(got.sum()); n_label += int(want["state_action"][:, R + 7].sum())
+        if done.any():
+            env.reset(mask=done)
+    assert unexplained == 0, "%d labels differ without a threshold tie" % unexplained
+    assert n_label > 20 and 0.01 * B * T < n_risky < 0.99 * B * T
+    # risk_ignore_estimation_probability (safe_motions_base.py:1652-1655): with 1.0 no rating is acted on, with 0.35 about a third is dropped
+    env.set_risk_rollout(backup_steps=K, ignore_probability=1.0)
+    _, _, _, info = env.step(torch.from_numpy(act).cuda())
+    assert float(info["values"][:, 11].sum()) == 0.0
+    env.close(); plain.close()
+    if risk is not None:
+        risk.close()
+    backup.close()
+
+
+def test_ground_truth_of_network_modes_and_ignore_probability(built):
+    """risk_store_ground_truth with a risk NETWORK (safe_motions_base.py:1605-1650): the decision is the network's, the copy only labels it -
+    stepped with the action and `backup_steps` backup actions for a state-action network, with backup actions alone for a current-state
+    network.  And risk_ignore_estimation_probability = 0.35 (README.md:131): the env's draws are the oracle's (Philox stream 15)."""
+    import torch
+    from oracle.oracle import OracleEnv
+    from oracle.risk_rollout import is_action_risky
+    from safemotionsrisk_amd import SPACE_ENV_CONFIG, VecSafeMotionsEnv, backup_policy, build_scene, risk_network
+    B, K, thr = 1024, 3, 0.5
+    for mode in (-1, 0):
+        env = VecSafeMotionsEnv(B, device=0, seed=9, auto_reset=False, **SPACE_ENV_CONFIG)
+        R = env.risk_observation_size
+        cols = np.arange(R)
+        rng = np.random.default_rng(31 + mode)
+        risk = risk_network(*_weights(rng, [R + (7 if mode == -1 else 0), 256, 128, 1], scale=3.0))
+        backup = backup_policy(*_weights(rng, [R, 256, 128, 14], scale=2.0))
+        env.set_risk_networks(risk, backup, risk_threshold=thr, risk_state_config=0)
+        env.set_risk_rollout(backup_steps=K, store_ground_truth=True, ignore_probability=0.35)
+        env.reset()
+        ora = OracleEnv(env.scene, B, seed=9, num_threads=16)
+        ora_sh = OracleEnv(build_scene(dict(env.scene.env_config, trajectory_duration=(K + 1) * 0.1), auto_reset=False), B, seed=9, num_threads=16)
+        dropped = kept = 0
+        for t in range(3):
+            st = env.get_state()
+            ora.set_state(**{k: st[k] for k in env.STATE_KEYS})
+            act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+            act[: B // 2, 1] = 1.0; act[: B // 2, 3] = -1.0
+            want = is_action_risky(ora, ora_sh, act, risk.reference, backup.reference, cols, mode, K, thr, store_ground_truth=True, ignore_probability=0.35, seed=9)
+            _, _, done, info = env.step(torch.from_numpy(act).cuda())
+            got = info["values"][:, 11].cpu().numpy() > 0.5
+            gt = env.risk_ground_truth["state_action"].cpu().numpy()
+            near = np.abs(want["rating"] - thr) < 2e-4
+            assert np.array_equal(got[~near], want["risky"][~near])
+            agree = gt[:, R + 7] == want["state_action"][:, R + 7]
+            assert agree.mean() > 0.99
+            assert np.abs(gt[:, :R + 7] - want["state_action"][:, :R + 7]).max() < 3e-5 and (gt[:, R + 9] == 1.0).all()
+            assert np.abs(gt[:, R + 8] - want["rating"]).max() < 2e-4
+            rated = want["rating"] >= thr
+            dropped += int((rated & ~want["risky"]).sum()); kept += int((rated & want["risky"]).sum())
+            if done.any():
+                env.reset(mask=done)
+        assert 0.25 < dropped / max(dropped + kept, 1) < 0.45 and dropped + kept > 200
+        env.close(); risk.close(); backup.close()
 
 
 def test_env_config_with_a_risk_network_waits_for_its_weights(built, tmp_path):

@@ -1,4 +1,5 @@
 """Episode metrics and the RLlib-style vector interface (host logic; CPU tensors and a fake env stand in for the GPU env)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -133,3 +134,35 @@ def test_rllib_vector_interface_shapes_and_episode_end_info():
             RllibVectorEnv(e)
         finally:
             e.scene.struct.auto_reset = 0
+
+
+def test_risk_ground_truth_log_writes_the_reference_tables(tmp_path):
+    """RiskGroundTruthLog: the rows smr_step leaves (state | action | risk | prediction | valid; state | risk | valid) become the
+    reference's tables and CSV files (safe_motions_base.py:1413-1458, 1567-1586): invalid rows are dropped, mode 4 has two tables."""
+    import pandas as pd
+    import torch
+    from safemotionsrisk_amd.metrics import RiskGroundTruthLog
+    R, B = 23, 6
+    rng = np.random.default_rng(0)
+    sa = rng.uniform(-1, 1, (B, R + 10)).astype(np.float32)
+    sa[:, R + 7] = [0, 1, 0, 0, 1, 0]; sa[:, R + 8] = sa[:, R + 7]; sa[:, R + 9] = 1
+    st = rng.uniform(-1, 1, (B, R + 2)).astype(np.float32)
+    st[:, R] = sa[:, R + 7]; st[:, R + 1] = [1, 0, 1, 1, 0, 1]
+    log = RiskGroundTruthLog(R, simulate_backup_trajectory=True)
+    log.add(dict(state_action=torch.from_numpy(sa), state=torch.from_numpy(st)))
+    log.add(dict(state_action=torch.from_numpy(sa), state=torch.from_numpy(st)))
+    assert len(log) == 12 and len(log.tables["state_risk"]["risk"]) == 8
+    paths = log.write(str(tmp_path), 0, 4, pid=77, risk_config=dict(action_size=None, checkpoint="x", observation_size=None, config={"a": 1}))
+    assert sorted(os.path.relpath(p, str(tmp_path)) for p in paths) == ["state_action_risk/episodes_0_to_4_risk_0.33_prediction_0.00_pid_77.csv",
+                                                                      "state_risk/episodes_0_to_4_risk_0.00_prediction_0.00_pid_77.csv"]
+    df = pd.read_csv(paths[0], index_col=0)
+    assert list(df.columns) == ["state", "action", "risk"] and len(df) == 12 and df["risk"].sum() == 4
+    assert len(eval(df["state"][0])) == R and len(eval(df["action"][0])) == 7
+    assert "config" not in open(tmp_path / "risk_config.json").read() and len(log) == 0
+    # a risk network's single table: valid rows only, with the prediction
+    sa[:, R + 9] = [1, 1, 0, 1, 1, 1]
+    net = RiskGroundTruthLog(R, simulate_backup_trajectory=False, state_action_network=False)
+    net.add(dict(state_action=torch.from_numpy(sa), state=torch.from_numpy(st)))
+    (p,) = net.write(str(tmp_path), 5, 9, pid=1)
+    df = pd.read_csv(p, index_col=0)
+    assert list(df.columns) == ["state", "risk", "risk_prediction"] and len(df) == 5 and "ground_truth_risk" in p

@@ -186,12 +186,21 @@ def test_risk_env_config_keys(tmp_path):
         build_scene(dict(task, trajectory_time_step=0.05), trained_networks_dir=root)
     with pytest.raises(FileNotFoundError):
         build_scene(task, trained_networks_dir=str(tmp_path / "nowhere"))
-    for bad in (dict(risk_check_initial_backup_trajectory=True), dict(risk_store_ground_truth=True), dict(risk_ignore_estimation_probability=0.1)):
-        with pytest.raises(NotImplementedError):
-            build_scene(dict(task, **bad), trained_networks_dir=root)
-    with pytest.raises(NotImplementedError):                 # the modes that step a background copy of the env
-        build_scene(dict({k: v for k, v in task.items() if k != "risk_config_dir"}, risk_state_config=3,
-                         risk_config=dict(action_size=None, checkpoint="backup_networks/space/checkpoint/checkpoint", observation_size=23)), trained_networks_dir=root)
+    with pytest.raises(NotImplementedError):                 # the initial-backup-trajectory loop (observations.py:155-185) is out of scope
+        build_scene(dict(task, risk_check_initial_backup_trajectory=True), trained_networks_dir=root)
+    # the modes that step a background copy of the env, the ground truth and the ignore probability (safe_motions_base.py:1518-1577,1605-1655)
+    sim = dict({k: v for k, v in task.items() if k != "risk_config_dir"}, risk_state_config=4, risk_store_ground_truth=True, risk_ignore_estimation_probability=0.35,
+               risk_state_deterministic_backup_trajectory=True, risk_ground_truth_episodes_per_file=5,
+               risk_config=dict(action_size=None, checkpoint="backup_networks/space/checkpoint/checkpoint", observation_size=None))     # evaluate.py:588-594
+    b4 = build_scene(sim, trained_networks_dir=root)
+    assert b4.risk == dict(observation_size=None, action_size=None, checkpoint="backup_networks/space/checkpoint/checkpoint", risk_threshold=0.065, risk_state_config=4,
+                           backup_trajectory_steps=20, store_ground_truth=True, ignore_probability=0.35, ground_truth_episodes_per_file=5,
+                           deterministic_backup_trajectory=True)                         # 20 = the backup policy's 2.0 s episodes / 0.1 s, base.py:573-576
+    assert build_scene(dict(sim, risk_state_config=3, risk_state_backup_trajectory_steps=7, risk_store_ground_truth=False), trained_networks_dir=root).risk["backup_trajectory_steps"] == 7
+    with pytest.raises(ValueError):
+        build_scene(dict(sim, risk_state_config=5), trained_networks_dir=root)
+    with pytest.raises(ValueError):
+        build_scene(dict(sim, risk_ignore_estimation_probability=1.5), trained_networks_dir=root)
     with pytest.warns(UserWarning):                          # safe_motions_base.py:560-568
         resolve_risk_config(dict(task, closest_point_safety_distance=0.02), root)
     # without a risk network the risk keys are inert, as in the reference
