@@ -42,6 +42,10 @@ CONFIGS = {
     "reach_risk": ("REACH", {}, dict(risk_networks=True), 390,
                    "reaching task with risk-aware stepping (actions.py:303-340): risk network 30-256-128-1 and backup policy 23-256-128-14 "
                    "on the MFMA units, synthetic weights"),
+    "reach_risk4": ("REACH", {}, dict(risk_networks="rollout4"), 390,
+                    "reaching task with risk_state_config 4 (RISK_CHECK_NEXT_STATE_SIMULATE_NEXT_STEP_AND_BACKUP_TRAJECTORY, safe_motions_base.py:1518-1577): "
+                    "every env-step steps a background copy of the batch 1 + 20 times on the device (the action, then 20 actions of the backup policy "
+                    "23-256-128-14, synthetic weights) and replaces the action where the copy collides; value counts the OUTER env-steps"),
     "reach_brake": ("REACH", dict(check_braking_trajectory_collisions=True), {}, 390,
                     "reaching task with the braking-trajectory safety layer (README.md:95: --check_braking_trajectory_collisions "
                     "--closest_point_safety_distance=0.01 --collision_check_time=0.033)"),
@@ -247,8 +251,13 @@ def main():
         mk = lambda sizes: ([(wrng.normal(size=(a, b)) * 2 / np.sqrt(a)).astype(np.float32) for a, b in zip(sizes[:-1], sizes[1:])],
                             [np.zeros(b, np.float32) for b in sizes[1:]])
         r = env.risk_observation_size
-        nets = (risk_network(*mk([r + 7, 256, 128, 1]), device=local_rank), backup_policy(*mk([r, 256, 128, 14]), device=local_rank))
-        env.set_risk_networks(*nets, risk_threshold=0.5)
+        if risk_nets == "rollout4":                     # no risk network: the background copy rates the action (base.py:1560-1566)
+            nets = (None, backup_policy(*mk([r, 256, 128, 14]), device=local_rank))
+            env.set_risk_networks(*nets, risk_threshold=0.5, risk_state_config=4)
+            env.set_risk_rollout(backup_steps=20)       # risk_state_backup_trajectory_steps of the shipped backup policies (2.0 s / 0.1 s, base.py:573-576)
+        else:
+            nets = (risk_network(*mk([r + 7, 256, 128, 1]), device=local_rank), backup_policy(*mk([r, 256, 128, 14]), device=local_rank))
+            env.set_risk_networks(*nets, risk_threshold=0.5)
     rollout = ShardedRollout(env, overlap=not args.sync_gather) if (distributed and not args.no_gather) else None
     gen = torch.Generator(device="cuda")
     gen.manual_seed(1234 + rank)

@@ -261,6 +261,13 @@ __device__ __forceinline__ void sampling_exhausted(const DState &st, int bit) { 
 // ---------------------------------------------------------------------------------------------
 struct F3 { float x, y, z; };
 typedef float V4 __attribute__((vector_size(16)));       // a plain 16-byte vector: loads / stores through address-space pointers (dwordx4)
+// One vertex = 4 floats at a 16-byte boundary (tables, LDS pools and LDS arrays are laid out that way): read as ONE 128-bit access.  Through a
+// plain `const float *` the compiler cannot know the alignment and splits the read into ds_read2_b32 / ds_read_b32 pairs - twice the LDS
+// instructions, each with its own bank conflicts (seen in the ISA of the jobs kernel: 47 dword reads, no ds_read_b128, round 4).
+__device__ __forceinline__ V4 load_v4(const float *p) { return *(const V4 *)p; }
+#ifndef SMR_HOST_EMUL
+__device__ __forceinline__ V4 load_v4(const SMR_GLOBAL float *p) { return *(const SMR_GLOBAL V4 *)p; }
+#endif
 __device__ __forceinline__ F3 operator+(F3 a, F3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ F3 operator-(F3 a, F3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ F3 operator*(float s, F3 a) { return {s * a.x, s * a.y, s * a.z}; }
@@ -766,8 +773,9 @@ struct ClimbHull {
     BP start;    // the piece's start map
     __device__ __forceinline__ F3 support(F3 dl, int &cur, bool first) const {
         if (first) cur = (int)start[climb_start_cell(dl)];
-        F3 pv = {v[4 * cur], v[4 * cur + 1], v[4 * cur + 2]};
-        uint32_t sp = (uint32_t)__float_as_int(v[4 * cur + 3]);
+        const V4 c0 = load_v4(v + 4 * cur);
+        F3 pv = {c0[0], c0[1], c0[2]};
+        uint32_t sp = (uint32_t)__float_as_int(c0[3]);
         float best = fmaf(pv.z, dl.z, fmaf(pv.y, dl.y, pv.x * dl.x));
         for (int guard = 0; guard < 256; ++guard) {
             const int g0 = (int)(sp & 0xffffu), g1 = g0 + (int)(sp >> 16);
@@ -778,26 +786,25 @@ struct ClimbHull {
             const uint32_t fa = ids4[g0], fb_raw = ids4[g0 + 1];
             const uint32_t fb = g1 - g0 > 1 ? fb_raw : fa;
             int id8[8];
-            float qx[8], qy[8], qz[8], qw[8];
+            V4 q8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 id8[k] = (int)(((k < 4 ? fa : fb) >> (8 * (k & 3))) & 255u);
-                qx[k] = v[4 * id8[k]]; qy[k] = v[4 * id8[k] + 1]; qz[k] = v[4 * id8[k] + 2]; qw[k] = v[4 * id8[k] + 3];
+                q8[k] = load_v4(v + 4 * id8[k]);
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float sq = fmaf(qz[k], dl.z, fmaf(qy[k], dl.y, qx[k] * dl.x));
-                if (sq > best) { best = sq; nb = id8[k]; pv = F3{qx[k], qy[k], qz[k]}; sp = (uint32_t)__float_as_int(qw[k]); }
+                const float sq = fmaf(q8[k][2], dl.z, fmaf(q8[k][1], dl.y, q8[k][0] * dl.x));
+                if (sq > best) { best = sq; nb = id8[k]; pv = F3{q8[k][0], q8[k][1], q8[k][2]}; sp = (uint32_t)__float_as_int(q8[k][3]); }
             }
             for (int g = g0 + 2; g < g1; ++g) {
                 const uint32_t four = ids4[g];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int id = (int)((four >> (8 * k)) & 255u);
-                    const F3 q = {v[4 * id], v[4 * id + 1], v[4 * id + 2]};
-                    const float qw1 = v[4 * id + 3];
-                    const float sq = fmaf(q.z, dl.z, fmaf(q.y, dl.y, q.x * dl.x));
-                    if (sq > best) { best = sq; nb = id; pv = q; sp = (uint32_t)__float_as_int(qw1); }
+                    const V4 q = load_v4(v + 4 * id);
+                    const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
+                    if (sq > best) { best = sq; nb = id; pv = F3{q[0], q[1], q[2]}; sp = (uint32_t)__float_as_int(q[3]); }
                 }
             }
             if (nb == cur) break;
@@ -1610,7 +1617,7 @@ __device__ inline void planet_gjk(const DScene &S, const float *pv, const float 
         for (int i = 0; i < ac; i += 4) {                   // ac is a multiple of 4 (padded with copies of the last vertex)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float *q = av + 4 * (i + u);
+                const V4 q = load_v4(av + 4 * (i + u));
                 const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
                 const bool gt = sq > best;
                 best = gt ? sq : best;
@@ -1887,7 +1894,7 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
                     for (int i = 0; i < ac; i += 4)
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const float *q = av + 4 * (i + u);
+                            const V4 q = load_v4(av + 4 * (i + u));
                             const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
                             const bool gt = sq > bs;
                             bs = gt ? sq : bs;
@@ -2182,7 +2189,7 @@ __device__ __forceinline__ bool job_trip(JobLane &J, float &dist) {
             float sq[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float *q = J.av + 4 * (i + u);
+                const V4 q = load_v4(J.av + 4 * (i + u));
                 sq[u] = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
             }
 #pragma unroll
@@ -2192,7 +2199,8 @@ __device__ __forceinline__ bool job_trip(JobLane &J, float &dist) {
                 bi = gt ? i + u : bi;
             }
         }
-        return apply(J.XA, F3{J.av[4 * bi], J.av[4 * bi + 1], J.av[4 * bi + 2]});
+        const V4 pw = load_v4(J.av + 4 * bi);
+        return apply(J.XA, F3{pw[0], pw[1], pw[2]});
     };
     float d;
     if (!gjk_iterate(J.g, sa, sb, d)) return false;
@@ -2260,12 +2268,13 @@ __device__ __forceinline__ bool coop_iterate(GjkRun &g, const Xf &X, bool is_sta
         float best = -3.0e38f;
         int bi = 0;
         for (int i = l16; i < ac; i += 16) {
-            const float *q = av + 4 * i;
+            const V4 q = load_v4(av + 4 * i);
             const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
             if (sq > best) { best = sq; bi = i; }
         }
         const int ia = row_argmax(best, bi);
-        const F3 p = {av[4 * ia], av[4 * ia + 1], av[4 * ia + 2]};
+        const V4 pw = load_v4(av + 4 * ia);
+        const F3 p = {pw[0], pw[1], pw[2]};
         pa = is_static ? p : apply(X, p);
     }
     F3 pb;
@@ -2274,12 +2283,13 @@ __device__ __forceinline__ bool coop_iterate(GjkRun &g, const Xf &X, bool is_sta
         float best = -3.0e38f;
         int bi = 0;
         for (int i = l16; i < hcount; i += 16) {
-            const float *q = hv + 4 * i;
+            const V4 q = load_v4(hv + 4 * i);
             const float sq = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
             if (sq > best) { best = sq; bi = i; }
         }
         const int ib = row_argmax(best, bi);
-        const F3 p = {hv[4 * ib], hv[4 * ib + 1], hv[4 * ib + 2]};
+        const V4 pw = load_v4(hv + 4 * ib);
+        const F3 p = {pw[0], pw[1], pw[2]};
         pb = is_static ? apply(X, p) : p;
     }
     const F3 w = pa - pb;
@@ -2384,7 +2394,7 @@ __device__ __forceinline__ bool pool_trip(PoolLane &J, float &dist) {
             float sq[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const float *q = J.av + 4 * (i + u);
+                const V4 q = load_v4(J.av + 4 * (i + u));
                 sq[u] = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
             }
 #pragma unroll
@@ -2394,7 +2404,8 @@ __device__ __forceinline__ bool pool_trip(PoolLane &J, float &dist) {
                 bi = gt ? i + u : bi;
             }
         }
-        const F3 p = {J.av[4 * bi], J.av[4 * bi + 1], J.av[4 * bi + 2]};
+        const V4 pw = load_v4(J.av + 4 * bi);
+        const F3 p = {pw[0], pw[1], pw[2]};
         return J.is_static ? p : apply(J.X, p);
     };
     float d;

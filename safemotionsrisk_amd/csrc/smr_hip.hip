@@ -177,10 +177,10 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
         }
     }
     // the hull, edge graph and start map staged in LDS: every support call of this block climbs over them
-    __shared__ float lds_v[4 * kMaxPieceVerts];
+    __shared__ __attribute__((aligned(16))) float lds_v[4 * kMaxPieceVerts];
     __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
     __shared__ uint32_t lds_start[kStartCells / 4];
-    __shared__ float lds_pv[AUTO ? 4 * kMaxPlanetVerts : 4];
+    __shared__ __attribute__((aligned(16))) float lds_pv[AUTO ? 4 * kMaxPlanetVerts : 4];
     __shared__ float lds_pd[AUTO ? kPlanetDescDwords * kMaxPlanetPieces : 4];
     __shared__ uint32_t lds_keys[AUTO ? 7 * kBlock : 4];
     __shared__ uint16_t lds_items[kBlock * kMaxItemsPerLane];   // per wavefront: 64 x 23 entries (source lane << 5 | sample k)
@@ -314,11 +314,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_KEYS_WA
             return;
         }
     }
-    __shared__ float lds_v[4 * kMaxPieceVerts];
+    __shared__ __attribute__((aligned(16))) float lds_v[4 * kMaxPieceVerts];
     __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
     __shared__ uint32_t lds_start[kStartCells / 4];
     __shared__ uint32_t lds_keys[7 * kBlock];
-    __shared__ float lds_pv[4 * kMaxPlanetVerts];
+    __shared__ __attribute__((aligned(16))) float lds_pv[4 * kMaxPlanetVerts];
     __shared__ float lds_pd[kPlanetDescDwords * kMaxPlanetPieces];
     const int pl = S.link_piece[l];
     const DPiece LP = load_piece(S.pieces, pl);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_KEYS_WA
 
 // tables of the first / jobs kernels in dynamic LDS: the hull pool of the bodies that take part in moving / static queries
 // (DScene::job_pool), the planets' padded vertex lists and descriptors (+ the table's corners)
-extern __shared__ uint32_t job_lds[];
+extern __shared__ __attribute__((aligned(16))) uint32_t job_lds[];
 struct JobTables { BodyPool BP; const float *pv, *pd, *cyl; };
 constexpr int kJobCylDwords = 8 * 4;             // up to four world-fixed cylinders named by self-collision pairs (8 floats each)
 __device__ __forceinline__ JobTables stage_job_tables(const DScene &S) {
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
 // asking for the next chunk when 16 / 32 / 48 lanes have settled so that the counter's round trip runs beside the last trips
 // (slower the earlier it asks: the chunk then waits for the wavefront's longest run while other wavefronts are idle).
 template <bool SELF>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st, int defer_after) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st, int defer_after, int quota_max) {
     const DScene &S = *Sp;
 #ifdef SMR_PROFILE_ROWS
     const unsigned long long pc0 = SMR_DEV_CLOCK();
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #ifndef SMR_JOB_QUOTA_MIN
 #define SMR_JOB_QUOTA_MIN 4
 #endif
-    const int quota = min(64, max(SMR_JOB_QUOTA_MIN, (n_jobs + n_waves - 1) / n_waves));
+    const int quota = min(quota_max, max(SMR_JOB_QUOTA_MIN, (n_jobs + n_waves - 1) / n_waves));
     __shared__ int first_base;
     if (threadIdx.x == 0) first_base = atomicAdd(st.job_next, (int)(blockDim.x >> 6) * quota);
     const JobTables JT = stage_job_tables(S);           // (ends with a barrier)
@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
     const int partner = pair_block ? S.self_pair[pair][1] : -1;
     const int l = pair_block ? (partner >= 0 ? partner : body) : body;                    // the body whose hull is staged (see collide_kernel)
     if (!pair_block && !((S.static_mask >> body) & 1u)) return;                            // nothing of this body is observed by a static obstacle
-    __shared__ float lds_v[4 * kMaxPieceVerts];
+    __shared__ __attribute__((aligned(16))) float lds_v[4 * kMaxPieceVerts];
     __shared__ uint32_t lds_ids[kMaxPieceIdGroups];
     __shared__ uint32_t lds_start[kStartCells / 4];
     const int pl = S.link_piece[l];
@@ -1695,7 +1695,7 @@ __device__ __forceinline__ void spawn_body(const DScene *__restrict__ Sp, const 
                                            const int *__restrict__ count_ptr, int count_fixed, int all_reset, int group_stride,
                                            float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
-    __shared__ uint32_t pool[kBodyPoolDwords];
+    __shared__ __attribute__((aligned(16))) uint32_t pool[kBodyPoolDwords];
     const int count = count_ptr ? *count_ptr : count_fixed;
     if (!stage_body_pool(S, pool, count, group_stride)) return;
     const BodyPool BP{pool};
@@ -1786,7 +1786,7 @@ __global__ SMR_TARGET_KERNEL void target_kernel(const DScene *__restrict__ Sp, D
                                                     const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                     float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
-    __shared__ uint32_t pool[kBodyPoolDwords];
+    __shared__ __attribute__((aligned(16))) uint32_t pool[kBodyPoolDwords];
     const int n_entries = count_ptr ? *count_ptr : count_fixed;
     if (!stage_body_pool(S, pool, n_entries, group_stride)) return;
     const BodyPool BP{pool};
@@ -1855,7 +1855,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
                                                    const int *__restrict__ count_ptr, int count_fixed, int group_stride,
                                                    float *__restrict__ obs, const unsigned *__restrict__ tags, int tag_offset) {
     const DScene &S = *Sp;
-    __shared__ uint32_t pool[kBodyPoolDwords];
+    __shared__ __attribute__((aligned(16))) uint32_t pool[kBodyPoolDwords];
     const int count = count_ptr ? *count_ptr : count_fixed;
     if (!stage_body_pool(S, pool, count, group_stride)) return;
     const BodyPool BP{pool};
@@ -2392,6 +2392,7 @@ struct smr_env {
     int job_block_lanes = 512;        // (SMR_JOB_BLOCK_LANES: 256 / 128 for measurements)
     int defer_after = 0;              // jobs_kernel: a run leaves its lane after this many iterations for jobs_coop_kernel (0: never; SMR_JOB_DEFER)
     int coop_blocks = 0;              // ... whose grid is one 1024-lane block per CU
+    int job_quota_max = 64;           // jobs a wavefront takes per hand-out at most (SMR_JOB_QUOTA_MAX: fewer = idle lanes, shorter chains)
     bool job_pool = false;            // jobs_pool_kernel (prepared runs in LDS) instead of jobs_kernel for the pair jobs (SMR_JOB_POOL)
     int job_refill_idle = 16;         // ... its refill threshold (SMR_JOB_REFILL_IDLE)
     // lanes per block of brake_check: one wavefront - with three wavefronts per SIMD a 4-wavefront block rarely finds its four slots at
@@ -2771,6 +2772,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         env->job_blocks = std::max(prop.multiProcessorCount, 1) * (B <= 32768 ? 2 : 1);
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         if (const char *v = getenv("SMR_JOB_BLOCK_LANES")) if (atoi(v) == 256 || atoi(v) == 512 || atoi(v) == 128) env->job_block_lanes = atoi(v);
+        if (const char *v = getenv("SMR_JOB_QUOTA_MAX")) env->job_quota_max = std::max(4, std::min(64, atoi(v)));
         if (const char *v = getenv("SMR_JOB_DEFER")) env->defer_after = std::max(0, std::min(31, atoi(v)));
         env->coop_blocks = std::max(prop.multiProcessorCount, 1);
         if (const char *v = getenv("SMR_COOP_BLOCKS")) if (atoi(v) > 0) env->coop_blocks = atoi(v);
@@ -3208,7 +3210,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         // gained: reaching task 94 -> 86 M env-steps/s; ball scene beside the collide kernel: 63.6 -> 51.8 M; both measured)
         if (pairs) {
             hipLaunchKernelGGL(self_bounds_kernel, dim3((B + 255) / 256, env->hscene.n_self_pairs), dim3(256), 0, env->stream, env->dscene, env->st);
-            if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st, 0);
+            if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st, 0, 64);
         }
         if (env->hscene.planets_jobs) {
             const int env_blocks = (B + 255) / 256;
@@ -3235,8 +3237,8 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
                     const int off = (int)(env->job_lds_bytes / 4);
                     if (self) hipLaunchKernelGGL((jobs_pool_kernel<true>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
                     else hipLaunchKernelGGL((jobs_pool_kernel<false>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
-                } else if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after);
-                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after);
+                } else if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
+                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
                 if (env->defer_after > 0 && !env->job_pool) {
                     if (self) hipLaunchKernelGGL((jobs_coop_kernel<true>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
                     else hipLaunchKernelGGL((jobs_coop_kernel<false>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);

@@ -36,6 +36,7 @@ inline bool body_pool_tables(const smr_scene_t &s, const HostGeometry &G, std::v
         const DPiece &P = G.pieces[piece];
         // the vertex list is padded to a multiple of 8 with copies of its last vertex: the job kernels scan it eight at a time
         const uint32_t padded = ((uint32_t)P.count + 7u) & ~7u;
+        pool.resize((pool.size() + 3u) & ~(size_t)3u);          // vertices at 16-byte boundaries: they are read as 128-bit words (load_v4)
         const uint32_t v_off = (uint32_t)pool.size(), ids_off = v_off + 4u * padded, start_off = ids_off + (uint32_t)P.ids_count;
         const uint32_t piece_off = start_off + kStartCells / 4;
         pool[(size_t)kBodyPoolHead * b] = v_off; pool[(size_t)kBodyPoolHead * b + 1] = ids_off; pool[(size_t)kBodyPoolHead * b + 2] = start_off;
@@ -47,6 +48,7 @@ inline bool body_pool_tables(const smr_scene_t &s, const HostGeometry &G, std::v
         std::memcpy(pool.data() + ids_off, G.ids4.data() + P.ids_begin, 4 * (size_t)P.ids_count);
         std::memcpy(pool.data() + start_off, G.start.data() + (size_t)kStartCells * piece, kStartCells);
     }
+    pool.resize((pool.size() + 3u) & ~(size_t)3u);              // ... and so is whatever a kernel puts behind the pool (the planets' vertices)
     return (int)pool.size() <= kBodyPoolDwords;
 }
 
