@@ -148,6 +148,14 @@ int smr_synchronize(smr_env_t *env);
  * launch of every step is timed. */
 int smr_set_profiling(smr_env_t *env, int32_t enable);
 int smr_get_profile(smr_env_t *env, double ms_out[SMR_K_COUNT], int64_t launches_out[SMR_K_COUNT]);
+/* Episodes that ended inside smr_step and were restarted there (auto_reset) since smr_create: what the reference's _episode_counter
+ * (base.py:913-916, one increment per reset()) has counted on top of the explicit smr_reset calls.  Synchronises the stream. */
+int smr_episode_count(smr_env_t *env, int64_t *auto_resets_out);
+/* log_obstacle_data (ctlp.py:1279-1282,2639-2660: LinkData.closest_point_distance_set of the static obstacles): static_dev float32
+ * [n_bodies][B] <- the distance of every body to the static obstacles at the END of the last smr_step, as the step computed it: exact
+ * below the query range (closest_point_maximum_relevant_distance, 0.102 m), the range itself beyond it - the reference asks with
+ * distance = 10 m and after every 1/240 s update; bodies the table cannot reach report the range.  Enqueued on the stream. */
+int smr_link_distances(smr_env_t *env, float *static_dev);
 
 /* ---- fully connected networks on the GPU (the backup policy model/keras_fcnet_last_layer_activation.py and the
  * risk network train_risk_network.py:273-282).  Weights come as plain host arrays - a Keras Dense kernel [in][out] row major and

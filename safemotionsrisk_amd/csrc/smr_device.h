@@ -245,6 +245,7 @@ struct DState {
     int *job_next;                     // [1] the next job of the list nobody has taken yet (jobs_kernel), cleared by plan_kernel
     int job_cap;                       // capacity of jobs[]
     int *overflow_env;                 // [B] 1: a job of this env found the list full - overflow_kernel evaluates ALL its queries itself
+    unsigned long long *episodes;      // [1] episodes that ended inside step() and were restarted there (auto_reset): smr_episode_count
     float *defer;                      // [defer_cap][kDeferWords] runs that left their lane unsettled ("deferred runs"): jobs_kernel -> jobs_coop_kernel
     int *defer_count;                  // [1] cleared by plan_kernel
     int defer_cap;

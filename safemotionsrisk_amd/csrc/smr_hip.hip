@@ -418,7 +418,13 @@ __device__ __forceinline__ void job_flags(const DScene &S, const LaneInput &in, 
 // atomics execute at the memory side, and a wavefront's next refill waits for every one it has in flight)
 __device__ __forceinline__ void job_result(const DScene &S, const DState &st, const Job &jb, bool mov, bool con, float d, float seen) {
     const int B = S.B;
-    if (jb.kind == kJobStaticEnd) { if (d <= S.static_max) atomicMin(&st.env_dstatic[jb.env], dist_bits(d)); return; }
+    if (jb.kind == kJobStaticEnd) {
+        if (d <= S.static_max) {
+            atomicMin(&st.env_dstatic[jb.env], dist_bits(d));
+            atomicMin((unsigned *)st.dist + (size_t)jb.body * B + jb.env, dist_bits(d));       // the body's own entry too (smr_link_distances; non-negative floats order like their bits)
+        }
+        return;
+    }
     if (jb.kind == kJobSelf) { if (d < S.self_cut && d < seen) atomicMin(&st.env_dself[jb.env], dist_bits(d)); return; }
     if (mov && d <= S.moving_max && d < seen) atomicMin(&st.env_min[jb.env], dist_bits(d));
     if (con && d <= S.contact_dist) st.res[(size_t)jb.body * B + jb.env] = 1.f;
@@ -1121,7 +1127,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     }
     if (S.punish_bt_min && S.check_braking) {
         const float bt = __uint_as_float(st.bt_min[e]);
-        if (braked || bt < S.brake_safety) bt_pun = 1.f;                      // (a hit: below the safety distance; no standstill within the timeout counts as one)
+        if (bt < S.brake_safety) bt_pun = 1.f;                                // (a hit leaves its distance below the safety distance in bt_min; a braking timeout is punished by
+                                                                              //  the minimum over the samples walked like any other trajectory, ctlp.py:2393-2415,3185-3203)
         else if (bt < S.bt_thr) { const float x = fmaxf(fminf((S.bt_thr - bt) / (S.bt_thr - S.brake_safety), 1.f), 0.f); bt_pun = x * x; }
     }
     if (S.ca_mode)                                                            // CollisionAvoidanceReward, rewards.py:432-502
@@ -1161,6 +1168,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     st.moving_hit[e] = hit;
 
     if (S.use_ball) { st.ball_i[e] = ball_k; st.ball_i[3 * B + e] = ball_active; }
+    if (d && S.auto_reset) atomicAdd(st.episodes, 1ull);                       // (one atomic per wavefront after the compiler's aggregation)
     if (d && S.auto_reset && staged) {
         const unsigned tag = st.reset_count[e];
         commit_staged(S, st, e, obs + (size_t)e * S.obs_size);   // next episode's start state was prepared in the background
@@ -1428,8 +1436,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
     const int B = S.B;
     const int e = env_block * (int)blockDim.x + (int)threadIdx.x;
     if (e >= B) return;
-    const int steps = st.brake_steps[e];
-    if (steps < 0) return;                               // braking timeout: brake_plan_kernel latched braked[e] already (ctlp.py:3201-3203)
+    // braking timeout: brake_plan_kernel latched braked[e] already (ctlp.py:3201-3203).  The decision is made; what is left to know is
+    // _braking_trajectory_minimum_distance, the minimum over the samples the reference walked until it noticed (ctlp.py:3185-3203): the
+    // rows that keep it (BT) walk all brake_timeout_steps + 1 segments, the others leave
+    const int steps_planned = st.brake_steps[e];
+    if (steps_planned < 0 && !BT) return;
+    const int steps = steps_planned < 0 ? S.brake_timeout_steps : steps_planned;
     // the segment's cubic per joint in Horner form, q(t) = p + t (v + t (ha + t j6)) with ha = a0 / 2, j6 = (a1 - a0) / (6 dt): three
     // multiply-adds per joint and sample (fewer instructions and 8 fewer spilled registers than the monomial form; the kernel's time did not move)
     const float inv_dt6 = 1.0f / (6.0f * S.dt);
@@ -2392,6 +2404,8 @@ struct smr_env {
     int job_block_lanes = 512;        // (SMR_JOB_BLOCK_LANES: 256 / 128 for measurements)
     int defer_after = 0;              // jobs_kernel: a run leaves its lane after this many iterations for jobs_coop_kernel (0: never; SMR_JOB_DEFER)
     int coop_blocks = 0;              // ... whose grid is one 1024-lane block per CU
+    size_t side_lds_pad = 0;          // dynamic LDS added to the staged refill kernels' blocks (SMR_SIDE_LDS_PAD, bytes): with their 60 KB of
+                                      // tables > 80 KB per block = one block per CU, so that a jobs block (64 KB) always finds room beside it
     int job_quota_max = 64;           // jobs a wavefront takes per hand-out at most (SMR_JOB_QUOTA_MAX: fewer = idle lanes, shorter chains)
     bool job_pool = false;            // jobs_pool_kernel (prepared runs in LDS) instead of jobs_kernel for the pair jobs (SMR_JOB_POOL)
     int job_refill_idle = 16;         // ... its refill threshold (SMR_JOB_REFILL_IDLE)
@@ -2795,6 +2809,8 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
             if (const char *v = getenv("SMR_ITEM_BLOCKS")) if (atoi(v) > 0) env->item_blocks = atoi(v) * cu;
         }
     }
+    if ((rc = dev_alloc(env, &st.episodes, 1))) return fail(rc);
+    if (hipMemset(st.episodes, 0, 8)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     if ((rc = dev_alloc(env, &st.tp, 5 * B)) || (rc = dev_alloc(env, &st.tp_count, B)) || (rc = dev_alloc(env, &st.tp_list, B)) ||
         (rc = dev_alloc(env, &st.tp_list_count, 1)) || (rc = dev_alloc(env, &st.error_flags, 1))) return fail(rc);
     if (hipMemset(st.tp, 0, 5 * B * 4) || hipMemset(st.tp_count, 0, B * 4) || hipMemset(st.tp_list_count, 0, 4) || hipMemset(st.error_flags, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
@@ -2802,6 +2818,13 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     {
         const char *off = std::getenv("SMR_SYNC_RESET");          // debugging / A-B measurement: reset on the critical path
         env->staged = !(off && off[0] == '1');
+    }
+    if (const char *v = getenv("SMR_SIDE_LDS_PAD")) {
+        env->side_lds_pad = (size_t)std::max(0, std::min(96 * 1024, atoi(v)));
+        const int total = (int)env->side_lds_pad;
+        const void *fns[] = {(const void *)reset_kernel<true, true>, (const void *)reset_kernel<true, false>, (const void *)spawn_kernel_extra<true>, (const void *)spawn_kernel_plain<true>,
+                             (const void *)target_kernel<true, true>, (const void *)target_kernel<false, true>};
+        for (const void *f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, total);
     }
     if (env->staged) {
         if ((rc = dev_alloc(env, &st.next_q, 14 * B)) || (rc = dev_alloc(env, &st.next_v, 14 * B)) || (rc = dev_alloc(env, &st.next_a, 14 * B)) ||
@@ -2916,8 +2939,9 @@ static dim3 side_grid(int entries, int stride) { return dim3((unsigned)(((size_t
 template <bool STAGED>
 static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs,
                          const unsigned *tags = nullptr, int tag_offset = 0) {
-    if (scene_extra(env)) hipLaunchKernelGGL((reset_kernel<STAGED, true>), grid, dim3(kSideBlock), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
-    else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(kSideBlock), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
+    const size_t pad = STAGED ? env->side_lds_pad : 0;     // staged refills run beside the step: one block per CU leaves room for a jobs block (smr_create)
+    if (scene_extra(env)) hipLaunchKernelGGL((reset_kernel<STAGED, true>), grid, dim3(kSideBlock), pad, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
+    else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(kSideBlock), pad, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
 }
 
 static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int all_reset, int stride, float *obs) {
@@ -2927,8 +2951,8 @@ static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *co
 // the staged launch of the NEXT ball of the listed envs (after their current one was installed), on stream s
 static void launch_spawn_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride,
                                 const unsigned *tags = nullptr, int tag_offset = 0) {
-    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel_extra<true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
-    else hipLaunchKernelGGL((spawn_kernel_plain<true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
+    if (scene_extra(env)) hipLaunchKernelGGL((spawn_kernel_extra<true>), grid, dim3(kSideBlock), env->side_lds_pad, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
+    else hipLaunchKernelGGL((spawn_kernel_plain<true>), grid, dim3(kSideBlock), env->side_lds_pad, s, env->dscene, env->st, list, count_ptr, count_fixed, 0, stride, (float *)nullptr, tags, tag_offset);
 }
 
 static void launch_target(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride, float *obs) {
@@ -2938,8 +2962,8 @@ static void launch_target(smr_env *env, dim3 grid, const int *list, const int *c
 // the staged next target of the listed envs (after their current one was installed), on stream s
 static void launch_target_staged(smr_env *env, hipStream_t s, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int stride,
                                  const unsigned *tags = nullptr, int tag_offset = 0) {
-    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
-    else hipLaunchKernelGGL((target_kernel<false, true>), grid, dim3(kSideBlock), 0, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
+    if (scene_extra(env)) hipLaunchKernelGGL((target_kernel<true, true>), grid, dim3(kSideBlock), env->side_lds_pad, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
+    else hipLaunchKernelGGL((target_kernel<false, true>), grid, dim3(kSideBlock), env->side_lds_pad, s, env->dscene, env->st, list, count_ptr, count_fixed, stride, (float *)nullptr, tags, tag_offset);
 }
 
 static int launch_reset_list(smr_env *env, float *obs_dev) {
@@ -3036,6 +3060,10 @@ int smr_reset(smr_env_t *env, const uint8_t *mask_dev, float *obs_dev) {
     SMR_HIP(hipSetDevice(env->device));
     const int B = env->B;
     int rc;
+    // explicit resets are timed whenever timing is on at all (the sampling period of smr_set_profiling counts steps); the flag is this
+    // call's own - it does not inherit the phase the last step left behind
+    struct ProfilingScope { smr_env *e; bool saved; ~ProfilingScope() { e->profiling = saved; } } scope{env, env->profiling};
+    env->profiling = env->profile_every > 0;
     if (env->staged && mask_dev && !env->primed) {     // a partial reset as the very first call: nothing is staged yet
         if ((rc = staged_prepare_all(env, 0)) || (rc = staged_prepare_all(env, 1))) return rc;
     }
@@ -3110,6 +3138,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     const int B = env->B;
     // a pair of timing events is a pair of barrier packets in the queue: around every launch of every step they cost 65 us per step
     // (0.485 -> 0.550 ms at 65 536 envs, measured) - with a period the timed steps are a sample
+    struct ProfilingScope { smr_env *e; ~ProfilingScope() { e->profiling = false; } } profiling_scope{env};      // this call's own flag
     env->profiling = env->profile_every > 0 && (env->step_seq++ % env->profile_every) == 0;
     if (env->auto_reset && !(env->staged && env->auto_reset)) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));   // staged: unused
     if (env->hscene.use_ball) {
@@ -3363,8 +3392,8 @@ int smr_set_profiling(smr_env_t *env, int32_t enable) {
     if (!env) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     int rc = resolve_profile(env);
-    env->profile_every = enable > 0 ? enable : 0;
-    env->profiling = enable != 0;
+    env->profile_every = enable > 0 ? enable : 0;      // (a negative value switches it off like 0)
+    env->profiling = false;                             // decided per call: smr_step for its sampled steps, smr_reset whenever timing is on
     return rc;
 }
 
@@ -3379,6 +3408,23 @@ int smr_get_profile(smr_env_t *env, double ms_out[SMR_K_COUNT], int64_t launches
         env->prof_ms[k] = 0; env->prof_n[k] = 0;
     }
     return staged_check(env);
+}
+
+int smr_episode_count(smr_env_t *env, int64_t *auto_resets_out) {
+    if (!env || !auto_resets_out) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    SMR_HIP(hipStreamSynchronize(env->stream));
+    unsigned long long n = 0;
+    SMR_HIP(hipMemcpy(&n, env->st.episodes, sizeof n, hipMemcpyDeviceToHost));
+    *auto_resets_out = (int64_t)n;
+    return SMR_OK;
+}
+
+int smr_link_distances(smr_env_t *env, float *static_dev) {
+    if (!env || !static_dev) return SMR_E_INVALID;
+    SMR_HIP(hipSetDevice(env->device));
+    SMR_HIP(hipMemcpyAsync(static_dev, env->st.dist, (size_t)env->hscene.n_bodies * env->B * sizeof(float), hipMemcpyDeviceToDevice, env->stream));
+    return SMR_OK;
 }
 
 int smr_mlp_create(int32_t n_layers, const int32_t *sizes, const float *const *weights_host, const float *const *biases_host,

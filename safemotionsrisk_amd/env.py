@@ -69,7 +69,7 @@ class VecSafeMotionsEnv:
         self.action_space = Box(-1, 1, (NJ,))                                   # actions.py:49-51
         self.observation_space = Box(-1, 1, (self.observation_size,))           # obs.py:116-117
         self.trajectory_time_step = float(self.scene.struct.dt)
-        self.episode_counter = 0
+        self._explicit_resets = 0
         self._return_info = bool(return_info)
         self._seed = 0 if seed is None else int(seed)                           # base.py:1704-1710
         self._device_index, self._env_index_base = int(device), int(env_index_base)
@@ -113,7 +113,7 @@ class VecSafeMotionsEnv:
         self._seed = 0 if seed is None else int(seed)
         self.close()
         self._create()
-        self.episode_counter = 0
+        self._explicit_resets = 0
         # the fresh handle knows nothing of what was configured on the old one: put it back (risk-aware stepping, profiling)
         rollout = self._rollout
         self._rollout = None
@@ -132,7 +132,7 @@ class VecSafeMotionsEnv:
             m = mask.to(device=self.device, dtype=t.uint8).contiguous()
         rc = self._L.smr_reset(self._h, None if m is None else C.c_void_p(m.data_ptr()), C.c_void_p(self.obs.data_ptr()))
         _lib.check(self._L, self._h, rc, "smr_reset")
-        self.episode_counter += self.num_envs if m is None else int(m.sum().item())
+        self._explicit_resets += self.num_envs if m is None else int(m.sum().item())
         return self.obs
 
     def step(self, action):
@@ -237,6 +237,23 @@ class VecSafeMotionsEnv:
                 self._L.smr_set_risk_rollout(self._h, None, 0, C.c_float(0.0), None, None)
             self._L.smr_destroy(self._shadow_h)
             self._shadow_h = None
+
+    @property
+    def episode_counter(self):
+        """base.py:913-916: one count per reset() of an env - the explicit resets plus the restarts that happened inside step()
+        (auto_reset; counted on the device, reading it waits for the stream)"""
+        n = C.c_int64(0)
+        _lib.check(self._L, self._h, self._L.smr_episode_count(self._h, C.byref(n)), "smr_episode_count")
+        return self._explicit_resets + int(n.value)
+
+    def link_distances(self):
+        """[n_bodies, B] distances of the bodies to the static obstacles at the end of the last step (log_obstacle_data, ctlp.py:2639-2660;
+        exact below the query range of 0.102 m, the range beyond it): what metrics.EpisodeMetrics folds into obstacles_link_data_*"""
+        t = self._torch
+        if getattr(self, "_link_dist", None) is None:
+            self._link_dist = t.zeros((int(self.scene.struct.n_bodies), self.num_envs), dtype=t.float32, device=self.device)
+        _lib.check(self._L, self._h, self._L.smr_link_distances(self._h, C.c_void_p(self._link_dist.data_ptr())), "smr_link_distances")
+        return self._link_dist
 
     @property
     def risk_observation_size(self):

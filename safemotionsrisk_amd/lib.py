@@ -27,7 +27,7 @@ EXPORTS = ("smr_abi_version", "smr_scene_sizeof", "smr_create", "smr_destroy", "
            "smr_obs_size", "smr_reset", "smr_step", "smr_observe", "smr_get_state", "smr_set_state",
            "smr_synchronize", "smr_set_profiling", "smr_get_profile", "smr_test_fk", "smr_test_safe_acc_range",
            "smr_test_distances", "smr_test_ball_distances", "smr_test_self_bounds", "smr_test_brake_plan", "smr_mlp_create", "smr_mlp_destroy", "smr_mlp_forward",
-           "smr_set_risk_networks", "smr_set_risk_state_config", "smr_set_risk_rollout")
+           "smr_set_risk_networks", "smr_set_risk_state_config", "smr_set_risk_rollout", "smr_episode_count", "smr_link_distances")
 
 
 class HostState(C.Structure):
@@ -98,6 +98,8 @@ def load():
     L.smr_mlp_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     L.smr_set_risk_networks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
     L.smr_set_risk_state_config.argtypes = [C.c_void_p, C.c_int32]
+    L.smr_episode_count.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.smr_link_distances.argtypes = [C.c_void_p, C.c_void_p]
     L.smr_set_risk_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
     if L.smr_abi_version() != ABI_VERSION:
         raise RuntimeError("libsmr_hip.so ABI %d != binding ABI %d" % (L.smr_abi_version(), ABI_VERSION))

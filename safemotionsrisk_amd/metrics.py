@@ -97,6 +97,7 @@ class EpisodeMetrics:
         # episode-end statistics of the obstacle wrapper (ctlp.py:1141-1309): steps, steps with the braking trajectory executed,
         # target points reached, balls by final state (hit_robot, hit_obstacle, missed_robot)
         self.events = torch.zeros((self.num_envs, 8), **kw)      # ... steps with a risky action, first such step (0: none)
+        self.link_min = None                                       # [B, n_bodies] running minimum of env.link_distances() (log_obstacle_data)
 
     def step_scalars(self, obs, reward, info_values):
         """[B, K] per-step scalars (the values of the reference's info['average'] entries of this step)."""
@@ -107,11 +108,19 @@ class EpisodeMetrics:
         return t.cat([jo, jo.abs(), t.linalg.vector_norm(vel, dim=1, keepdim=True), info_values[:, self._info_sel].float(),
                       (d == 0).float(), reward.float().unsqueeze(1)], dim=1)
 
-    def update(self, obs, reward, done, info):
+    def update(self, obs, reward, done, info, link_distances=None):
         """Fold one step in; returns FinishedEpisodes for the envs with done set (their accumulators restart).
         With auto_reset the obs of a finished env already belongs to its next episode, so the obs-derived scalars of
-        terminal steps are left out there (every other scalar covers all steps)."""
+        terminal steps are left out there (every other scalar covers all steps).
+        link_distances: ``env.link_distances()`` of this step ([n_bodies, B]) when the reference's ``log_obstacle_data`` statistics are
+        wanted: the episode's minimum per body is reported as ``obstacles_link_data_table_body_<k>_closest_point_distance_set_min``
+        (= ``..._actual_min``: the setpoints are the actual values of a kinematic env; ctlp.py:1279-1282, LinkData.export_metrics
+        ctlp.py:5345-5358).  Sampled at the end of every step and exact below the query range of 0.102 m (the reference samples every
+        1/240 s with a range of 10 m); its observed-point lists are empty for observed_link_point_scene = 0."""
         t = self._t
+        if link_distances is not None:
+            ld = link_distances.t().float()
+            self.link_min = ld.clone() if self.link_min is None else t.minimum(self.link_min, ld)
         x = self.step_scalars(obs, reward, info["values"])
         valid = t.ones_like(x, dtype=t.bool)
         d = done.bool()
@@ -147,6 +156,11 @@ class EpisodeMetrics:
         for code, name in TERMINATION_RATE_KEYS.items():
             metrics[name] = (reason == code).float()
         metrics.update(self._obstacle_stats(self.events[idx]))
+        if self.link_min is not None:
+            for k in range(self.link_min.shape[1]):
+                metrics["obstacles_link_data_table_body_%d_closest_point_distance_set_min" % k] = self.link_min[idx, k]
+                metrics["obstacles_link_data_table_body_%d_closest_point_distance_actual_min" % k] = self.link_min[idx, k]
+            self.link_min[idx] = float("inf")
         for col, name in self._episode_cols:
             if col < info["values"].shape[1]:
                 metrics[name] = info["values"][idx, col].float()
@@ -161,8 +175,12 @@ class EpisodeMetrics:
     def _obstacle_stats(self, ev):
         """ObstacleWrapperSim.get_info_and_print_stats (ctlp.py:1141-1309), the part this path produces: the braking-trajectory
         influence (torque checks are physics: 0), target points reached, final states of the balls of the episode
-        (obstacles_starting_point_sampling_attempts comes from its info column, update()).  Not produced: the target-point
-        sampling attempts of several robots (ctlp.py:1171-1176) and obstacles_link_data_* (log_obstacle_data)."""
+        (obstacles_starting_point_sampling_attempts comes from its info column, obstacles_link_data_* from env.link_distances(), both
+        in update()).  Not produced: the target-point sampling attempts of several robots (ctlp.py:1171-1176) and the per-pair
+        obstacles_self_collision_data_* (the self distances exist per env, not per pair).
+        minimum_distance_self_collision_{average,min,max} differ from the reference's logged values where the self distance is at or
+        beyond the range its reward reads (SMR_INFO_D_SELF): the reference logs the closest-point distance up to
+        0.102 m, this column holds the range there; reward and termination are unaffected."""
         t = self._t
         steps, braked, reached, hit_robot, hit_obstacle, missed, risky, first_risky = ev.unbind(dim=1)
         infl = braked / steps.clamp(min=1)

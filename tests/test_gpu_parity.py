@@ -207,7 +207,7 @@ def test_reset_properties_and_oracle_agreement(built):
 
 
 def test_full_size_invariants_and_determinism(built):
-    """BASELINE size (65 536 envs, N=3, auto-reset): size-independent properties over 45 steps."""
+    """BASELINE size (65 536 envs, 24 contact samples per step = the default, auto-reset): size-independent properties over 45 steps."""
     import torch
     B, T = 65536, 45
     outs = []
@@ -1091,4 +1091,75 @@ def test_braking_layer_rollout_against_oracle(built):
         n_braked += int(info["values"][:, 8].sum().item())
     env.synchronize()
     assert not set(reasons) & {3, 4} and 5 in reasons and n_braked > 1000
+    env.close()
+
+
+@pytest.mark.gpu
+def test_braking_timeout_is_punished_by_the_walked_minimum(built):
+    """A braking trajectory that does not come to a standstill within the braking timeout counts as a collision (ctlp.py:3201-3203), but its
+    punish_braking_trajectory_min_distance term is the quadratic of the minimum distance over the samples that were walked (ctlp.py:2393-2415,
+    3185-3203), not 1.  The timeout is never reached with the shipped limits (every joint stops within 12 steps), so the scene's
+    brake_timeout_steps is cut to 2 here - for the kernels and the oracle alike."""
+    import torch
+    from safemotionsrisk_amd import VecSafeMotionsEnv
+    from safemotionsrisk_amd.scene import reach_brake_punish_env_config
+    from oracle.oracle import OracleEnv
+    B = 1024
+    env = VecSafeMotionsEnv(B, device=0, seed=5, auto_reset=False, **reach_brake_punish_env_config())
+    env.scene.struct.brake_timeout_steps = 2
+    env.set_seed(5)                                      # a fresh handle from the edited scene
+    env.reset()
+    ora = OracleEnv(env.scene, B, seed=5, num_threads=16)
+    rng = np.random.default_rng(3)
+    n_timeout = n_partial = 0
+    for t in range(4):
+        st = env.get_state()
+        st["v"] = (rng.uniform(-0.8, 0.8, (B, 7)) * np.array(env.scene.struct.vel_max)).astype(np.float32)      # moving joints do not stop in 3 segments
+        env.set_state(v=st["v"])
+        ora.set_state(**{k: st[k] for k in env.STATE_KEYS})
+        act = rng.uniform(-1, 1, (B, 7)).astype(np.float32)
+        obs, rew, done, info = env.step(torch.from_numpy(act).cuda())
+        o_obs, o_rew, o_done, o_reason, o_info = ora.step(act.astype(np.float64))
+        vals = info["values"].cpu().numpy()
+        same = (vals[:, 8] == o_info[:, 8]) & (done.cpu().numpy() == o_done)
+        assert same.mean() > 0.98
+        close = np.abs(vals[:, 13] - o_info[:, 13]) < 5e-3
+        assert (close | ~same).mean() > 0.99
+        braked = o_info[:, 8] > 0
+        n_timeout += int(braked.sum()); n_partial += int((braked & (o_info[:, 13] < 1.0)).sum())
+        if done.any():
+            env.reset(mask=done)
+    assert n_timeout > 0.5 * 4 * B and n_partial > 100        # most envs time out, and many of them with a punishment below 1
+    env.close()
+
+
+@pytest.mark.gpu
+def test_episode_counter_counts_auto_resets_and_link_distances_fold_to_the_static_distance(built):
+    """episode_counter (base.py:913-916: one count per reset()) includes the restarts inside step(); env.link_distances() - the per-body
+    distances to the static obstacles behind log_obstacle_data (ctlp.py:2639-2660) - have the step's static distance as their minimum,
+    and EpisodeMetrics reports their episode minima as obstacles_link_data_*."""
+    import torch
+    from safemotionsrisk_amd.metrics import EpisodeMetrics
+    B, T = 4096, 30
+    env = _env(B, seed=2, auto_reset=True)
+    env.reset()
+    assert env.episode_counter == B
+    met = EpisodeMetrics(B, env.INFO_COLUMNS, device=env.device, auto_reset=True)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    n_done, seen = 0, False
+    for t in range(T):
+        act = torch.rand((B, 7), device="cuda", generator=gen) * 2 - 1
+        act[:, 1] = 1.0; act[:, 3] = -1.0                    # towards the table: static distances inside the query range
+        obs, rew, done, info = env.step(act)
+        ld = env.link_distances()
+        fin = met.update(obs, rew, done, info, link_distances=ld)
+        d_static = info["values"][:, 0]
+        fold = torch.where(ld.min(dim=0).values < 0.001, torch.zeros_like(d_static), ld.min(dim=0).values)      # rewards.py:115-117
+        assert float((fold - d_static).abs().max()) < 1e-6
+        n_done += int(done.sum())
+        if len(fin):
+            key = "obstacles_link_data_table_body_7_closest_point_distance_set_min"
+            assert key in fin.metrics and fin.metrics[key].shape[0] == len(fin)
+            seen = seen or bool((fin.metrics[key] < 0.102).any())
+    assert env.episode_counter == B + n_done and n_done > B and seen
     env.close()
