@@ -238,6 +238,8 @@ struct DState {
                                        //     order like their bits); plan_kernel starts it at moving_max + 0.002
     unsigned *env_dstatic;             // [B] ... of the static distance found by deferred table runs (starts at static_max)
     float *frames;                     // [n_bodies][B][12] frame of (body, env) at t = dt: keys kernel -> the end-of-step jobs (job_setup)
+    unsigned *lb1;                     // [n_bodies][B] float bits of a lower bound of (env, body)'s BEST candidate's distance (low 5 bits: its piece; the
+                                       //     bound rounded down to make room): the first GJK iteration of that pair, made by the keys kernel anyway
     unsigned *env_dself;               // [B] ... of the self-collision distance: atomicMin over the env's self-pair jobs (starts at static_max)
     unsigned long long *items;         // intermediate contact samples still to be tested: job words (env, body, k) of kind kJobItem
     unsigned long long *jobs;          // GJK runs to make: job words (env, body, piece, k, kind)
@@ -1780,7 +1782,8 @@ struct LaneInput {
 // k_first .. k_need: the intermediate samples that still need a test (empty when k_first > k_need); lb_end: the bound at t = dt
 struct LaneResult { bool contact; float d_static, d_moving; int k_first, k_need; float lb_end; bool static_pending;
                     unsigned best; float ub;      // KEYS_ONLY: the best candidate (key << 5 | piece; ~0u: none) and an upper bound of ITS distance
-                    Xf frame; };                  // KEYS_ONLY: the body's frame at t = dt, handed on to the jobs of this (env, body)
+                    Xf frame;                     // KEYS_ONLY: the body's frame at t = dt, handed on to the jobs of this (env, body)
+                    float lb1; };                 // KEYS_ONLY: lower bound of the best candidate's distance from the same support pair (0: none)
 
 // frame of body l at time t of the step's cubic
 template <bool SELF, bool FAST = false>
@@ -1817,6 +1820,7 @@ template <bool SELF, bool AUTO, bool KEYS_ONLY = false, class HB>
 __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &LP, const HB &hull, const LaneInput &in,
                                           const float *lds_pv, const float *lds_pd, uint32_t *keys, int kstride) {
     LaneResult out = {false, S.static_max, S.moving_max + 0.002f, 1, 0, -1.f, false, 0xFFFFFFFFu, 3.0e38f};
+    out.lb1 = 0.f;
     const int N = S.checks_per_step, upd = S.updates_per_step / N;
     const bool con_link = (S.contact_mask >> l) & 1u;
     bool want_contact, sweep_contact, moving_alive = true;
@@ -1904,6 +1908,11 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
                     int hint = 0;
                     const F3 w = apply(XA, F3{av[4 * bi], av[4 * bi + 1], av[4 * bi + 2]}) - hull.support(v, hint, true);
                     out.ub = (sqrtf(dot(w, w)) - (d[2] + LP.margin)) * 1.00001f + 1e-6f;
+                    // ... and the LOWER bound the same pair gives: it is the first iteration of the pair's GJK run (same start vector, same
+                    // supports), whose separating-plane test v.w / |v| - margins > cutoff settles 56 % of all jobs (round 4 profile).  The
+                    // enumeration knows the cutoff - the env's upper bound - and drops the candidate there instead of making it a job.
+                    const float vw = dot(v, w);
+                    if (vw > 0.f) out.lb1 = (vw / sqrtf(dot(v, v)) - (d[2] + LP.margin)) * 0.99999f - 1e-6f;
                 }
                 out.best = (best >> 5) != 255u ? best : 0xFFFFFFFFu;
             } else planet_gjk(S, lds_pv, lds_pd, keys, kstride, LP, hull, T, idx, want_moving, want_contact, S.moving_max, r, static_pending);

@@ -355,6 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_KEYS_WA
             const Xf &T = r.frame;
             f[0] = V4{T.r[0], T.r[1], T.r[2], T.r[3]}; f[1] = V4{T.r[4], T.r[5], T.r[6], T.r[7]}; f[2] = V4{T.r[8], T.t.x, T.t.y, T.t.z};
         }
+        st.lb1[(size_t)l * B + e] = (r.best != 0xFFFFFFFFu && r.lb1 > 0.f) ? (((unsigned)__float_as_int(r.lb1) & ~31u) | (r.best & 31u)) : 0u;
         if (r.best != 0xFFFFFFFFu) {
             st.env_best[e] = 1u;                             // some body of the env has a candidate
             if (r.ub <= S.moving_max) atomicMin(&st.env_min[e], dist_bits(r.ub));
@@ -535,6 +536,12 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
                         const uint32_t key = (kws[w] >> (8 * k)) & 0xFFu;
                         if (key != 255u && (float)key * kKeyStep <= cutoff) mask |= 1u << (4 * w + k);
                     }
+                // the best candidate's first GJK iteration was made by the keys kernel: where its separating plane already lies beyond the
+                // cutoff the run would end there - no job (SMR_NO_LB1: A/B switch, compile time)
+#ifndef SMR_NO_LB1
+                const unsigned l1 = st.lb1[(size_t)b * B + e];
+                if (__uint_as_float(l1 & ~31u) > cutoff) mask &= ~(1u << (l1 & 31u));
+#endif
                 masks[b] = mask;
             }
         }
@@ -2770,7 +2777,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (cap > 0x7FFFFFFFull) { env->err = "num_envs too large for the job list"; return fail(SMR_E_INVALID); }
         st.job_cap = (int)cap;
         if ((rc = dev_alloc(env, &st.keyw, pj ? 7 * NB * B : 1)) || (rc = dev_alloc(env, &st.env_best, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_min, pj ? B : 1)) ||
-            (rc = dev_alloc(env, &st.env_dstatic, pj ? B : 1)) || (rc = dev_alloc(env, &st.frames, pj ? 12 * NB * B : 4)) || (rc = dev_alloc(env, &st.env_dself, B)) || (rc = dev_alloc(env, &st.items, (pj && N > 1) ? B * NB * (N - 1) : 1)) ||
+            (rc = dev_alloc(env, &st.env_dstatic, pj ? B : 1)) || (rc = dev_alloc(env, &st.frames, pj ? 12 * NB * B : 4)) || (rc = dev_alloc(env, &st.lb1, pj ? NB * B : 1)) || (rc = dev_alloc(env, &st.env_dself, B)) || (rc = dev_alloc(env, &st.items, (pj && N > 1) ? B * NB * (N - 1) : 1)) ||
             (rc = dev_alloc(env, &st.jobs, std::max<size_t>(cap, 1))) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) || (rc = dev_alloc(env, &st.job_next, 1)) ||
             (rc = dev_alloc(env, &st.overflow_env, B)) || (rc = dev_alloc(env, &st.defer_count, 1))) return fail(rc);
         st.defer_cap = (int)std::min<size_t>(4 * B + 4096, 1u << 22);      // up to ~2 deferred runs per env when every run leaves after its first iteration; a full list defers no more
