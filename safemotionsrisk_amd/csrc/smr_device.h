@@ -246,6 +246,13 @@ struct DState {
     int *item_count, *job_count;       // [1] each, cleared by plan_kernel
     int *job_next;                     // [1] the next job of the list nobody has taken yet (jobs_kernel), cleared by plan_kernel
     int job_cap;                       // capacity of jobs[]
+    // Two regions of jobs[] (round 4): [0, job_split) the jobs whose scanned side is short (ISS pieces up to 24 padded vertices, the table's
+    // 8 corners) and the self-collision pairs (appended first, by self_bounds_kernel: they sit together at the front), [job_split, job_cap)
+    // the jobs with a long scan (asteroid: 64 vertices, the station's largest piece: 56).  A wavefront scans as long as its longest lane:
+    // mixed, nearly every trip ran the asteroid's 8 rounds of 8 vertices for lanes that needed 1 to 3.
+    int *job_count_big;                // [1] jobs in the second region, cleared by plan_kernel
+    int job_split;
+    unsigned big_piece_mask;           // planet pieces (bit = index into the planet descriptors) whose padded vertex list is longer than kSmallScan
     int *overflow_env;                 // [B] 1: a job of this env found the list full - overflow_kernel evaluates ALL its queries itself
     unsigned long long *episodes;      // [1] episodes that ended inside step() and were restarted there (auto_reset): smr_episode_count
     float *defer;                      // [defer_cap][kDeferWords] runs that left their lane unsettled ("deferred runs"): jobs_kernel -> jobs_coop_kernel
@@ -1995,6 +2002,7 @@ __device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, co
 // ---------------------------------------------------------------------------------------------
 // kJobSelf: self-collision pair `piece` of the env at the end of the step (the job word's piece field holds the pair index)
 enum { kJobPlanetEnd = 0, kJobItem = 1, kJobStaticEnd = 2, kJobSelf = 3 };
+constexpr int kSmallScan = 24;        // padded vertices of a "short" scanned side (three rounds of eight)
 // job word: env 0..31 | body 32..35 | piece 36..41 | sample k 42..49 | kind 50..52.  k runs to checks_per_step (the end-of-step jobs carry
 // k = N), which check_scene bounds by kMaxChecksPerStep - the lane form's item queue packs (lane << 5 | k) and holds N - 1 items per lane.
 constexpr int kMaxChecksPerStep = 24;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
         }
         st.env_dself[e] = dist_bits(S.static_max);
         st.overflow_env[e] = 0;
-        if (e == 0) { *st.item_count = 0; *st.job_count = 0; *st.job_next = 0; *st.defer_count = 0; }
+        if (e == 0) { *st.item_count = 0; *st.job_count = 0; *st.job_count_big = 0; *st.job_next = 0; *st.defer_count = 0; }
     }
     float u = actions[(size_t)e * SMR_NJ + j];
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_KEYS_WA
         if (lane == 0) base = atomicAdd(st.item_count, total);
     }
     if (pending) {
-        if (slot < st.job_cap) st.jobs[slot] = job_word(e, l, S.auto_static, N, kJobStaticEnd);
+        if (slot < st.job_split) st.jobs[slot] = job_word(e, l, S.auto_static, N, kJobStaticEnd);
         else st.overflow_env[e] = 1;
     }
     if (items) {
@@ -448,26 +448,32 @@ __device__ __forceinline__ void job_limits(const DScene &S, const Job &jb, bool 
 template <int NM>
 __device__ __forceinline__ void push_jobs(const DState &st, int env, const int (&bodies)[NM], const uint32_t (&masks)[NM], int k, int kind) {
     const int lane = (int)__lane_id();
-    int n = 0;
+    // planet pieces with a long vertex list go to the second region of the list (DState::job_split); self pairs / the table stay in front
+    const unsigned big = (kind == kJobPlanetEnd || kind == kJobItem) ? st.big_piece_mask : 0u;
+    int n = 0, nb = 0;
 #pragma unroll
-    for (int i = 0; i < NM; ++i) n += __popc(masks[i]);
-    if (!__any(n > 0)) return;
-    int incl = n;
+    for (int i = 0; i < NM; ++i) { n += __popc(masks[i] & ~big); nb += __popc(masks[i] & big); }
+    if (!__any(n + nb > 0)) return;
+    int incl = n, inclb = nb;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-    const int total = __shfl(incl, 63);
-    int base = 0;
-    if (lane == 0) base = atomicAdd(st.job_count, total);
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d), tb = __shfl_up(inclb, d); if (lane >= d) { incl += t; inclb += tb; } }
+    const int total = __shfl(incl, 63), totalb = __shfl(inclb, 63);
+    int base = 0, baseb = 0;
+    if (lane == 0) {                                     // (both counters asked before either answer is used)
+        if (total > 0) base = atomicAdd(st.job_count, total);
+        if (totalb > 0) baseb = atomicAdd(st.job_count_big, totalb);
+    }
     base = __shfl(base, 0) + incl - n;
-    if (n > 0 && base + n > st.job_cap) st.overflow_env[env] = 1;
+    baseb = st.job_split + __shfl(baseb, 0) + inclb - nb;
+    if ((n > 0 && base + n > st.job_split) || (nb > 0 && baseb + nb > st.job_cap)) st.overflow_env[env] = 1;
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
         uint32_t mask = masks[i];
         while (mask) {
             const int piece = __ffs((int)mask) - 1;
             mask &= mask - 1;
-            if (base < st.job_cap) st.jobs[base] = job_word(env, bodies[i], piece, k, kind);
-            ++base;
+            if ((big >> piece) & 1u) { if (baseb < st.job_cap) st.jobs[baseb] = job_word(env, bodies[i], piece, k, kind); ++baseb; }
+            else { if (base < st.job_split) st.jobs[base] = job_word(env, bodies[i], piece, k, kind); ++base; }
         }
     }
 }
@@ -590,7 +596,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     const unsigned long long prof_w0 = wall_clock64();
     unsigned long long prof_w1 = 0;
 #endif
-    const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
+    const int n_front = min(*st.job_count, st.job_split), n_jobs = n_front + min(*st.job_count_big, st.job_cap - st.job_split);
     // An agent-scope atomic on the list counter is a round trip to the memory side of ~10 us, more when 2048 wavefronts ask at once
     // (profile counters: 83 000 of a wavefront's 390 000 cycles at 65 536 envs went into 2.5 of them; a look at the counter before
     // staging, to let late blocks leave, cost the kernel 4 %; a look before every read-modify-write 30 %).  So the first hand-out
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #endif
             const int rank = __popcll(idle & ((1ull << lane) - 1ull)), j = base + rank;
             if (!active && rank < take && j < n_jobs) {
-                jword = st.jobs[j];
+                jword = st.jobs[j < n_front ? j : st.job_split + (j - n_front)];      // the short scans first, then the long ones
                 jb = job_unpack(jword);
                 const LaneInput in = load_lane_input(S, st, jb.env);
                 job_flags(S, in, jb.body, mov, con);
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_POO
     const unsigned long long prof_w0 = wall_clock64();
     unsigned long long prof_w1 = 0;
 #endif
-    const int count = *st.job_count, n_jobs = count < st.job_cap ? count : st.job_cap;
+    const int n_front = min(*st.job_count, st.job_split), n_jobs = n_front + min(*st.job_count_big, st.job_cap - st.job_split);
     const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
     const int quota = min(64, max(SMR_JOB_QUOTA_MIN, (n_jobs + n_waves - 1) / n_waves));
     __shared__ int first_base;
@@ -847,7 +853,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_POO
             dry = dry || base + quota >= n_jobs;
             const int j = base + lane;
             if (lane < quota && j < n_jobs) {
-                const unsigned long long word = st.jobs[j];
+                const unsigned long long word = st.jobs[j < n_front ? j : st.job_split + (j - n_front)];
                 const Job nj = job_unpack(word);
                 const LaneInput in = load_lane_input(S, st, nj.env);
                 bool m2, c2;
@@ -2413,6 +2419,7 @@ struct smr_env {
     int coop_blocks = 0;              // ... whose grid is one 1024-lane block per CU
     size_t side_lds_pad = 0;          // dynamic LDS added to the staged refill kernels' blocks (SMR_SIDE_LDS_PAD, bytes): with their 60 KB of
                                       // tables > 80 KB per block = one block per CU, so that a jobs block (64 KB) always finds room beside it
+    std::vector<int> host_planet_padded;      // padded vertex count of every planet descriptor (auto_desc[..][1]), for DState::big_piece_mask
     int job_quota_max = 64;           // jobs a wavefront takes per hand-out at most (SMR_JOB_QUOTA_MAX: fewer = idle lanes, shorter chains)
     bool job_pool = false;            // jobs_pool_kernel (prepared runs in LDS) instead of jobs_kernel for the pair jobs (SMR_JOB_POOL)
     int job_refill_idle = 16;         // ... its refill threshold (SMR_JOB_REFILL_IDLE)
@@ -2581,6 +2588,8 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed,
         float4 *dav; float *dad;
         if ((rc = dev_upload(env, &dav, G.auto_verts)) || (rc = dev_upload(env, &dad, G.auto_desc))) return rc;
         d.auto_verts = (const float *)dav; d.auto_desc = dad;
+        env->host_planet_padded.clear();
+        for (size_t c = 0; c * kPlanetDescDwords < G.auto_desc.size(); ++c) { int padded; std::memcpy(&padded, &G.auto_desc[c * kPlanetDescDwords + 1], 4); env->host_planet_padded.push_back(padded); }
         // pair-job path (the default in planet scenes; SMR_COLLIDE_LANES=1: the lane-per-(env, body) collide kernel, for A/B runs)
         const char *lanes = getenv("SMR_COLLIDE_LANES");
         d.planets_jobs = !(lanes && atoi(lanes));
@@ -2776,14 +2785,23 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (const char *v = getenv("SMR_JOB_CAP")) cap = (size_t)std::max(0, atoi(v));       // tests: force the full-list path
         if (cap > 0x7FFFFFFFull) { env->err = "num_envs too large for the job list"; return fail(SMR_E_INVALID); }
         st.job_cap = (int)cap;
+        // the long scans: a quarter of the list.  One list for small batches, where the step is a chain of latencies and the second counter's
+        // round trip costs more than the shorter scans save (4096 envs: enumerate 0.020 -> 0.024 ms, measured); SMR_JOB_ONE_LIST=0 / 1: A/B switch
+        bool one_list = B <= 16384;
+        if (const char *v = getenv("SMR_JOB_ONE_LIST")) one_list = atoi(v) != 0;
+        st.job_split = one_list ? (int)cap : (int)(cap - cap / 4);
+        st.big_piece_mask = 0u;
+        if (pj && !one_list)
+            for (int c = 0; c < env->hscene.planet_pn && c < 32 && c < (int)env->host_planet_padded.size(); ++c)
+                if (env->host_planet_padded[c] > kSmallScan) st.big_piece_mask |= 1u << c;
         if ((rc = dev_alloc(env, &st.keyw, pj ? 7 * NB * B : 1)) || (rc = dev_alloc(env, &st.env_best, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_min, pj ? B : 1)) ||
             (rc = dev_alloc(env, &st.env_dstatic, pj ? B : 1)) || (rc = dev_alloc(env, &st.frames, pj ? 12 * NB * B : 4)) || (rc = dev_alloc(env, &st.lb1, pj ? NB * B : 1)) || (rc = dev_alloc(env, &st.env_dself, B)) || (rc = dev_alloc(env, &st.items, (pj && N > 1) ? B * NB * (N - 1) : 1)) ||
-            (rc = dev_alloc(env, &st.jobs, std::max<size_t>(cap, 1))) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) || (rc = dev_alloc(env, &st.job_next, 1)) ||
+            (rc = dev_alloc(env, &st.jobs, std::max<size_t>(cap, 1))) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) || (rc = dev_alloc(env, &st.job_count_big, 1)) || (rc = dev_alloc(env, &st.job_next, 1)) ||
             (rc = dev_alloc(env, &st.overflow_env, B)) || (rc = dev_alloc(env, &st.defer_count, 1))) return fail(rc);
         st.defer_cap = (int)std::min<size_t>(4 * B + 4096, 1u << 22);      // up to ~2 deferred runs per env when every run leaves after its first iteration; a full list defers no more
         if ((rc = dev_alloc(env, &st.defer, (size_t)st.defer_cap * kDeferWords))) return fail(rc);
         if (hipMemset(st.defer_count, 0, 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
-        if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4) || hipMemset(st.job_next, 0, 4) || hipMemset(st.overflow_env, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+        if (hipMemset(st.item_count, 0, 4) || hipMemset(st.job_count, 0, 4) || hipMemset(st.job_count_big, 0, 4) || hipMemset(st.job_next, 0, 4) || hipMemset(st.overflow_env, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) { env->err = "hipGetDeviceProperties failed"; return fail(SMR_E_HIP); }
         // one 512-lane block per CU at the full batch; two up to 32 768 envs, where the kernel is the chain of its longest wavefront and
