@@ -585,7 +585,12 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
 // What was measured on the way: refilling as soon as 16 / 32 lanes are idle (slower: a refill stalls the running lanes for a setup),
 // asking for the next chunk when 16 / 32 / 48 lanes have settled so that the counter's round trip runs beside the last trips
 // (slower the earlier it asks: the chunk then waits for the wavefront's longest run while other wavefronts are idle).
-template <bool SELF>
+// INWAVE (round 4, small batches): a run that has not settled after `defer_after` iterations in its lane is finished by a GROUP OF 16
+// LANES of its own wavefront (coop_iterate, smr_device.h "deferred runs") as soon as no lane-form run is left in the wavefront: four
+// runs at a time, full scans and row reductions instead of 12 000-cycle trips with one or two lanes switched on.  Below 32 768 envs
+// the kernel is the chain of its longest run (18 iterations); which form computes an iteration depends on the run's iteration count
+// alone, so the step stays deterministic.
+template <bool SELF, bool INWAVE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st, int defer_after, int quota_max) {
     const DScene &S = *Sp;
 #ifdef SMR_PROFILE_ROWS
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #endif
         { const int nn = J.g.n; prof_n[0] += __popcll(__ballot(active && nn <= 1)); prof_n[1] += __popcll(__ballot(active && nn == 2)); prof_n[2] += __popcll(__ballot(active && nn == 3)); }
 #endif
-        if (active && job_trip<SELF>(J, d)) {
+        if (active && !(INWAVE && J.g.it >= defer_after) && job_trip<SELF>(J, d)) {
             active = false;
             job_result(S, st, jb, mov, con, d, seen);
 #ifdef SMR_PROFILE_ROWS
@@ -694,9 +699,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
             prof_its = J.g.it + 1;
 #endif
         }
+        if (INWAVE) {
+            const unsigned long long waiting = __ballot(active && J.g.it >= defer_after);
+            if (waiting && !__ballot(active && J.g.it < defer_after)) {              // (wave uniform) no lane-form run left: finish the waiting ones
+                const float *lds0 = (const float *)job_lds;
+                // this lane's run as a group would need it: one frame (the scanned side seen from the hull's frame, or - world-frame runs -
+                // the hull body's world frame), the scanned side by LDS offset, the hull by body index
+                Xf Xl;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) Xl.r[i] = J.is_static ? J.T.r[i] : J.XA.r[i];
+                Xl.t = sel3(J.is_static, J.T.t, J.XA.t);
+                const int av_off = (int)(J.av - lds0), packed = J.ac | (J.hull_body << 9) | ((int)J.is_static << 13) | (J.g.n << 14) | (J.g.it << 17) | (J.g.stalls << 23);
+                for (unsigned long long rem = waiting; rem;) {
+                    int src[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { src[k] = rem ? __ffsll((long long)rem) - 1 : -1; rem &= rem - 1ull; }
+                    const int grp = lane >> 4;
+                    const int L = grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3];
+                    const bool gact = L >= 0;
+                    const int Ls = gact ? L : lane;
+                    GjkRun cg;
+                    Xf cX;
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) cX.r[i] = __shfl(Xl.r[i], Ls);
+                    cX.t = F3{__shfl(Xl.t.x, Ls), __shfl(Xl.t.y, Ls), __shfl(Xl.t.z, Ls)};
+                    cg.w0 = F3{__shfl(J.g.w0.x, Ls), __shfl(J.g.w0.y, Ls), __shfl(J.g.w0.z, Ls)}; cg.w1 = F3{__shfl(J.g.w1.x, Ls), __shfl(J.g.w1.y, Ls), __shfl(J.g.w1.z, Ls)};
+                    cg.w2 = F3{__shfl(J.g.w2.x, Ls), __shfl(J.g.w2.y, Ls), __shfl(J.g.w2.z, Ls)}; cg.w3 = F3{__shfl(J.g.w3.x, Ls), __shfl(J.g.w3.y, Ls), __shfl(J.g.w3.z, Ls)};
+                    cg.v = F3{__shfl(J.g.v.x, Ls), __shfl(J.g.v.y, Ls), __shfl(J.g.v.z, Ls)}; cg.vv = dot(cg.v, cg.v);
+                    cg.cutoff2 = __shfl(J.g.cutoff2, Ls); cg.stop2 = __shfl(J.g.stop2, Ls); cg.hint_a = 0; cg.hint_b = 0;
+                    const int pk = __shfl(packed, Ls), aoff = __shfl(av_off, Ls);
+                    cg.n = (pk >> 14) & 7; cg.it = (pk >> 17) & 63; cg.stalls = (pk >> 23) & 15;
+                    const int c_ac = pk & 511, c_hb = (pk >> 9) & 15;
+                    const bool c_static = (pk >> 13) & 1;
+                    const uint32_t *head_w = JT.BP.pool + kBodyPoolHead * c_hb;
+                    const float *c_hv = (const float *)JT.BP.pool + head_w[0];
+                    const int c_hcount = (int)JT.BP.pool[head_w[3] + 1];
+                    bool cdone = !gact;
+                    float cd = 0.f;
+                    for (;;) {
+                        if (!__any(!cdone)) break;
+                        float dd;
+                        if (!cdone && coop_iterate<SELF>(cg, cX, c_static, lds0 + aoff, c_ac, c_hv, c_hcount, dd)) { cdone = true; cd = dd; }
+                    }
+                    // back to the lanes that own the runs: lane src[k] reads its distance from group k
+                    const int mine = lane == src[0] ? 0 : lane == src[1] ? 1 : lane == src[2] ? 2 : lane == src[3] ? 3 : -1;
+                    const float dback = __shfl(cd, 16 * (mine < 0 ? 0 : mine));
+                    if (mine >= 0) {
+                        active = false;
+                        job_result(S, st, jb, mov, con, dback - J.margins, seen);
+                    }
+                }
+            }
+        }
         // a run that has used up its iterations in the lane form leaves as a record for jobs_coop_kernel (smr_device.h, "deferred runs"):
         // one atomic per wavefront and trip that has such runs, i.e. one per hand-out
-        {
+        if (!INWAVE) {
             const bool leave = active && defer_after > 0 && J.g.it >= defer_after;
             const unsigned long long lm = __ballot(leave);
             if (lm) {
@@ -2417,6 +2474,7 @@ struct smr_env {
     int job_block_lanes = 512;        // (SMR_JOB_BLOCK_LANES: 256 / 128 for measurements)
     int defer_after = 0;              // jobs_kernel: a run leaves its lane after this many iterations for jobs_coop_kernel (0: never; SMR_JOB_DEFER)
     int coop_blocks = 0;              // ... whose grid is one 1024-lane block per CU
+    int coop_inwave = 0;              // jobs_kernel<*, true>: runs are finished by 16-lane groups of their own wavefront after this many iterations (SMR_JOB_INWAVE)
     size_t side_lds_pad = 0;          // dynamic LDS added to the staged refill kernels' blocks (SMR_SIDE_LDS_PAD, bytes): with their 60 KB of
                                       // tables > 80 KB per block = one block per CU, so that a jobs block (64 KB) always finds room beside it
     std::vector<int> host_planet_padded;      // padded vertex count of every planet descriptor (auto_desc[..][1]), for DState::big_piece_mask
@@ -2812,6 +2870,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         if (const char *v = getenv("SMR_JOB_BLOCK_LANES")) if (atoi(v) == 256 || atoi(v) == 512 || atoi(v) == 128) env->job_block_lanes = atoi(v);
         if (const char *v = getenv("SMR_JOB_QUOTA_MAX")) env->job_quota_max = std::max(4, std::min(64, atoi(v)));
+        if (const char *v = getenv("SMR_JOB_INWAVE")) env->coop_inwave = std::max(0, std::min(31, atoi(v)));
         if (const char *v = getenv("SMR_JOB_DEFER")) env->defer_after = std::max(0, std::min(31, atoi(v)));
         env->coop_blocks = std::max(prop.multiProcessorCount, 1);
         if (const char *v = getenv("SMR_COOP_BLOCKS")) if (atoi(v) > 0) env->coop_blocks = atoi(v);
@@ -3291,9 +3350,12 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
                     const int off = (int)(env->job_lds_bytes / 4);
                     if (self) hipLaunchKernelGGL((jobs_pool_kernel<true>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
                     else hipLaunchKernelGGL((jobs_pool_kernel<false>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
+                } else if (env->coop_inwave > 0) {
+                    if (self) hipLaunchKernelGGL((jobs_kernel<true, true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->coop_inwave, env->job_quota_max);
+                    else hipLaunchKernelGGL((jobs_kernel<false, true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->coop_inwave, env->job_quota_max);
                 } else if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
                 else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
-                if (env->defer_after > 0 && !env->job_pool) {
+                if (env->defer_after > 0 && !env->job_pool && env->coop_inwave <= 0) {
                     if (self) hipLaunchKernelGGL((jobs_coop_kernel<true>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
                     else hipLaunchKernelGGL((jobs_coop_kernel<false>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
                 }

@@ -14,4 +14,5 @@ for g in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_
 done
 python3 scripts/make_pmc_json.py $O/pmc.json $C $ENVS $CHECKS $O/pmc_1 $O/pmc_2 $O/pmc_3 $O/pmc_4
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+rm -rf $O/stats $O/pmc_1 $O/pmc_2 $O/pmc_3 $O/pmc_4          # the raw traces: gpurun copies back at most 64 MiB
 head -12 $O/kernel_stats.csv

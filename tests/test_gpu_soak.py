@@ -7,7 +7,7 @@ short tests is a count: how many env-steps were compared, how many decisions dif
     SMR_SOAK_SEEDS=11,12,13   seeds (default: one seed, so that the suite stays short)
     SMR_SOAK_STEPS=25         steps per seed
     SMR_SOAK_ENVS=4096
-    SMR_SOAK_REPORT=path.json the counts as JSON (profiles/round3_soak_parity.json was written this way)
+    SMR_SOAK_REPORT=path.json the counts as JSON (profiles/round<R>_soak_parity.json are written this way)
 """
 import json
 import os
