@@ -2340,98 +2340,6 @@ __device__ __forceinline__ bool coop_iterate(GjkRun &g, const Xf &X, bool is_sta
 }
 #endif
 
-// ---- prepared runs (jobs kernel, round 4) -----------------------------------------------------
-// A job is SET UP by whichever lane draws it - all 64 lanes of a wavefront set up 64 jobs at once, whatever their own runs are doing -
-// and the result waits in the wavefront's LDS pool until a lane whose run has settled takes it.  Setting up (state loads, the body's
-// frame, the piece's frame composed into it) and iterating are then both dense: the trips no longer run with the lanes of settled
-// runs switched off until the wavefront's longest run is through (round 3: 30 % of the lanes had a run on an average trip).
-// Record (SoA: word w of entry r at pool[w * 64 + r], conflict free for dense writes and for reads of distinct entries):
-//   0..11 frame (the scanned piece seen from the body frame; table / cylinder runs: the body's world frame)   12..14 start vector
-//   15 cutoff^2   16 stop^2   17 margins   18 the env's minimum when the job was drawn   19 meta   20..21 job word
-// meta: av (dword offset of the scanned side's vertices / cylinder parameters in the block's LDS) 0..15 | ac 16..24 | hull body 25..28 |
-//       world-frame run 29 | mov 30 | con 31
-constexpr int kRunWords = 22;
-struct PoolLane {
-    GjkRun g;
-    Xf X;
-    LocalHull hull;
-    const float *av; int ac;
-    float margins;
-    bool is_static;
-};
-// lds0: base of the block's dynamic LDS (what the av offsets are relative to)
-template <bool SELF>
-__device__ inline void run_prepare(const DScene &S, const BodyPool &BP, const float *pv, const float *pd, const float *cyl, const float *lds0,
-                                   const LaneInput &in, const float *frames, const Job &jb, bool mov, bool con, float cutoff, float stop_below,
-                                   float seen, unsigned long long word, float *pool, int r) {
-    JobLane J;
-    job_setup<SELF>(S, BP, pv, pd, cyl, in, frames, jb, cutoff, stop_below, J);
-    int hull_body = jb.body;
-    if (SELF && jb.kind == kJobSelf) { const int a = S.self_pair[jb.piece][0], partner = S.self_pair[jb.piece][1]; hull_body = partner >= 0 ? partner : a; }
-    const Xf &X = J.is_static ? J.T : J.XA;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) pool[i * 64 + r] = X.r[i];
-    pool[9 * 64 + r] = X.t.x; pool[10 * 64 + r] = X.t.y; pool[11 * 64 + r] = X.t.z;
-    pool[12 * 64 + r] = J.g.v.x; pool[13 * 64 + r] = J.g.v.y; pool[14 * 64 + r] = J.g.v.z;
-    pool[15 * 64 + r] = J.g.cutoff2; pool[16 * 64 + r] = J.g.stop2; pool[17 * 64 + r] = J.margins; pool[18 * 64 + r] = seen;
-    pool[19 * 64 + r] = __int_as_float((int)run_meta((int)(J.av - lds0), J.ac, hull_body, J.is_static, mov, con));
-    pool[20 * 64 + r] = __int_as_float((int)(unsigned)(word & 0xFFFFFFFFull)); pool[21 * 64 + r] = __int_as_float((int)(unsigned)(word >> 32));
-}
-__device__ __forceinline__ void run_take(const BodyPool &BP, const float *lds0, const float *pool, int r, PoolLane &J, Job &jb, bool &mov, bool &con, float &seen) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) J.X.r[i] = pool[i * 64 + r];
-    J.X.t = F3{pool[9 * 64 + r], pool[10 * 64 + r], pool[11 * 64 + r]};
-    const F3 v0 = {pool[12 * 64 + r], pool[13 * 64 + r], pool[14 * 64 + r]};
-    J.g.start(v0, 0.f, 0.f);
-    J.g.cutoff2 = pool[15 * 64 + r]; J.g.stop2 = pool[16 * 64 + r]; J.margins = pool[17 * 64 + r]; seen = pool[18 * 64 + r];
-    const unsigned meta = (unsigned)__float_as_int(pool[19 * 64 + r]);
-    J.av = lds0 + (meta & 0xFFFFu); J.ac = (int)((meta >> 16) & 0x1FFu); J.hull = BP.hull((int)((meta >> 25) & 15u));
-    J.is_static = (meta >> 29) & 1u; mov = (meta >> 30) & 1u; con = (meta >> 31) & 1u;
-    jb = job_unpack((unsigned long long)(unsigned)__float_as_int(pool[20 * 64 + r]) | ((unsigned long long)(unsigned)__float_as_int(pool[21 * 64 + r]) << 32));
-}
-// one iteration of a taken run: job_trip with the one frame the run needs (the scanned side under X and the hull in its own frame, or -
-// world-frame runs - the scanned side as it is and the hull under X).  Same arithmetic: the identity job_trip applies to the other side
-// changes no bit (x * 1 + 0 * y + 0 * z, p + 0).
-template <bool SELF>
-__device__ __forceinline__ bool pool_trip(PoolLane &J, float &dist) {
-    const auto sb = [&](F3 d, int &hint, bool first) {
-        const F3 p = J.hull.support(J.is_static ? rot_t(J.X, d) : d, hint, first);
-        return J.is_static ? apply(J.X, p) : p;
-    };
-    const auto sa = [&](F3 d, int &, bool) {
-        if (SELF && J.ac == 0) {                           // btCylinderShapeZ::localGetSupportingVertexWithoutMargin, world frame
-            const float sxy = sqrtf(d.x * d.x + d.y * d.y), r = J.av[3];
-            F3 p = sxy > 0.f ? F3{J.av[0] + r * d.x / sxy, J.av[1] + r * d.y / sxy, J.av[2]} : F3{J.av[0] + r, J.av[1], J.av[2]};
-            p.z += d.z < 0.f ? -J.av[4] : J.av[4];
-            return p;
-        }
-        const F3 dl = J.is_static ? d : rot_t(J.X, d);
-        float best = -3.0e38f;
-        int bi = 0;
-        for (int i = 0; i < J.ac; i += 8) {                // padded to multiples of 8: eight vertex reads in flight per round trip
-            float sq[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const V4 q = load_v4(J.av + 4 * (i + u));
-                sq[u] = fmaf(q[2], dl.z, fmaf(q[1], dl.y, q[0] * dl.x));
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool gt = sq[u] > best;
-                best = gt ? sq[u] : best;
-                bi = gt ? i + u : bi;
-            }
-        }
-        const V4 pw = load_v4(J.av + 4 * bi);
-        const F3 p = {pw[0], pw[1], pw[2]};
-        return J.is_static ? p : apply(J.X, p);
-    };
-    float d;
-    if (!gjk_iterate(J.g, sa, sb, d)) return false;
-    dist = d - J.margins;
-    return true;
-}
-
 // A15: planet part of the observation (obs.py:262-292)
 __device__ inline void write_planet_observation(const DScene &S, const int idx[SMR_MAX_PLANETS], float *row) {
     int o = 0;

@@ -585,12 +585,7 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
 // What was measured on the way: refilling as soon as 16 / 32 lanes are idle (slower: a refill stalls the running lanes for a setup),
 // asking for the next chunk when 16 / 32 / 48 lanes have settled so that the counter's round trip runs beside the last trips
 // (slower the earlier it asks: the chunk then waits for the wavefront's longest run while other wavefronts are idle).
-// INWAVE (round 4, small batches): a run that has not settled after `defer_after` iterations in its lane is finished by a GROUP OF 16
-// LANES of its own wavefront (coop_iterate, smr_device.h "deferred runs") as soon as no lane-form run is left in the wavefront: four
-// runs at a time, full scans and row reductions instead of 12 000-cycle trips with one or two lanes switched on.  Below 32 768 envs
-// the kernel is the chain of its longest run (18 iterations); which form computes an iteration depends on the run's iteration count
-// alone, so the step stays deterministic.
-template <bool SELF, bool INWAVE = false>
+template <bool SELF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st, int defer_after, int quota_max) {
     const DScene &S = *Sp;
 #ifdef SMR_PROFILE_ROWS
@@ -691,7 +686,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #endif
         { const int nn = J.g.n; prof_n[0] += __popcll(__ballot(active && nn <= 1)); prof_n[1] += __popcll(__ballot(active && nn == 2)); prof_n[2] += __popcll(__ballot(active && nn == 3)); }
 #endif
-        if (active && !(INWAVE && J.g.it >= defer_after) && job_trip<SELF>(J, d)) {
+        if (active && job_trip<SELF>(J, d)) {
             active = false;
             job_result(S, st, jb, mov, con, d, seen);
 #ifdef SMR_PROFILE_ROWS
@@ -699,61 +694,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
             prof_its = J.g.it + 1;
 #endif
         }
-        if (INWAVE) {
-            const unsigned long long waiting = __ballot(active && J.g.it >= defer_after);
-            if (waiting && !__ballot(active && J.g.it < defer_after)) {              // (wave uniform) no lane-form run left: finish the waiting ones
-                const float *lds0 = (const float *)job_lds;
-                // this lane's run as a group would need it: one frame (the scanned side seen from the hull's frame, or - world-frame runs -
-                // the hull body's world frame), the scanned side by LDS offset, the hull by body index
-                Xf Xl;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) Xl.r[i] = J.is_static ? J.T.r[i] : J.XA.r[i];
-                Xl.t = sel3(J.is_static, J.T.t, J.XA.t);
-                const int av_off = (int)(J.av - lds0), packed = J.ac | (J.hull_body << 9) | ((int)J.is_static << 13) | (J.g.n << 14) | (J.g.it << 17) | (J.g.stalls << 23);
-                for (unsigned long long rem = waiting; rem;) {
-                    int src[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { src[k] = rem ? __ffsll((long long)rem) - 1 : -1; rem &= rem - 1ull; }
-                    const int grp = lane >> 4;
-                    const int L = grp == 0 ? src[0] : grp == 1 ? src[1] : grp == 2 ? src[2] : src[3];
-                    const bool gact = L >= 0;
-                    const int Ls = gact ? L : lane;
-                    GjkRun cg;
-                    Xf cX;
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) cX.r[i] = __shfl(Xl.r[i], Ls);
-                    cX.t = F3{__shfl(Xl.t.x, Ls), __shfl(Xl.t.y, Ls), __shfl(Xl.t.z, Ls)};
-                    cg.w0 = F3{__shfl(J.g.w0.x, Ls), __shfl(J.g.w0.y, Ls), __shfl(J.g.w0.z, Ls)}; cg.w1 = F3{__shfl(J.g.w1.x, Ls), __shfl(J.g.w1.y, Ls), __shfl(J.g.w1.z, Ls)};
-                    cg.w2 = F3{__shfl(J.g.w2.x, Ls), __shfl(J.g.w2.y, Ls), __shfl(J.g.w2.z, Ls)}; cg.w3 = F3{__shfl(J.g.w3.x, Ls), __shfl(J.g.w3.y, Ls), __shfl(J.g.w3.z, Ls)};
-                    cg.v = F3{__shfl(J.g.v.x, Ls), __shfl(J.g.v.y, Ls), __shfl(J.g.v.z, Ls)}; cg.vv = dot(cg.v, cg.v);
-                    cg.cutoff2 = __shfl(J.g.cutoff2, Ls); cg.stop2 = __shfl(J.g.stop2, Ls); cg.hint_a = 0; cg.hint_b = 0;
-                    const int pk = __shfl(packed, Ls), aoff = __shfl(av_off, Ls);
-                    cg.n = (pk >> 14) & 7; cg.it = (pk >> 17) & 63; cg.stalls = (pk >> 23) & 15;
-                    const int c_ac = pk & 511, c_hb = (pk >> 9) & 15;
-                    const bool c_static = (pk >> 13) & 1;
-                    const uint32_t *head_w = JT.BP.pool + kBodyPoolHead * c_hb;
-                    const float *c_hv = (const float *)JT.BP.pool + head_w[0];
-                    const int c_hcount = (int)JT.BP.pool[head_w[3] + 1];
-                    bool cdone = !gact;
-                    float cd = 0.f;
-                    for (;;) {
-                        if (!__any(!cdone)) break;
-                        float dd;
-                        if (!cdone && coop_iterate<SELF>(cg, cX, c_static, lds0 + aoff, c_ac, c_hv, c_hcount, dd)) { cdone = true; cd = dd; }
-                    }
-                    // back to the lanes that own the runs: lane src[k] reads its distance from group k
-                    const int mine = lane == src[0] ? 0 : lane == src[1] ? 1 : lane == src[2] ? 2 : lane == src[3] ? 3 : -1;
-                    const float dback = __shfl(cd, 16 * (mine < 0 ? 0 : mine));
-                    if (mine >= 0) {
-                        active = false;
-                        job_result(S, st, jb, mov, con, dback - J.margins, seen);
-                    }
-                }
-            }
-        }
         // a run that has used up its iterations in the lane form leaves as a record for jobs_coop_kernel (smr_device.h, "deferred runs"):
         // one atomic per wavefront and trip that has such runs, i.e. one per hand-out
-        if (!INWAVE) {
+        {
             const bool leave = active && defer_after > 0 && J.g.it >= defer_after;
             const unsigned long long lm = __ballot(leave);
             if (lm) {
@@ -850,123 +793,6 @@ __global__ __launch_bounds__(1024) void jobs_coop_kernel(const DScene *__restric
             if (head) job_result(S, st, jb, mov, con, d - margins, seen);
         }
     }
-}
-
-// jobs kernel, round 4: prepared runs in an LDS pool (smr_device.h, "prepared runs").  The stream, the tables and the results are those of
-// jobs_kernel above; what changes is who iterates what.  A wavefront that runs out of prepared runs draws the next `quota` jobs and ALL its
-// lanes set them up into its pool (pool_off: dword offset of the pools behind the tables, 64 x kRunWords per wavefront); a lane whose run
-// has settled takes the next prepared run at once.  refill_idle: how many lanes must be without a run before an empty pool is refilled
-// (1: at once - the wavefront then holds up to 64 prepared runs nobody else can take when the stream dries up; 64: as jobs_kernel).
-#ifndef SMR_JOB_POOL_WAVES
-#define SMR_JOB_POOL_WAVES 2          // one 512-lane block per CU: two wavefronts per SIMD, 256 registers each
-#endif
-template <bool SELF>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_POOL_WAVES, SMR_JOB_POOL_WAVES))) void jobs_pool_kernel(const DScene *__restrict__ Sp, DState st, int pool_off, int refill_idle) {
-    const DScene &S = *Sp;
-#ifdef SMR_PROFILE_ROWS
-    const unsigned long long pc0 = SMR_DEV_CLOCK();
-    unsigned long long pc_setup = 0, pc_trip = 0;
-    int prof_trips = 0, prof_refills = 0, prof_maxit = 0, prof_lanes = 0;
-    const unsigned prof_wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const unsigned long long prof_w0 = wall_clock64();
-    unsigned long long prof_w1 = 0;
-#endif
-    const int n_front = min(*st.job_count, st.job_split), n_jobs = n_front + min(*st.job_count_big, st.job_cap - st.job_split);
-    const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
-    const int quota = min(64, max(SMR_JOB_QUOTA_MIN, (n_jobs + n_waves - 1) / n_waves));
-    __shared__ int first_base;
-    if (threadIdx.x == 0) first_base = atomicAdd(st.job_next, (int)(blockDim.x >> 6) * quota);      // (its round trip hides behind the staging)
-    const JobTables JT = stage_job_tables(S);           // (ends with a barrier)
-#ifdef SMR_PROFILE_ROWS
-    SMR_DEV_COUNT(26, SMR_DEV_CLOCK() - pc0);
-    prof_w1 = wall_clock64();
-#endif
-    const float *lds0 = (const float *)job_lds;
-    float *pool = (float *)job_lds + pool_off + (int)(threadIdx.x >> 6) * 64 * kRunWords;
-    const int lane = (int)__lane_id();
-    bool active = false, mov = false, con = false, first = true;
-    bool dry = (long long)n_waves * quota >= (long long)n_jobs;
-    int stock = 0;                                        // prepared runs in this wavefront's pool (wave uniform)
-    Job jb = {0, 0, 0, 0, 0};
-    float seen = 0.f;
-    PoolLane J;
-    J.g.start(F3{1.f, 0.f, 0.f}, 0.f, 0.f);
-    J.X = Xf{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, F3{0.f, 0.f, 0.f}};
-    J.hull = JT.BP.hull(0); J.av = JT.pv; J.ac = 0; J.margins = 0.f; J.is_static = false;
-    for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        const int n_idle = __popcll(idle);
-        if (stock == 0 && n_idle >= refill_idle && (first || !dry)) {
-#ifdef SMR_PROFILE_ROWS
-            const unsigned long long t0 = SMR_DEV_CLOCK();
-            ++prof_refills;
-#endif
-            int base = 0;
-            if (first) { base = first_base + (int)(threadIdx.x >> 6) * quota; first = false; }
-            else {
-                if (lane == 0) base = atomicAdd(st.job_next, quota);
-                base = __builtin_amdgcn_readfirstlane(base);
-            }
-            dry = dry || base + quota >= n_jobs;
-            const int j = base + lane;
-            if (lane < quota && j < n_jobs) {
-                const unsigned long long word = st.jobs[j < n_front ? j : st.job_split + (j - n_front)];
-                const Job nj = job_unpack(word);
-                const LaneInput in = load_lane_input(S, st, nj.env);
-                bool m2, c2;
-                job_flags(S, in, nj.body, m2, c2);
-                if (nj.kind == kJobItem) { m2 = false; c2 = true; }
-                const unsigned *running = (SELF && nj.kind == kJobSelf) ? st.env_dself : st.env_min;
-                const float sn = __uint_as_float(running[nj.env]);       // a plain load: a stale value is still an upper bound
-                float cutoff, stop;
-                job_limits(S, nj, m2, c2, sn, cutoff, stop);
-                run_prepare<SELF>(S, JT.BP, JT.pv, JT.pd, JT.cyl, lds0, in, st.frames, nj, m2, c2, cutoff, stop, sn, word, pool, lane);
-            }
-            stock = max(0, min(quota, n_jobs - base));
-#ifdef SMR_PROFILE_ROWS
-            pc_setup += SMR_DEV_CLOCK() - t0;
-#endif
-        }
-        if (n_idle > 0 && stock > 0) {                    // (the pool is this wavefront's own: written and read in program order, no barrier)
-            const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-            if (!active && rank < stock) {
-                run_take(JT.BP, lds0, pool, stock - 1 - rank, J, jb, mov, con, seen);
-                active = true;
-            }
-            stock -= min(n_idle, stock);
-        }
-        if (!__any(active)) {
-            if (stock == 0 && dry && !first) break;
-            continue;
-        }
-#ifdef SMR_PROFILE_ROWS
-        const unsigned long long t1 = SMR_DEV_CLOCK();
-        ++prof_trips;
-        prof_lanes += __popcll(__ballot(active));
-#endif
-        float d;
-        if (active && pool_trip<SELF>(J, d)) {
-            active = false;
-            job_result(S, st, jb, mov, con, d, seen);
-#ifdef SMR_PROFILE_ROWS
-            prof_maxit = max(prof_maxit, J.g.it + 1);
-#endif
-        }
-#ifdef SMR_PROFILE_ROWS
-        pc_trip += SMR_DEV_CLOCK() - t1;
-#endif
-    }
-#ifdef SMR_PROFILE_ROWS
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) prof_maxit = max(prof_maxit, __shfl_xor(prof_maxit, d));
-    SMR_DEV_COUNT(27, pc_setup); SMR_DEV_COUNT(28, pc_trip); SMR_DEV_COUNT(29, prof_trips); SMR_DEV_MAX(30, prof_maxit);
-    SMR_DEV_MAX(31, SMR_DEV_CLOCK() - pc0); SMR_DEV_COUNT(25, prof_refills); SMR_DEV_COUNT(10, prof_lanes);
-    if (prof_wave < 16384u && (threadIdx.x & 63) == 0) {
-        g_block_times[2 * prof_wave] = prof_w0; g_block_times[2 * prof_wave + 1] = wall_clock64();
-        g_wave_rec[8 * prof_wave] = (unsigned)prof_refills; g_wave_rec[8 * prof_wave + 1] = (unsigned)prof_trips; g_wave_rec[8 * prof_wave + 2] = (unsigned)prof_maxit;
-        g_wave_rec[8 * prof_wave + 3] = (unsigned)(prof_w1 - prof_w0);
-    }
-#endif
 }
 
 // env.reset() from the staged start state (prepared by reset_kernel<true> for tag reset_count[e]): obs.py:144-149
@@ -2474,13 +2300,10 @@ struct smr_env {
     int job_block_lanes = 512;        // (SMR_JOB_BLOCK_LANES: 256 / 128 for measurements)
     int defer_after = 0;              // jobs_kernel: a run leaves its lane after this many iterations for jobs_coop_kernel (0: never; SMR_JOB_DEFER)
     int coop_blocks = 0;              // ... whose grid is one 1024-lane block per CU
-    int coop_inwave = 0;              // jobs_kernel<*, true>: runs are finished by 16-lane groups of their own wavefront after this many iterations (SMR_JOB_INWAVE)
     size_t side_lds_pad = 0;          // dynamic LDS added to the staged refill kernels' blocks (SMR_SIDE_LDS_PAD, bytes): with their 60 KB of
                                       // tables > 80 KB per block = one block per CU, so that a jobs block (64 KB) always finds room beside it
     std::vector<int> host_planet_padded;      // padded vertex count of every planet descriptor (auto_desc[..][1]), for DState::big_piece_mask
     int job_quota_max = 64;           // jobs a wavefront takes per hand-out at most (SMR_JOB_QUOTA_MAX: fewer = idle lanes, shorter chains)
-    bool job_pool = false;            // jobs_pool_kernel (prepared runs in LDS) instead of jobs_kernel for the pair jobs (SMR_JOB_POOL)
-    int job_refill_idle = 16;         // ... its refill threshold (SMR_JOB_REFILL_IDLE)
     // lanes per block of brake_check: one wavefront - with three wavefronts per SIMD a 4-wavefront block rarely finds its four slots at
     // once (560 of 768 blocks resident; 256 -> 128 -> 64 lanes: 1.58 -> 1.42 -> 1.39 ms).  SMR_BRAKE_BLOCK, read at smr_create
     int brake_block = 64;
@@ -2870,18 +2693,9 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         if (const char *v = getenv("SMR_JOB_BLOCK_LANES")) if (atoi(v) == 256 || atoi(v) == 512 || atoi(v) == 128) env->job_block_lanes = atoi(v);
         if (const char *v = getenv("SMR_JOB_QUOTA_MAX")) env->job_quota_max = std::max(4, std::min(64, atoi(v)));
-        if (const char *v = getenv("SMR_JOB_INWAVE")) env->coop_inwave = std::max(0, std::min(31, atoi(v)));
         if (const char *v = getenv("SMR_JOB_DEFER")) env->defer_after = std::max(0, std::min(31, atoi(v)));
         env->coop_blocks = std::max(prop.multiProcessorCount, 1);
         if (const char *v = getenv("SMR_COOP_BLOCKS")) if (atoi(v) > 0) env->coop_blocks = atoi(v);
-        if (const char *v = getenv("SMR_JOB_POOL")) env->job_pool = atoi(v) != 0;
-        if (const char *v = getenv("SMR_JOB_REFILL_IDLE")) if (atoi(v) >= 1 && atoi(v) <= 64) env->job_refill_idle = atoi(v);
-        if (env->job_pool) {          // tables + one pool per wavefront: more than the 64 KB a kernel gets without asking
-            const int lds = (int)(env->job_lds_bytes + 8 * 64 * kRunWords * 4);
-            if (hipFuncSetAttribute((const void *)jobs_pool_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-                hipFuncSetAttribute((const void *)jobs_pool_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) { env->err = "hipFuncSetAttribute failed"; return fail(SMR_E_HIP); }
-            if (!getenv("SMR_JOB_BLOCKS")) env->job_blocks = std::max(prop.multiProcessorCount, 1);      // the pools leave room for one block per CU
-        }
         env->self_job_blocks = std::max(8, std::min(env->job_blocks, (int)((B + 1023) / 1024)));      // ~40 jobs per wavefront
         if (const char *v = getenv("SMR_SELF_JOB_BLOCKS")) if (atoi(v) > 0) env->self_job_blocks = atoi(v);
         // the item part of the enumerate grid: one round for the usual 1.2 items per (env, body) - every round of a wavefront ends with a
@@ -3345,17 +3159,9 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         if (env->hscene.jobs_on) {
             if (env->hscene.planets_jobs) {
                 LaunchTimer tj(env, SMR_K_JOBS);
-                if (env->job_pool) {
-                    const size_t lds = env->job_lds_bytes + (size_t)(env->job_block_lanes >> 6) * 64 * kRunWords * 4;
-                    const int off = (int)(env->job_lds_bytes / 4);
-                    if (self) hipLaunchKernelGGL((jobs_pool_kernel<true>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
-                    else hipLaunchKernelGGL((jobs_pool_kernel<false>), jgrid, dim3(env->job_block_lanes), lds, env->stream, env->dscene, env->st, off, env->job_refill_idle);
-                } else if (env->coop_inwave > 0) {
-                    if (self) hipLaunchKernelGGL((jobs_kernel<true, true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->coop_inwave, env->job_quota_max);
-                    else hipLaunchKernelGGL((jobs_kernel<false, true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->coop_inwave, env->job_quota_max);
-                } else if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
+                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
                 else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
-                if (env->defer_after > 0 && !env->job_pool && env->coop_inwave <= 0) {
+                if (env->defer_after > 0) {
                     if (self) hipLaunchKernelGGL((jobs_coop_kernel<true>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
                     else hipLaunchKernelGGL((jobs_coop_kernel<false>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
                 }
