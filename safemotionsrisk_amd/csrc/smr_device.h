@@ -101,6 +101,7 @@ struct DScene {
     // pair-job path of the collide stage ("Pair jobs" below): on / off, and the LDS pool of its first / jobs kernels - like body_pool,
     // with the hull tables of the bodies that take part in moving / contact / static queries only
     int planets_jobs, job_pool_dwords;
+    int ball_jobs, ball_jobs_vn;          // ball scenes (round 4): the ball's GJK runs are jobs too; its padded vertex count in the job kernels' LDS
     const uint32_t *job_pool;
     // self-collision pairs ("Self pairs" below): jobs_on - the job lists exist (pair jobs and / or self-pair jobs); self_cut - the
     // distance range the reward and the termination read (rewards.py:119-126): a self distance at or above it is "none"; the bound
@@ -1438,7 +1439,9 @@ template <class HB>
 __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, const HB &hull, const Xf &T,
                                       const int idx[SMR_MAX_PLANETS], const Xf *XB, bool want_static, bool want_moving,
                                       bool want_contact, const float *q_self = nullptr, bool skip_planets = false, float moving_cut = -1.f,
-                                      bool *static_defer = nullptr) {
+                                      bool *static_defer = nullptr, int *ball_defer = nullptr) {
+    // ball_defer (ball scenes in the job form): the GJK run against the ball is not made - *ball_defer = 1 | mov << 1 | con << 2 when the
+    // bounds could not settle it (the job kernels make it), 0 otherwise
     // static_defer (scenes with auto_static): a GJK run against the static piece is not made here - the caller hands it to planet_gjk
     // moving_cut: moving distances above it are "no closest point" (default: the scene's moving_max; the contact sweep asks for less)
     const float moving_max = moving_cut >= 0.f ? moving_cut : S.moving_max;
@@ -1469,7 +1472,10 @@ __device__ inline Sample collide_link(const DScene &S, int l, const DPiece &LP, 
         const bool con = want_contact && con_link;
         float cutoff = mov ? moving_max : S.contact_dist;
         if (con) cutoff = fmaxf(cutoff, S.contact_dist);
-        float d = piece_distance<false>(S, S.ball_piece, *XB, LP, hull, T, cutoff, stop_moving);
+        bool pend = false;
+        float d = piece_distance<false>(S, S.ball_piece, *XB, LP, hull, T, cutoff, stop_moving, nullptr, ball_defer ? &pend : nullptr);
+        if (ball_defer) *ball_defer = pend ? (1 | ((int)mov << 1) | ((int)con << 2)) : 0;
+        if (pend) return out;
         if (mov && d <= moving_max && d < out.d_moving) out.d_moving = d;
         if (con && d <= S.contact_dist) out.contact = true;
         return out;
@@ -1790,7 +1796,8 @@ struct LaneInput {
 struct LaneResult { bool contact; float d_static, d_moving; int k_first, k_need; float lb_end; bool static_pending;
                     unsigned best; float ub;      // KEYS_ONLY: the best candidate (key << 5 | piece; ~0u: none) and an upper bound of ITS distance
                     Xf frame;                     // KEYS_ONLY: the body's frame at t = dt, handed on to the jobs of this (env, body)
-                    float lb1; };                 // KEYS_ONLY: lower bound of the best candidate's distance from the same support pair (0: none)
+                    float lb1;                    // KEYS_ONLY: lower bound of the best candidate's distance from the same support pair (0: none)
+                    int ball_pending; };          // ball jobs: the end-of-step run against the ball was not made (bit 0: asked for, 1: distance, 2: contact)
 
 // frame of body l at time t of the step's cubic
 template <bool SELF, bool FAST = false>
@@ -1827,7 +1834,7 @@ template <bool SELF, bool AUTO, bool KEYS_ONLY = false, class HB>
 __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &LP, const HB &hull, const LaneInput &in,
                                           const float *lds_pv, const float *lds_pd, uint32_t *keys, int kstride) {
     LaneResult out = {false, S.static_max, S.moving_max + 0.002f, 1, 0, -1.f, false, 0xFFFFFFFFu, 3.0e38f};
-    out.lb1 = 0.f;
+    out.lb1 = 0.f; out.ball_pending = 0;
     const int N = S.checks_per_step, upd = S.updates_per_step / N;
     const bool con_link = (S.contact_mask >> l) & 1u;
     bool want_contact, sweep_contact, moving_alive = true;
@@ -1860,7 +1867,8 @@ __device__ inline LaneResult collide_lane(const DScene &S, int l, const DPiece &
     if (!AUTO && S.use_ball) {           // (the lane-autonomous planet queries exist in planet scenes only)
         const Xf XB = ball_pose(S, in.ball, in.ball_k0 + N * upd, nullptr);
         const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
-        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near);
+        r = collide_link(S, l, LP, hull, T, nullptr, &XB, want_static, want_moving, want_contact && near, nullptr, false, -1.f, nullptr,
+                         S.ball_jobs ? &out.ball_pending : nullptr);
         if (moving_alive && sweep_contact) lb = ball_lower_bound(S, LP, T, XB);
     } else {
         int idx[SMR_MAX_PLANETS] = {0, 0};
@@ -2001,7 +2009,8 @@ __device__ inline bool collide_item(const DScene &S, int l, const DPiece &LP, co
 // The critical path of the step is one GJK run, not the longest lane's list of runs.
 // ---------------------------------------------------------------------------------------------
 // kJobSelf: self-collision pair `piece` of the env at the end of the step (the job word's piece field holds the pair index)
-enum { kJobPlanetEnd = 0, kJobItem = 1, kJobStaticEnd = 2, kJobSelf = 3 };
+// kJobBallEnd / kJobBallItem (ball scenes): the ball at the end of the step / at contact sample k; the piece field carries mov | con << 1
+enum { kJobPlanetEnd = 0, kJobItem = 1, kJobStaticEnd = 2, kJobSelf = 3, kJobBallEnd = 4, kJobBallItem = 5 };
 constexpr int kSmallScan = 24;        // padded vertices of a "short" scanned side (three rounds of eight)
 // job word: env 0..31 | body 32..35 | piece 36..41 | sample k 42..49 | kind 50..52.  k runs to checks_per_step (the end-of-step jobs carry
 // k = N), which check_scene bounds by kMaxChecksPerStep - the lane form's item queue packs (lane << 5 | k) and holds N - 1 items per lane.
@@ -2155,6 +2164,19 @@ __device__ inline void job_setup(const DScene &S, const BodyPool &BP, const floa
 #pragma unroll
         for (int j = 0; j < SMR_NJ; ++j) qs[j] = interp_pos(in.q[j * in.stride], in.v[j * in.stride], in.a[j * in.stride], in.a1[j * in.stride], t, S.dt);
         self_job_setup(S, BP, cyl, qs, jb.piece, cutoff, stop_below, J);
+        return;
+    }
+    if (jb.kind == kJobBallEnd || jb.kind == kJobBallItem) {
+        // the ball (ONE piece; its padded vertices lead the planets' slot of the tables) seen from the body frame at sample k
+        J.T = lane_frame_any<false>(S, jb.body, in, t);
+        const DPiece LPb = BP.piece(jb.body);
+        const DPiece BPc = load_piece_lane(S.pieces, S.ball_piece);
+        J.hull = BP.hull(jb.body); J.hull_body = jb.body;
+        J.av = pv; J.ac = S.ball_jobs_vn;
+        J.margins = BPc.margin + LPb.margin;
+        J.is_static = false;
+        J.XA = inv_compose(J.T, ball_pose(S, in.ball, in.ball_k0 + jb.k * upd, nullptr));
+        J.g.start(apply(J.XA, F3{BPc.cx, BPc.cy, BPc.cz}) - F3{LPb.cx, LPb.cy, LPb.cz}, cutoff + J.margins, stop_below + J.margins);
         return;
     }
     if (jb.kind == kJobItem) J.T = lane_frame_any<false>(S, jb.body, in, t);

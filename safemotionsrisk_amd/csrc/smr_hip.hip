@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
             st.env_min[e] = dist_bits(S.moving_max + 0.002f);
             st.env_dstatic[e] = dist_bits(S.static_max);
         }
+        if (S.ball_jobs) st.env_min[e] = dist_bits(S.moving_max + 0.002f);
         st.env_dself[e] = dist_bits(S.static_max);
         st.overflow_env[e] = 0;
         if (e == 0) { *st.item_count = 0; *st.job_count = 0; *st.job_count_big = 0; *st.job_next = 0; *st.defer_count = 0; }
@@ -152,13 +153,18 @@ struct PhaseClock {
 #ifndef SMR_COLLIDE_WAVES
 #define SMR_COLLIDE_WAVES 4      // 128 VGPRs (a 56-byte spill) for a fourth wavefront per SIMD: 0.96 -> 0.89 ms at 65536 envs
 #endif
+template <int NM>
+__device__ __forceinline__ void push_jobs(const DState &st, int env, const int (&bodies)[NM], const uint32_t (&masks)[NM], int k, int kind);      // (pair-job path, below)
 constexpr int kMaxItemsPerLane = kMaxChecksPerStep - 1;   // N - 1 intermediate samples (check_scene: N <= kMaxChecksPerStep)
 // SELF: the scene has self-collision pairs (ball machine); the plain robot runs the instantiation without that code
 // AUTO: lane-autonomous planet queries (planet_queries_auto); four wavefronts then share the LDS copies
+#ifndef SMR_COLLIDE_BLOCK
+#define SMR_COLLIDE_BLOCK 128    // ball scenes (no lane-autonomous planet queries): two wavefronts share the LDS copies (64 -> 128 lanes: ball 139.1 -> 141.7 M, 256: 131.2)
+#endif
 template <bool SELF, bool AUTO>
-__global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
+__global__ __launch_bounds__(AUTO ? 256 : SMR_COLLIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
-    constexpr int kBlock = AUTO ? 256 : 64;
+    constexpr int kBlock = AUTO ? 256 : SMR_COLLIDE_BLOCK;
     SMR_ROW_CLOCK((int)blockIdx.y);
     // grid y: the bodies, outer ones (most planet work, the longest blocks) leading.  (The self-collision pairs of a scene with mounted
     // bodies are not rows of this grid: self_bounds_kernel / jobs_kernel.)
@@ -226,6 +232,11 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
         if (N > 1) st.lb_moving[(size_t)l * B + e] = r.lb_end;
     }
     bool contact = r.contact;
+    if (!AUTO && S.ball_jobs) {                           // the run against the ball the bounds could not settle: a job (piece field: mov | con << 1)
+        const int bodies[1] = {l};
+        const uint32_t masks[1] = {(valid && r.ball_pending) ? 1u << (r.ball_pending >> 1) : 0u};
+        push_jobs(st, e, bodies, masks, N, kJobBallEnd);
+    }
 #ifdef SMR_PROFILE_ROWS
     const unsigned long long items_t0 = SMR_DEV_CLOCK();
 #endif
@@ -259,10 +270,16 @@ __global__ __launch_bounds__(AUTO ? 256 : 64) __attribute__((amdgpu_waves_per_eu
                 __builtin_amdgcn_wave_barrier();
             }
             SMR_WAVE_REC(5, total); SMR_WAVE_REC(6, pending);
-            // ... and get the real test, again 64 at a time
+            // ... and get the real test, again 64 at a time (ball jobs: as jobs of kind kJobBallItem, contact only)
             for (int base = 0; base < pending; base += 64) {
                 const bool live = base + lane < pending;
                 const int item = queue[live ? base + lane : 0], src = item >> 5;
+                if (!AUTO && S.ball_jobs) {
+                    const int bodies[1] = {l};
+                    const uint32_t masks[1] = {live ? 1u << 2 : 0u};
+                    push_jobs(st, __shfl(e, src), bodies, masks, item & 31, kJobBallItem);
+                    continue;
+                }
                 const LaneInput it = lane_input(__shfl(e, src));
                 if (collide_item<SELF, AUTO, false>(S, l, LP, hull, it, item & 31, live, lds_pv, lds_pd, lds_keys + threadIdx.x, kBlock) && live) lds_hit[wave0 + src] = 1u;
             }
@@ -285,6 +302,10 @@ __device__ __forceinline__ LaneInput load_lane_input(const DScene &S, const DSta
     in.planet_idx[0] = st.planet_idx[env]; in.planet_idx[1] = st.planet_idx[B + env];
     in.moving_hit = st.moving_hit[env];
     in.ball_k0 = 0; in.ball_kmax = 0; in.ball_khit = 0; in.ball_active = 0; in.lb_start = -1.f;
+    if (S.use_ball) {
+        in.ball = load_ball(st, B, env);
+        in.ball_k0 = st.ball_i[env]; in.ball_kmax = st.ball_i[B + env]; in.ball_khit = st.ball_i[2 * B + env]; in.ball_active = st.ball_i[3 * B + env];
+    }
     return in;
 }
 
@@ -394,11 +415,16 @@ struct JobTables { BodyPool BP; const float *pv, *pd, *cyl; };
 constexpr int kJobCylDwords = 8 * 4;             // up to four world-fixed cylinders named by self-collision pairs (8 floats each)
 __device__ __forceinline__ JobTables stage_job_tables(const DScene &S) {
     uint32_t *pool = job_lds;
-    const int vn = S.planets_jobs ? S.auto_vn : 0, pn = S.planets_jobs ? S.auto_pn : 0;      // (a scene without pair jobs stages no planets)
+    const int vn = S.planets_jobs ? S.auto_vn : (S.ball_jobs ? S.ball_jobs_vn : 0), pn = S.planets_jobs ? S.auto_pn : 0;      // (a scene without pair jobs stages no planets)
     float *pv = (float *)(job_lds + S.job_pool_dwords), *pd = pv + 4 * vn, *cyl = pd + kPlanetDescDwords * pn;
     const SMR_GLOBAL uint32_t *g = (const SMR_GLOBAL uint32_t *)S.job_pool;
     for (int i = threadIdx.x; i < S.job_pool_dwords; i += blockDim.x) pool[i] = g[i];
     if (S.planets_jobs) stage_planets(S, threadIdx.x, blockDim.x, pv, pd);
+    if (S.ball_jobs) {                                   // the ball's vertices, padded to a multiple of 8 with its last one (ball jobs scan them eight at a time)
+        const DPiece BPc = load_piece(S.pieces, S.ball_piece);
+        const SMR_GLOBAL float *gv = (const SMR_GLOBAL float *)S.verts + 4 * (size_t)BPc.begin;
+        for (int i = threadIdx.x; i < 4 * S.ball_jobs_vn; i += blockDim.x) pv[i] = gv[4 * min(i >> 2, BPc.count - 1) + (i & 3)];
+    }
     if ((int)threadIdx.x < S.n_self_pairs && S.self_cyl_slot[threadIdx.x] >= 0) {       // centre, core radius, core half length, margin
         const DPiece A = load_piece_lane(S.pieces, -(S.self_pair[threadIdx.x][1] + 1));
         float *c = cyl + 8 * S.self_cyl_slot[threadIdx.x];
@@ -435,7 +461,7 @@ __device__ __forceinline__ void job_result(const DScene &S, const DState &st, co
 __device__ __forceinline__ void job_limits(const DScene &S, const Job &jb, bool mov, bool con, float env_min, float &cutoff, float &stop) {
     if (jb.kind == kJobStaticEnd) { cutoff = S.static_max; stop = S.collision_dist; return; }
     if (jb.kind == kJobSelf) { cutoff = fminf(env_min, S.self_cut); stop = S.collision_dist; return; }      // env_min: the env's self distance so far
-    if (jb.kind == kJobItem) { cutoff = S.contact_dist; stop = S.contact_dist; return; }
+    if (jb.kind == kJobItem || jb.kind == kJobBallItem) { cutoff = S.contact_dist; stop = S.contact_dist; return; }
     cutoff = mov ? fminf(env_min, S.moving_max) : S.contact_dist;
     if (con) cutoff = fmaxf(cutoff, S.contact_dist);
     stop = con ? S.contact_dist : S.collision_dist;
@@ -653,6 +679,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
                 const LaneInput in = load_lane_input(S, st, jb.env);
                 job_flags(S, in, jb.body, mov, con);
                 if (jb.kind == kJobItem) { mov = false; con = true; }
+                if (jb.kind == kJobBallEnd || jb.kind == kJobBallItem) { mov = jb.piece & 1; con = (jb.piece >> 1) & 1; }      // decided by the collide kernel
                 float cutoff, stop;
                 // the env's minimum so far prunes the run.  A plain load: a value another XCD has lowered since is still an upper bound,
                 // and the jobs of one env sit side by side in the list - they start together whatever the load returns
@@ -875,6 +902,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
         d_moving = fminf(d_moving, __uint_as_float(st.env_min[e]));
         d_static = fminf(d_static, __uint_as_float(st.env_dstatic[e]));
     }
+    if (S.ball_jobs) d_moving = fminf(d_moving, __uint_as_float(st.env_min[e]));    // ball jobs
 
     float q[SMR_NJ], v[SMR_NJ], a[SMR_NJ], amax = 0.f, vrel = 0.f, arel = 0.f;
     // A14: the target point is reached when the target link point comes within its radius at one of the updates of the
@@ -2092,6 +2120,27 @@ __global__ __launch_bounds__(64) void overflow_kernel(const DScene *__restrict__
         }
         if (S.planets_jobs && want_contact) contact = contact || collide_sample(S, q, idx, false, true).contact;
     }
+    if (S.ball_jobs) {                                   // the ball, every body and sample in the lane form (collide_lane / collide_item's rules)
+        const LaneInput in = load_lane_input(S, st, e);
+        const int u_end = ball_retire_update(S, in.ball_k0, in.ball_kmax, in.ball_khit);
+        for (int k = N; k >= 1 && in.ball_active; --k) {
+            if (!(k * upd < u_end)) continue;               // retired before this sample
+            const Xf XB = ball_pose(S, in.ball, in.ball_k0 + k * upd, nullptr);
+            const bool near = XB.t.x * XB.t.x + XB.t.y * XB.t.y < S.ball_active_xy_radius * S.ball_active_xy_radius;
+            for (int l = 0; l < S.n_bodies; ++l) {
+                const bool mov = k == N && ((S.moving_mask >> l) & 1u), con = near && !contact && ((S.contact_mask >> l) & 1u);
+                if (!(mov || con)) continue;
+                const int pl = S.link_piece[l];
+                const DPiece LP = load_piece(S.pieces, pl);
+                const Xf T = lane_frame_any<false>(S, l, in, k == N ? S.dt : S.dt * (float)k / (float)N);
+                float cutoff = mov ? S.moving_max : S.contact_dist;
+                if (con) cutoff = fmaxf(cutoff, S.contact_dist);
+                const float d = piece_distance<false>(S, S.ball_piece, XB, LP, global_hull(S, pl, LP), T, cutoff, con ? S.contact_dist : S.collision_dist);
+                if (mov && d <= S.moving_max) atomicMin(&st.env_min[e], dist_bits(d));
+                if (con && d <= S.contact_dist) contact = true;
+            }
+        }
+    }
     if (contact) st.res[e] = 1.f;                       // finish ORs the bodies' flags: body 0's slot will do
 }
 
@@ -2479,19 +2528,30 @@ static int build_device_scene(smr_env *env, const smr_scene_t &s, uint64_t seed,
         // of the bodies the self-collision pairs name; behind it the planets' vertices and descriptors and the pairs' cylinders
         uint32_t self_mask = 0u;
         for (int i = 0; i < d.n_self_pairs; ++i) { self_mask |= 1u << d.self_pair[i][0]; if (d.self_pair[i][1] >= 0) self_mask |= 1u << d.self_pair[i][1]; }
+        // ball scenes (round 4): the GJK runs against the ball can be jobs as well - its padded vertex list takes the planets' place in the
+        // tables.  The default where the scene has self-collision pairs, whose jobs need a launch of the jobs kernel anyway (ball machine
+        // mounted, 65 536 envs: 72.3 -> 82.3 M env-steps/s); without them the launch costs what the collide kernel saves (its span is the
+        // longest run of the batch, 0.16 ms: 139 -> 127 M), so the runs stay in the collide kernel's lanes.  SMR_BALL_JOBS=0 / 1: A/B switch
+        d.ball_jobs = 0; d.ball_jobs_vn = 0;
+        if (s.use_ball && !d.planets_auto && s.ball_piece >= 0 && s.ball_piece < s.n_pieces) {
+            d.ball_jobs = d.n_self_pairs > 0;
+            if (const char *v = getenv("SMR_BALL_JOBS")) d.ball_jobs = atoi(v) != 0;
+            if (const char *lanes = getenv("SMR_COLLIDE_LANES")) if (atoi(lanes)) d.ball_jobs = 0;
+            d.ball_jobs_vn = (G.pieces[s.ball_piece].count + 7) & ~7;
+        }
         auto lds_bytes = [&](uint32_t mask, bool planets, std::vector<uint32_t> &pool) {
             body_pool_tables(s, G, pool, mask);
-            return 4 * (pool.size() + (planets ? 4 * (size_t)d.auto_vn + kPlanetDescDwords * (size_t)d.auto_pn : 0) + kJobCylDwords);
+            return 4 * (pool.size() + (planets ? 4 * (size_t)d.auto_vn + kPlanetDescDwords * (size_t)d.auto_pn : 0) + (d.ball_jobs ? 4 * (size_t)d.ball_jobs_vn : 0) + kJobCylDwords);
         };
         std::vector<uint32_t> job_pool;
         const uint32_t pair_mask = d.static_mask | d.moving_mask | d.contact_mask;
-        size_t bytes = lds_bytes((d.planets_jobs ? pair_mask : 0u) | self_mask, d.planets_jobs != 0, job_pool);
-        if (d.planets_jobs && bytes > 64 * 1024) {             // does not fit two blocks per CU: the planets stay with the lane form
-            d.planets_jobs = 0;
+        size_t bytes = lds_bytes(((d.planets_jobs || d.ball_jobs) ? pair_mask : 0u) | self_mask, d.planets_jobs != 0, job_pool);
+        if ((d.planets_jobs || d.ball_jobs) && bytes > 64 * 1024) {             // does not fit two blocks per CU: the planets / the ball stay with the lane form
+            d.planets_jobs = 0; d.ball_jobs = 0;
             bytes = lds_bytes(self_mask, false, job_pool);
         }
         if (d.n_self_pairs > 0 && bytes > 64 * 1024) { env->err = "the hull tables of the self-collision pairs' bodies exceed the LDS pool of the job kernels"; return SMR_E_INVALID; }
-        d.jobs_on = (d.planets_jobs || d.n_self_pairs > 0) ? 1 : 0;
+        d.jobs_on = (d.planets_jobs || d.ball_jobs || d.n_self_pairs > 0) ? 1 : 0;
         if (d.jobs_on) {
             uint32_t *dpool;
             if ((rc = dev_upload(env, &dpool, job_pool))) return rc;
@@ -2675,7 +2735,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         if (pj && !one_list)
             for (int c = 0; c < env->hscene.planet_pn && c < 32 && c < (int)env->host_planet_padded.size(); ++c)
                 if (env->host_planet_padded[c] > kSmallScan) st.big_piece_mask |= 1u << c;
-        if ((rc = dev_alloc(env, &st.keyw, pj ? 7 * NB * B : 1)) || (rc = dev_alloc(env, &st.env_best, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_min, pj ? B : 1)) ||
+        if ((rc = dev_alloc(env, &st.keyw, pj ? 7 * NB * B : 1)) || (rc = dev_alloc(env, &st.env_best, pj ? B : 1)) || (rc = dev_alloc(env, &st.env_min, (pj || env->hscene.ball_jobs) ? B : 1)) ||
             (rc = dev_alloc(env, &st.env_dstatic, pj ? B : 1)) || (rc = dev_alloc(env, &st.frames, pj ? 12 * NB * B : 4)) || (rc = dev_alloc(env, &st.lb1, pj ? NB * B : 1)) || (rc = dev_alloc(env, &st.env_dself, B)) || (rc = dev_alloc(env, &st.items, (pj && N > 1) ? B * NB * (N - 1) : 1)) ||
             (rc = dev_alloc(env, &st.jobs, std::max<size_t>(cap, 1))) || (rc = dev_alloc(env, &st.item_count, 1)) || (rc = dev_alloc(env, &st.job_count, 1)) || (rc = dev_alloc(env, &st.job_count_big, 1)) || (rc = dev_alloc(env, &st.job_next, 1)) ||
             (rc = dev_alloc(env, &st.overflow_env, B)) || (rc = dev_alloc(env, &st.defer_count, 1))) return fail(rc);
@@ -2690,6 +2750,9 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
         // 0.140 -> 0.128, 16 384 0.171 -> 0.153, 32 768 0.206 -> 0.191; 65 536: 0.217 -> 0.224 ms in the space scene, 0.173 -> 0.162 in the
         // reaching task; 256-lane blocks - one wavefront per SIMD - at 4096 envs: 0.119 -> 0.142 ms)
         env->job_blocks = std::max(prop.multiProcessorCount, 1) * (B <= 32768 ? 2 : 1);
+        // ball jobs (1.3 per env, runs of up to 31 iterations): one block per two CUs - denser wavefronts, fewer of them beside the refill
+        // kernels (65 536 envs, ball machine mounted: jobs 0.270 -> 0.230 ms; 96 / 192 blocks: 0.242 / 0.262)
+        if (env->hscene.ball_jobs && B > 32768) env->job_blocks = std::max(prop.multiProcessorCount / 2, 1);
         if (const char *v = getenv("SMR_JOB_BLOCKS")) if (atoi(v) > 0) env->job_blocks = atoi(v);
         if (const char *v = getenv("SMR_JOB_BLOCK_LANES")) if (atoi(v) == 256 || atoi(v) == 512 || atoi(v) == 128) env->job_block_lanes = atoi(v);
         if (const char *v = getenv("SMR_JOB_QUOTA_MAX")) env->job_quota_max = std::max(4, std::min(64, atoi(v)));
@@ -3127,12 +3190,13 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
         const bool self = scene_extra(env), autop = env->hscene.planets_auto != 0, pairs = env->hscene.n_self_pairs > 0;
-        const int block = autop ? 256 : 64;
+        const int block = autop ? 256 : SMR_COLLIDE_BLOCK;
         const dim3 grid((B + block - 1) / block, env->hscene.n_bodies);
         const dim3 jgrid(env->job_blocks);
         // the self-collision pairs: bounds per env, the survivors as jobs (worked by the jobs kernel behind the pair jobs of a planet
         // scene, by a launch of its own otherwise)
-        const bool self_jobs_alone = pairs && !env->hscene.planets_jobs;      // no pair jobs to work them behind
+        const bool ball_jobs = env->hscene.ball_jobs != 0;
+        const bool self_jobs_alone = pairs && !env->hscene.planets_jobs && !ball_jobs;      // no pair / ball jobs to work them behind
         // (on a stream of their own beside the other distance kernels they finished sooner, but took from the staged refills what they
         // gained: reaching task 94 -> 86 M env-steps/s; ball scene beside the collide kernel: 63.6 -> 51.8 M; both measured)
         if (pairs) {
@@ -3157,6 +3221,15 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
         if (env->hscene.jobs_on) {
+            if (ball_jobs) {                                  // the self pairs' and the ball's runs: one launch behind the collide kernel
+                LaunchTimer tj(env, SMR_K_JOBS);
+                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
+                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
+                if (env->defer_after > 0) {
+                    if (self) hipLaunchKernelGGL((jobs_coop_kernel<true>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                    else hipLaunchKernelGGL((jobs_coop_kernel<false>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
+                }
+            }
             if (env->hscene.planets_jobs) {
                 LaunchTimer tj(env, SMR_K_JOBS);
                 if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);

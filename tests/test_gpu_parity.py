@@ -277,12 +277,12 @@ def test_profiling_counters(built):
 
 
 # ------------------------------------------------------------------ ball scene (A10, BASELINE configs[3])
-def _ball_env(B, **kw):
+def _ball_env(B, ball_machine=False, **kw):
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     from safemotionsrisk_amd import VecSafeMotionsEnv, BALL_ENV_CONFIG
     kw.setdefault("auto_reset", False)
-    return VecSafeMotionsEnv(B, device=0, **kw, **BALL_ENV_CONFIG)
+    return VecSafeMotionsEnv(B, device=0, **kw, **dict(BALL_ENV_CONFIG, ball_machine_mode=ball_machine))
 
 
 BALL_OBS_TOL = np.concatenate([np.full(7, 2e-6), np.full(7, 1e-5), np.full(7, 2e-5), np.full(6, 5e-6)])
@@ -341,11 +341,20 @@ def test_ball_step_against_golden(built):
     env.close()
 
 
-def test_ball_rollout_and_reset_against_oracle(built):
+@pytest.mark.parametrize("ball_machine,switches", [(False, {}), (False, {"SMR_BALL_JOBS": "1"}), (True, {}), (True, {"SMR_BALL_JOBS": "0"}),
+                                                   (True, {"SMR_JOB_CAP": "200"})])
+def test_ball_rollout_and_reset_against_oracle(built, monkeypatch, ball_machine, switches):
+    """Both forms of the runs against the ball - in the lanes of the collide kernel (the default without self-collision pairs) and as jobs
+    of the jobs kernel (the default with the ball machine mounted, where the self pairs' jobs run anyway), SMR_BALL_JOBS forcing the
+    other one - and a job list that is far too short (overflow_kernel's ball branch): every one against the float64 oracle."""
     import torch
     from oracle.oracle import OracleEnv
     B, T = 4096, 16
-    env = _ball_env(B, seed=5)
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    env = _ball_env(B, ball_machine, seed=5)
+    for k in switches:
+        monkeypatch.delenv(k)
     obs0 = env.reset().cpu().numpy()
     ora = OracleEnv(env.scene, B, seed=5, num_threads=16)
     ora1 = OracleEnv(env.scene, 1)
