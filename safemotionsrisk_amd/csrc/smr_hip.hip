@@ -24,6 +24,7 @@
 // number of additions; slots 0..31: wavefront cycles per grid row of the collide kernel, 32..63: phases and counts (the first
 // active lane of a wavefront adds) - and a record per wavefront of the collide kernel (g_wave_rec)
 __device__ unsigned long long g_row_cycles[128];
+__device__ unsigned long long g_job_hist[8 * 8];      // scripts/study/job_hist.py: [slack between cutoff and key bound][iterations 1, 2, 3-4, 5-8, 9+ | long scans | jobs]; scripts/study/brake_hist.py: [2 row] passes, lanes; 50.. walk counts
 __device__ unsigned g_wave_rec[8 * 65536];
 #define SMR_DEV_CLOCK() __builtin_readcyclecounter()
 #define SMR_DEV_COUNT(i, n) do { if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) { atomicAdd(&g_row_cycles[32 + (i)], (unsigned long long)(n)); atomicAdd(&g_row_cycles[96 + (i)], 1ull); } } while (0)
@@ -79,6 +80,11 @@ struct RowClock {
         if (__lane_id() == 0 && row < 64) { atomicAdd(&g_row_cycles[row], __builtin_readcyclecounter() - t0); atomicAdd(&g_row_cycles[64 + row], 1ull); }
     }
 };
+extern "C" int smr_debug_job_hist(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_job_hist), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_job_hist), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 extern "C" int smr_debug_row_cycles(unsigned long long *out, int reset) {
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_row_cycles), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
     if (reset) { unsigned long long z[128] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_row_cycles), z, sizeof(z)) != hipSuccess) return -1; }
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #ifdef SMR_PROFILE_ROWS
     const unsigned long long pc0 = SMR_DEV_CLOCK();
     unsigned long long pc_setup = 0, pc_trip = 0, pc_atomic = 0, pc_loads = 0, pc_sa = 0, pc_sb = 0, pc_rest = 0;
-    int prof_trips = 0, prof_refills = 0, prof_maxit = 0, prof_lanes = 0, prof_hist[5] = {0, 0, 0, 0, 0}, prof_n[3] = {0, 0, 0};
+    int prof_trips = 0, prof_refills = 0, prof_maxit = 0, prof_lanes = 0, prof_hist[5] = {0, 0, 0, 0, 0}, prof_n[3] = {0, 0, 0}, prof_bucket = -1;
     const unsigned prof_wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);       // scripts/profile_jobs.py: the schedule of the wavefronts
     const unsigned long long prof_w0 = wall_clock64();
     unsigned long long prof_w1 = 0;
@@ -693,6 +699,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #endif
                 job_setup<SELF>(S, JT.BP, JT.pv, JT.pd, JT.cyl, in, st.frames, jb, cutoff, stop, J);
                 active = true;
+#ifdef SMR_PROFILE_ROWS
+                prof_bucket = -1;
+                if (jb.kind == kJobPlanetEnd || jb.kind == kJobItem) {
+                    float ratio = 1.f;
+                    if (jb.kind == kJobPlanetEnd) {
+                        const uint32_t kw = st.keyw[((size_t)(jb.piece >> 2) * S.n_bodies + jb.body) * S.B + jb.env];
+                        ratio = (float)((kw >> (8 * (jb.piece & 3))) & 0xFFu) * kKeyStep / fmaxf(cutoff, 1e-6f);
+                    }
+                    {   // slack between the cutoff and the key bound, in key steps: < 1, < 2, < 4, < 8, < 16, < 32, more; row 7: the items
+                        const float slack = (1.f - ratio) * fmaxf(cutoff, 1e-6f) / kKeyStep;
+                        const int row = jb.kind == kJobItem ? 7 : (slack < 1.f ? 0 : slack < 2.f ? 1 : slack < 4.f ? 2 : slack < 8.f ? 3 : slack < 16.f ? 4 : slack < 32.f ? 5 : 6);
+                        prof_bucket = 8 * row;
+                    }
+                    if (J.ac > kSmallScan) atomicAdd(&g_job_hist[prof_bucket + 5], 1ull);
+                    atomicAdd(&g_job_hist[prof_bucket + 6], 1ull);
+                }
+#endif
             }
 #ifdef SMR_PROFILE_ROWS
             pc_setup += SMR_DEV_CLOCK() - t0;
@@ -719,6 +742,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
 #ifdef SMR_PROFILE_ROWS
             prof_maxit = max(prof_maxit, J.g.it + 1);
             prof_its = J.g.it + 1;
+            if (prof_bucket >= 0) atomicAdd(&g_job_hist[prof_bucket + (prof_its == 1 ? 0 : prof_its == 2 ? 1 : prof_its <= 4 ? 2 : prof_its <= 8 ? 3 : 4)], 1ull);
 #endif
         }
         // a run that has used up its iterations in the lane form leaves as a record for jobs_coop_kernel (smr_device.h, "deferred runs"):
@@ -1366,6 +1390,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
     const int steps_planned = st.brake_steps[e];
     if (steps_planned < 0 && !BT) return;
     const int steps = steps_planned < 0 ? S.brake_timeout_steps : steps_planned;
+#ifdef SMR_PROFILE_ROWS
+    { const unsigned long long am = __ballot(true); if ((int)__lane_id() == __ffsll((long long)am) - 1) { atomicAdd(&g_job_hist[51], 1ull); atomicAdd(&g_job_hist[52], (unsigned long long)__popcll(am)); } atomicAdd(&g_job_hist[53], (unsigned long long)(steps + 1)); }
+#endif
     // the segment's cubic per joint in Horner form, q(t) = p + t (v + t (ha + t j6)) with ha = a0 / 2, j6 = (a1 - a0) / (6 dt): three
     // multiply-adds per joint and sample (fewer instructions and 8 fewer spilled registers than the monomial form; the kernel's time did not move)
     const float inv_dt6 = 1.0f / (6.0f * S.dt);
@@ -1399,7 +1426,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_BRAKE_W
             // With no evaluation at all (measurement build, SMR_BRAKE_WALK_ONLY) the braking kernels take 0.67 of their 1.56 ms: two fifths
             // of the time is this walk, repeated in each of the 24 rows.  Walking only the joints that move what the row tests (the
             // others interpolated when a sample is evaluated) was measured too: 1.57 -> 1.77 ms, 116 -> 132 spilled registers.)
+#ifdef SMR_PROFILE_ROWS      // (scripts/study/brake_hist.py) wave-level sample steps | evaluation passes and evaluating lanes per row
+            { const unsigned long long am = __ballot(true); if ((int)__lane_id() == __ffsll((long long)am) - 1) atomicAdd(&g_job_hist[50], 1ull); }
+#endif
             if (moved * 1.0001f + 1e-6f < margin) continue;
+#ifdef SMR_PROFILE_ROWS
+            { const unsigned long long am = __ballot(true); if ((int)__lane_id() == __ffsll((long long)am) - 1 && row < 24) { atomicAdd(&g_job_hist[2 * row], 1ull); atomicAdd(&g_job_hist[2 * row + 1], (unsigned long long)__popcll(am)); } }
+#endif
             float d = -kNoBound;
             // a pair with a bound table (partner iiwa_link_4 / _5: the rows with the smallest clearances, evaluated at nearly every
             // sample): two bytes indexed by the last joints' angles BEFORE any frame - an evaluation is a chain of seven dependent
