@@ -180,6 +180,12 @@ struct DState {
     int *moving_hit;           // [B]
     unsigned *reset_count;     // [B]  number of resets of the env = Philox tag of its next reset
     float *a1;                 // [7][B]   plan -> collide/finish
+    // the safe acceleration range of the NEXT step (round 4): a function of the state the step ends in, not of the next action - range_kernel
+    // computes it beside the distance kernels as soon as the step is planned, the staged start states bring theirs along, and the next
+    // step's plan kernel only maps the action into it.  range_valid[e] == 0: plan computes it itself (injected state, unstaged reset)
+    float *range_lo, *range_hi;   // [7][B]
+    int *range_valid;             // [B]
+    float *next_lo, *next_hi;     // [2][7][B] the ranges of the staged start states
     float *res;                // [n_bodies][B] collide -> finish: contact of body l at any of the N contact samples of the step
     float *dist;               // [2][8][B] collide -> finish: d_static, d_moving of link l at the end-of-step sample
     int *braked;               // [B] 1: the braking acceleration replaced this step's action (adapt_action, ctlp.py:3055-3153)

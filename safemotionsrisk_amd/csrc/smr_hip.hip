@@ -43,16 +43,23 @@ namespace smr {
 // kernels
 // ---------------------------------------------------------------------------------------------
 // one lane per (env, joint); the lanes of a wavefront share the root finding of its open position-limit brackets
-__global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions) {
+// use_ranges: the ranges range_kernel / the staged start states left behind are taken where they are valid (DState::range_valid)
+__global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions, int use_ranges) {
     const DScene &S = *Sp;
     const int B = S.B;
     const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = e0 < B;                          // the wavefront searches its open brackets together: no lane leaves early
     const int e = live ? e0 : B - 1;
     const int j = blockIdx.y;
-    float lo, hi;
-    int code;
-    safe_acc_range_joint<64>(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo, hi, code, live);
+    float lo = 0.f, hi = 0.f;
+    const bool have = use_ranges && st.range_valid[e] != 0;
+    if (have) { lo = st.range_lo[j * B + e]; hi = st.range_hi[j * B + e]; }
+    if (__any(live && !have)) {
+        float lo2, hi2;
+        int code;
+        safe_acc_range_joint<64>(joint_lim(S, j), st.q[j * B + e], st.v[j * B + e], st.a[j * B + e], lo2, hi2, code, live && !have);
+        if (!have) { lo = lo2; hi = hi2; }
+    }
     if (!live) return;
     if (j == 0 && S.check_braking) { st.braked[e] = 0; st.bt_min[e] = 0x7F800000u; }   // set by brake_plan_kernel / brake_check_kernel
     if (j == 0 && S.jobs_on) {                         // the accumulators and lists of this step's jobs (self_bounds / keys / enumerate / jobs kernels)
@@ -68,6 +75,57 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
     }
     float u = actions[(size_t)e * SMR_NJ + j];
     st.a1[j * B + e] = lo + 0.5f * (u + 1.0f) * (hi - lo);      // actions.py:496-498 (klimits.denormalize)
+}
+
+// The next step's safe acceleration ranges, from the state the planned step ends in (finish_kernel's arithmetic: base.py:1179-1181): the grid
+// of the plan kernel, on a stream of its own beside the distance kernels.  An env that ends its episode in this step gets the range of
+// its staged start state instead (finish_kernel / commit_staged), or none (range_valid = 0).
+// (one wavefront: joint j of the 64 envs from e0 on; its lanes share the root finding)
+__device__ __forceinline__ void range_wave(const DScene &S, const DState &st, int j, int e0) {
+    const int B = S.B;
+    const bool live = e0 < B;
+    const int e = live ? e0 : B - 1;
+    const float q0 = st.q[j * B + e], v0 = st.v[j * B + e], a0 = st.a[j * B + e], a1 = st.a1[j * B + e];
+    float lo, hi;
+    int code;
+    safe_acc_range_joint<64>(joint_lim(S, j), interp_pos(q0, v0, a0, a1, S.dt, S.dt), interp_vel(v0, a0, a1, S.dt, S.dt), a1, lo, hi, code, live);
+    if (!live) return;
+    st.range_lo[j * B + e] = lo; st.range_hi[j * B + e] = hi;
+    if (j == 0) st.range_valid[e] = 1;
+}
+__global__ __launch_bounds__(256) void range_kernel(const DScene *__restrict__ Sp, DState st) {
+    range_wave(*Sp, st, (int)blockIdx.y, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+// ... as the last `range_blocks` blocks of a jobs kernel launch (that kernel is a chain of latencies on a tenth of the issue slots: the
+// ranges ride along, without the two stream dependencies a kernel of their own costs): wavefront w = joint w / waves_per_joint
+// ... and of the staged start states reset_kernel<true> just wrote (same list, same tags; on its stream, behind it - inside that kernel the
+// call cost its 256-register instantiations a quarter to two thirds of their speed in spills): 8 lanes per entry, lane g < 7 = joint g
+// direct: the unstaged reset path - the live state's range (reset_kernel<false> wrote q, v, a), so that every start state gets its first range the same way
+__global__ __launch_bounds__(256) void staged_range_kernel(const DScene *__restrict__ Sp, DState st, const int *__restrict__ list, const int *__restrict__ count_ptr,
+                                                           int count_fixed, const unsigned *__restrict__ tags, int tag_offset, int direct) {
+    const DScene &S = *Sp;
+    const int count = count_ptr ? *count_ptr : count_fixed;
+    if ((int)((blockIdx.x * blockDim.x) >> 3) >= count) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, i = t >> 3, g = t & 7, B = S.B;
+    const bool want = i < count && g < SMR_NJ;
+    const int ii = i < count ? i : count - 1;
+    const int e = list ? list[ii] : ii;
+    const unsigned tag = direct ? 0u : (tags ? tags[ii] : st.reset_count[e] + (unsigned)tag_offset);
+    const int j = g < SMR_NJ ? g : 0;
+    const size_t k = direct ? (size_t)j * B + e : ((size_t)(tag & 1u) * SMR_NJ + j) * B + e;
+    const float *sq = direct ? st.q : st.next_q, *sv = direct ? st.v : st.next_v, *sa = direct ? st.a : st.next_a;
+    float lo, hi;
+    int code;
+    safe_acc_range_joint<8>(joint_lim(S, j), sq[k], sv[k], sa[k], lo, hi, code, want);      // (the env's own 8 lanes: the result does not depend on its neighbours in the list)
+    if (want) { (direct ? st.range_lo : st.next_lo)[k] = lo; (direct ? st.range_hi : st.next_hi)[k] = hi; }
+    if (direct && i < count && g == SMR_NJ) st.range_valid[e] = 1;
+}
+__device__ __forceinline__ void range_block(const DScene &S, const DState &st, int rb) {
+    const int waves_per_joint = (S.B + 63) >> 6;
+    const int w = rb * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    const int j = __builtin_amdgcn_readfirstlane(w / waves_per_joint);
+    if (j >= SMR_NJ) return;
+    range_wave(S, st, j, (w - j * waves_per_joint) * 64 + (int)__lane_id());
 }
 
 #ifdef SMR_PROFILE_ROWS
@@ -172,6 +230,8 @@ __global__ __launch_bounds__(AUTO ? 256 : SMR_COLLIDE_BLOCK) __attribute__((amdg
     const DScene &S = *Sp;
     constexpr int kBlock = AUTO ? 256 : SMR_COLLIDE_BLOCK;
     SMR_ROW_CLOCK((int)blockIdx.y);
+    // rows behind the bodies (a ball scene without a jobs launch): the next step's safe acceleration ranges, row n_bodies + j = joint j (range_wave)
+    if ((int)blockIdx.y >= S.n_bodies) { range_wave(S, st, (int)blockIdx.y - S.n_bodies, (int)(blockIdx.x * blockDim.x + threadIdx.x)); return; }
     // grid y: the bodies, outer ones (most planet work, the longest blocks) leading.  (The self-collision pairs of a scene with mounted
     // bodies are not rows of this grid: self_bounds_kernel / jobs_kernel.)
     const int l = S.body_order[(int)blockIdx.y];
@@ -618,8 +678,9 @@ __global__ __launch_bounds__(256) void enumerate_kernel(const DScene *__restrict
 // asking for the next chunk when 16 / 32 / 48 lanes have settled so that the counter's round trip runs beside the last trips
 // (slower the earlier it asks: the chunk then waits for the wavefront's longest run while other wavefronts are idle).
 template <bool SELF>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st, int defer_after, int quota_max) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAVES, SMR_JOB_WAVES))) void jobs_kernel(const DScene *__restrict__ Sp, DState st, int defer_after, int quota_max, int range_blocks) {
     const DScene &S = *Sp;
+    if ((int)blockIdx.x >= (int)gridDim.x - range_blocks) { range_block(S, st, (int)blockIdx.x - ((int)gridDim.x - range_blocks)); return; }
 #ifdef SMR_PROFILE_ROWS
     const unsigned long long pc0 = SMR_DEV_CLOCK();
     unsigned long long pc_setup = 0, pc_trip = 0, pc_atomic = 0, pc_loads = 0, pc_sa = 0, pc_sb = 0, pc_rest = 0;
@@ -636,7 +697,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SMR_JOB_WAV
     // With fewer jobs than lanes (small batches) the wavefronts share them out thinly: every SIMD gets a few runs instead of a few
     // CUs getting them all, and a wavefront's chain is the longest of four runs, not of sixty-four (a floor of 8 -> 4 with two blocks per
     // CU: 4096 envs 0.117 -> 0.106 ms; 2: 0.109 ms).
-    const int n_waves = (int)gridDim.x * (int)(blockDim.x >> 6);
+    const int n_waves = ((int)gridDim.x - range_blocks) * (int)(blockDim.x >> 6);
 #ifndef SMR_JOB_QUOTA_MIN
 #define SMR_JOB_QUOTA_MIN 4
 #endif
@@ -857,9 +918,11 @@ __device__ inline void commit_staged(const DScene &S, const DState &st, int e, f
     for (int j = 0; j < SMR_NJ; ++j) {
         q[j] = st.next_q[(sl * SMR_NJ + j) * B + e]; v[j] = st.next_v[(sl * SMR_NJ + j) * B + e]; a[j] = st.next_a[(sl * SMR_NJ + j) * B + e];
         st.q[j * B + e] = q[j]; st.v[j * B + e] = v[j]; st.a[j * B + e] = a[j];
+        st.range_lo[j * B + e] = st.next_lo[(sl * SMR_NJ + j) * B + e]; st.range_hi[j * B + e] = st.next_hi[(sl * SMR_NJ + j) * B + e];
     }
     int idx[SMR_MAX_PLANETS] = {st.next_planet_idx[(sl * 2) * B + e], st.next_planet_idx[(sl * 2 + 1) * B + e]};
     st.planet_idx[e] = idx[0]; st.planet_idx[B + e] = idx[1];
+    st.range_valid[e] = 1;
     st.step_count[e] = 0;
     st.moving_hit[e] = st.next_hit[sl * B + e];
     st.start_attempts[e] = st.next_attempts[sl * B + e];
@@ -900,7 +963,7 @@ __device__ inline void install_target(const DScene &S, const DState &st, int e, 
 
 __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ Sp, DState st, const float *__restrict__ actions,
                                                      float *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ done,
-                                                     int8_t *__restrict__ reason, float *__restrict__ info, int staged) {
+                                                     int8_t *__restrict__ reason, float *__restrict__ info, int staged, int ranges_ahead) {
     const DScene &S = *Sp;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e == 0 && st.refill_zero) *st.refill_zero = 0;                        // the list counters of the NEXT step
@@ -1096,6 +1159,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const DScene *__restrict__ 
     if (!d && finished) { d = true; rs = SMR_TERMINATION_TRAJECTORY_LENGTH; }
     done[e] = d ? 1 : 0;
     reason[e] = (int8_t)rs;
+    // range_kernel saw the episode go on; a staged start state brings its own range below.  (The store stays up here: placed behind the
+    // ball branch's stores, in front of the episode counter's atomic, the kernel faulted on address 0 in ball scenes - ROCm 7.2 build, the
+    // same store here or at the top of the kernel is fine; not understood, scripts/study/repro_ball.py reproduces it.)
+    if (d || !ranges_ahead) st.range_valid[e] = 0;
     if (info) {
         float *row = info + (size_t)e * SMR_INFO_N;
         row[SMR_INFO_D_STATIC] = d_static; row[SMR_INFO_D_SELF] = d_self; row[SMR_INFO_D_MOVING] = d_moving;
@@ -1986,6 +2053,7 @@ __global__ SMR_SIDE_KERNEL void reset_kernel(const DScene *__restrict__ Sp, DSta
     } else {
         st.planet_idx[e] = idx[0];
         st.planet_idx[B + e] = idx[1];
+        st.range_valid[e] = 0;                             // (the first plan kernel computes the range of an unstaged start state itself)
         st.step_count[e] = 0;
         st.moving_hit[e] = hit;
         st.start_attempts[e] = first_attempts;
@@ -2267,7 +2335,9 @@ __global__ void rollout_snapshot_kernel(const DScene *__restrict__ Sp, DState sr
     const int e = blockIdx.x * blockDim.x + threadIdx.x, B = S.B;
     if (e >= B) return;
 #pragma unroll
-    for (int j = 0; j < SMR_NJ; ++j) { dst.q[j * B + e] = src.q[j * B + e]; dst.v[j * B + e] = src.v[j * B + e]; dst.a[j * B + e] = src.a[j * B + e]; }
+    for (int j = 0; j < SMR_NJ; ++j) { dst.q[j * B + e] = src.q[j * B + e]; dst.v[j * B + e] = src.v[j * B + e]; dst.a[j * B + e] = src.a[j * B + e];
+                                       dst.range_lo[j * B + e] = src.range_lo[j * B + e]; dst.range_hi[j * B + e] = src.range_hi[j * B + e]; }
+    dst.range_valid[e] = src.range_valid[e];
     dst.planet_idx[e] = src.planet_idx[e]; dst.planet_idx[B + e] = src.planet_idx[B + e];
     dst.step_count[e] = 0;
     dst.moving_hit[e] = src.moving_hit[e];
@@ -2357,6 +2427,11 @@ struct smr_env {
     int *tp_refill_lists = nullptr;   // [3][B]
     unsigned *tp_refill_tag_lists = nullptr, *spawn_tag_lists = nullptr;   // [3][B] each
     hipEvent_t ev_commit = nullptr, ev_refill = nullptr;
+    // the next step's safe acceleration ranges are computed beside the distance kernels (range_kernel; SMR_RANGE_AHEAD=0: by the plan kernel, as before)
+    int range_mode = 1;                               // SMR_RANGE_AHEAD=0: the plan kernel computes the ranges itself, as it did until round 4 (A/B switch)
+    bool range_host = true;                           // as extra blocks of the jobs kernel where the step has one (SMR_RANGE_HOST=0: always the stream)
+    hipStream_t range_stream = nullptr;
+    hipEvent_t ev_planned = nullptr, ev_ranges = nullptr;
     DScene hscene;              // host copy (device pointers inside)
     int *refill_slots = nullptr; // two list counters: step s uses slot s & 1, its finish kernel clears the other
     int *tp_refill_slots = nullptr;   // the same for the staged target points (null: not staged)
@@ -2699,6 +2774,9 @@ int smr_destroy(smr_env_t *env) {
     if (!env) return SMR_OK;
     (void)hipSetDevice(env->device);
     (void)hipStreamSynchronize(env->stream);
+    if (env->range_stream) { (void)hipStreamSynchronize(env->range_stream); (void)hipStreamDestroy(env->range_stream); }
+    if (env->ev_planned) (void)hipEventDestroy(env->ev_planned);
+    if (env->ev_ranges) (void)hipEventDestroy(env->ev_ranges);
     if (env->side) { (void)hipStreamSynchronize(env->side); (void)hipStreamDestroy(env->side); }
     if (env->side2) { (void)hipStreamSynchronize(env->side2); (void)hipStreamDestroy(env->side2); }
     if (env->side_b) { (void)hipStreamSynchronize(env->side_b); (void)hipStreamDestroy(env->side_b); }
@@ -2738,6 +2816,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     if ((rc = dev_alloc(env, &st.q, 7 * B)) || (rc = dev_alloc(env, &st.v, 7 * B)) || (rc = dev_alloc(env, &st.a, 7 * B)) ||
         (rc = dev_alloc(env, &st.planet_idx, 2 * B)) || (rc = dev_alloc(env, &st.step_count, B)) ||
         (rc = dev_alloc(env, &st.moving_hit, B)) || (rc = dev_alloc(env, &st.reset_count, B)) || (rc = dev_alloc(env, &st.start_attempts, B)) || (rc = dev_alloc(env, &st.a1, 7 * B)) ||
+        (rc = dev_alloc(env, &st.range_lo, 7 * B)) || (rc = dev_alloc(env, &st.range_hi, 7 * B)) || (rc = dev_alloc(env, &st.range_valid, B)) ||
         (rc = dev_alloc(env, &st.res, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.lb_moving, (size_t)scene->n_bodies * B)) || (rc = dev_alloc(env, &st.braked, B)) || (rc = dev_alloc(env, &st.brake_steps, B)) || (rc = dev_alloc(env, &st.bt_min, B)) || 
         (rc = dev_alloc(env, &st.brake_acc, scene->check_braking_trajectory_collisions ? (size_t)(scene->brake_timeout_steps + 1) * SMR_NJ * B : 1)) || (rc = dev_alloc(env, &st.dist, (size_t)(2 * scene->n_bodies + scene->n_self_pairs) * B)) ||
         (rc = dev_alloc(env, &st.done_list, B)) || (rc = dev_alloc(env, &st.done_count, 1)) || (rc = dev_alloc(env, &st.ball, 10 * B)) ||
@@ -2748,7 +2827,9 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     hipError_t e1 = hipMemset(st.q, 0, 7 * B * 4), e2 = hipMemset(st.v, 0, 7 * B * 4), e3 = hipMemset(st.a, 0, 7 * B * 4),
                e4 = hipMemset(st.planet_idx, 0, 2 * B * 4), e5 = hipMemset(st.step_count, 0, B * 4), e6 = hipMemset(st.moving_hit, 0, B * 4),
                e7 = hipMemset(st.reset_count, 0, B * 4) ? hipErrorUnknown : hipMemset(st.start_attempts, 0, B * 4), e8 = hipMemset(st.done_count, 0, 4), e9 = hipMemset(st.a1, 0, 7 * B * 4);
-    if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9 || hipMemset(st.range_valid, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
+    if (const char *v = getenv("SMR_RANGE_AHEAD")) env->range_mode = atoi(v) != 0 ? 1 : 0;
+    if (const char *v = getenv("SMR_RANGE_HOST")) env->range_host = atoi(v) != 0;
     if (const char *v = getenv("SMR_BRAKE_BLOCK")) if (atoi(v) == 64 || atoi(v) == 128 || atoi(v) == 192 || atoi(v) == 256) env->brake_block = atoi(v);
     if (env->hscene.jobs_on) {
         const size_t NB = (size_t)scene->n_bodies, N = (size_t)scene->collision_checks_per_step;
@@ -2822,6 +2903,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     }
     if (env->staged) {
         if ((rc = dev_alloc(env, &st.next_q, 14 * B)) || (rc = dev_alloc(env, &st.next_v, 14 * B)) || (rc = dev_alloc(env, &st.next_a, 14 * B)) ||
+            (rc = dev_alloc(env, &st.next_lo, 14 * B)) || (rc = dev_alloc(env, &st.next_hi, 14 * B)) ||
             (rc = dev_alloc(env, &st.next_planet_idx, 4 * B)) || (rc = dev_alloc(env, &st.next_hit, 2 * B)) || (rc = dev_alloc(env, &st.next_attempts, 2 * B)) || (rc = dev_alloc(env, &st.staged_tag, 2 * B)) ||
             (rc = dev_alloc(env, &env->refill_lists, 3 * B)) || (rc = dev_alloc(env, &env->refill_tag_lists, 3 * B)) ||
             (rc = dev_alloc(env, &env->refill_slots, 3)) || (rc = dev_alloc(env, &st.stale_commits, 1)))
@@ -2936,6 +3018,7 @@ static void launch_reset(smr_env *env, dim3 grid, hipStream_t stream, const int 
     const size_t pad = STAGED ? env->side_lds_pad : 0;     // staged refills run beside the step: one block per CU leaves room for a jobs block (smr_create)
     if (scene_extra(env)) hipLaunchKernelGGL((reset_kernel<STAGED, true>), grid, dim3(kSideBlock), pad, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
     else hipLaunchKernelGGL((reset_kernel<STAGED, false>), grid, dim3(kSideBlock), pad, stream, env->dscene, env->st, list, count_ptr, count_fixed, stride, obs, tags, tag_offset);
+    hipLaunchKernelGGL(staged_range_kernel, dim3((unsigned)(((size_t)env->B * 8 + 255) / 256)), dim3(256), 0, stream, env->dscene, env->st, list, count_ptr, count_fixed, tags, tag_offset, STAGED ? 0 : 1);
 }
 
 static void launch_spawn(smr_env *env, dim3 grid, const int *list, const int *count_ptr, int count_fixed, int all_reset, int stride, float *obs) {
@@ -3141,6 +3224,10 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
     }
     if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
+    // The next step's safe acceleration ranges ahead of time: range_block inside the step's jobs launch, range_kernel on a stream of its own
+    // in the scenes without one (65 536 envs: space 133 -> 146 M env-steps/s, ball 141 -> 148, reaching task 109 -> 115, with the risk
+    // networks 57 -> 67, ball machine + ball 81.4 -> 81.9)
+    const bool range_ahead = env->range_mode != 0;
     const float *planned_actions = actions_dev;         // what the plan kernel maps into the safe range
     if (env->backup_net) {                              // actions.py:303-340: the backup policy's action where the risk rating objects
         LaunchTimer t(env, SMR_K_RISK);
@@ -3152,7 +3239,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         if (!simulate && !env->risk_net) { env->err = "smr_step: no risk network"; return SMR_E_INVALID; }
         const dim3 egrid((B + 255) / 256), mgrid((B + kMlpRows - 1) / kMlpRows);
         if (mode == SMR_RISK_NEXT_KINEMATIC || mode == SMR_RISK_NEXT_FULL)      // the forecast needs the requested action's end acceleration
-            hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev);
+            hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, range_ahead ? 1 : 0);
         // the network rows of the CURRENT state: the backup policy's (what replaces a risky action), and the risk network's unless it rates a simulated state
         hipLaunchKernelGGL(risk_input_kernel, egrid, dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, env->risk_x, ldx, env->backup_x, robs,
                            simulate ? SMR_RISK_CURRENT_STATE : mode);
@@ -3203,7 +3290,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     }
     {
         LaunchTimer t(env, SMR_K_PLAN);
-        hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, planned_actions);
+        hipLaunchKernelGGL(plan_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st, planned_actions, range_ahead ? 1 : 0);
     }
     SMR_HIP(hipGetLastError());
     if (env->hscene.check_braking) {                    // adapt_action: the braking acceleration replaces actions whose braking trajectory collides
@@ -3220,12 +3307,28 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         hipLaunchKernelGGL(brake_apply_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->stream, env->dscene, env->st);
         SMR_HIP(hipGetLastError());
     }
+    const bool range_in_jobs = range_ahead && env->range_host && (env->hscene.planets_jobs || env->hscene.ball_jobs);
+    const bool range_in_collide = range_ahead && env->range_host && !range_in_jobs && !env->hscene.planets_jobs;      // the lane-form collide kernel runs: rows behind its bodies
+    const bool range_hosted = range_in_jobs || range_in_collide;
+    if (range_ahead && !range_hosted) {            // the step is planned: the next step's ranges, beside the distance kernels
+        // (the stream is made when a step first needs it: every stream of the process shifts the others' places in the runtime's four hardware
+        // queues - with an idle sixth stream the staged refills of the ball-machine scenes shared a queue and took 1.8 instead of 1.1 ms)
+        if (!env->range_stream && (hipStreamCreateWithFlags(&env->range_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&env->ev_planned, hipEventDisableTiming) != hipSuccess ||
+                                   hipEventCreateWithFlags(&env->ev_ranges, hipEventDisableTiming) != hipSuccess)) { env->err = "could not create the range stream"; return SMR_E_HIP; }
+        SMR_HIP(hipEventRecord(env->ev_planned, env->stream));
+        SMR_HIP(hipStreamWaitEvent(env->range_stream, env->ev_planned, 0));
+        hipLaunchKernelGGL(range_kernel, dim3((B + 255) / 256, SMR_NJ), dim3(256), 0, env->range_stream, env->dscene, env->st);
+        SMR_HIP(hipEventRecord(env->ev_ranges, env->range_stream));
+    }
     {
         LaunchTimer t(env, SMR_K_COLLIDE);
         const bool self = scene_extra(env), autop = env->hscene.planets_auto != 0, pairs = env->hscene.n_self_pairs > 0;
         const int block = autop ? 256 : SMR_COLLIDE_BLOCK;
         const dim3 grid((B + block - 1) / block, env->hscene.n_bodies);
-        const dim3 jgrid(env->job_blocks);
+        // the next step's ranges ride along with the step's full jobs launch (range_block); scenes without one get them from range_kernel
+        const int range_blocks = range_in_jobs ? (7 * ((B + 63) / 64) + env->job_block_lanes / 64 - 1) / (env->job_block_lanes / 64) : 0;
+        const dim3 cgrid(grid.x, grid.y + (range_in_collide ? SMR_NJ : 0));
+        const dim3 jgrid(env->job_blocks + range_blocks);
         // the self-collision pairs: bounds per env, the survivors as jobs (worked by the jobs kernel behind the pair jobs of a planet
         // scene, by a launch of its own otherwise)
         const bool ball_jobs = env->hscene.ball_jobs != 0;
@@ -3234,7 +3337,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         // gained: reaching task 94 -> 86 M env-steps/s; ball scene beside the collide kernel: 63.6 -> 51.8 M; both measured)
         if (pairs) {
             hipLaunchKernelGGL(self_bounds_kernel, dim3((B + 255) / 256, env->hscene.n_self_pairs), dim3(256), 0, env->stream, env->dscene, env->st);
-            if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st, 0, 64);
+            if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st, 0, 64, 0);
         }
         if (env->hscene.planets_jobs) {
             const int env_blocks = (B + 255) / 256;
@@ -3249,15 +3352,15 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
                 if (self) hipLaunchKernelGGL((enumerate_kernel<true>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
                 else hipLaunchKernelGGL((enumerate_kernel<false>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
             }
-        } else if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL((collide_kernel<false, false>), grid, dim3(block), 0, env->stream, env->dscene, env->st);
+        } else if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st);
+        else hipLaunchKernelGGL((collide_kernel<false, false>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st);
         if (env->hscene.jobs_on) {
             if (ball_jobs) {                                  // the self pairs' and the ball's runs: one launch behind the collide kernel
                 LaunchTimer tj(env, SMR_K_JOBS);
-                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
-                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
+                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max, range_blocks);
+                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max, range_blocks);
                 if (env->defer_after > 0) {
                     if (self) hipLaunchKernelGGL((jobs_coop_kernel<true>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
                     else hipLaunchKernelGGL((jobs_coop_kernel<false>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
@@ -3265,8 +3368,8 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
             }
             if (env->hscene.planets_jobs) {
                 LaunchTimer tj(env, SMR_K_JOBS);
-                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
-                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max);
+                if (self) hipLaunchKernelGGL((jobs_kernel<true>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max, range_blocks);
+                else hipLaunchKernelGGL((jobs_kernel<false>), jgrid, dim3(env->job_block_lanes), env->job_lds_bytes, env->stream, env->dscene, env->st, env->defer_after, env->job_quota_max, range_blocks);
                 if (env->defer_after > 0) {
                     if (self) hipLaunchKernelGGL((jobs_coop_kernel<true>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
                     else hipLaunchKernelGGL((jobs_coop_kernel<false>), dim3(env->coop_blocks), dim3(1024), env->job_lds_bytes, env->stream, env->dscene, env->st);
@@ -3288,10 +3391,11 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         env->st.refill_zero = env->refill_slots + nxt;
         env->st.tp_refill_zero = env->tp_refill_slots ? env->tp_refill_slots + nxt : nullptr;
     } else { env->st.refill_zero = nullptr; env->st.tp_refill_zero = nullptr; }
+    if (range_ahead && !range_hosted) SMR_HIP(hipStreamWaitEvent(env->stream, env->ev_ranges, 0));      // finish overwrites the ranges of the envs that restart
     {
         LaunchTimer t(env, SMR_K_FINISH);
         hipLaunchKernelGGL(finish_kernel, dim3((B + 255) / 256), dim3(256), 0, env->stream, env->dscene, env->st, actions_dev, obs_dev,
-                           reward_dev, done_dev, reason_dev, info_dev, staged ? 1 : 0);
+                           reward_dev, done_dev, reason_dev, info_dev, staged ? 1 : 0, range_ahead ? 1 : 0);
     }
     SMR_HIP(hipGetLastError());
     if (env->hscene.use_ball) {
@@ -3326,6 +3430,7 @@ int smr_synchronize(smr_env_t *env) {
     if (!env) return SMR_E_INVALID;
     SMR_HIP(hipSetDevice(env->device));
     SMR_HIP(hipStreamSynchronize(env->stream));
+    if (env->range_stream) SMR_HIP(hipStreamSynchronize(env->range_stream));
     if (env->side) { SMR_HIP(hipStreamSynchronize(env->side)); SMR_HIP(hipStreamSynchronize(env->side_b)); }
     return staged_check(env);
 }
@@ -3364,6 +3469,7 @@ int smr_set_state(smr_env_t *env, const smr_host_state_t *h) {
         (rc = state_set(env, h->target, env->st.tp, 5)) || (rc = state_set(env, h->target_count, env->st.tp_count, 1)))
         return rc;
     SMR_HIP(hipMemset(env->st.lb_moving, 0xFF, (size_t)env->hscene.n_bodies * env->B * 4));     // NaN: the bounds of the last step no longer hold
+    SMR_HIP(hipMemset(env->st.range_valid, 0, (size_t)env->B * 4));                              // ... nor do the ranges computed ahead
     SMR_HIP(hipDeviceSynchronize());
     if (env->staged && h->reset_count) {               // the staged start states belong to the old reset counters
         if ((rc = staged_prepare_all(env, 0)) || (rc = staged_prepare_all(env, 1))) return rc;
