@@ -219,6 +219,7 @@ struct PhaseClock {
 #endif
 template <int NM>
 __device__ __forceinline__ void push_jobs(const DState &st, int env, const int (&bodies)[NM], const uint32_t (&masks)[NM], int k, int kind);      // (pair-job path, below)
+__device__ __forceinline__ void self_bounds_row(const DScene &S, const DState &st, int pair, int e0);
 constexpr int kMaxItemsPerLane = kMaxChecksPerStep - 1;   // N - 1 intermediate samples (check_scene: N <= kMaxChecksPerStep)
 // SELF: the scene has self-collision pairs (ball machine); the plain robot runs the instantiation without that code
 // AUTO: lane-autonomous planet queries (planet_queries_auto); four wavefronts then share the LDS copies
@@ -226,12 +227,19 @@ constexpr int kMaxItemsPerLane = kMaxChecksPerStep - 1;   // N - 1 intermediate 
 #define SMR_COLLIDE_BLOCK 128    // ball scenes (no lane-autonomous planet queries): two wavefronts share the LDS copies (64 -> 128 lanes: ball 139.1 -> 141.7 M, 256: 131.2)
 #endif
 template <bool SELF, bool AUTO>
-__global__ __launch_bounds__(AUTO ? 256 : SMR_COLLIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st) {
+__global__ __launch_bounds__(AUTO ? 256 : SMR_COLLIDE_BLOCK) __attribute__((amdgpu_waves_per_eu(SMR_COLLIDE_WAVES, SMR_COLLIDE_WAVES))) void collide_kernel(const DScene *__restrict__ Sp, DState st, int pair_rows) {
     const DScene &S = *Sp;
     constexpr int kBlock = AUTO ? 256 : SMR_COLLIDE_BLOCK;
     SMR_ROW_CLOCK((int)blockIdx.y);
-    // rows behind the bodies (a ball scene without a jobs launch): the next step's safe acceleration ranges, row n_bodies + j = joint j (range_wave)
-    if ((int)blockIdx.y >= S.n_bodies) { range_wave(S, st, (int)blockIdx.y - S.n_bodies, (int)(blockIdx.x * blockDim.x + threadIdx.x)); return; }
+    // rows behind the bodies: the bound tests of the self-collision pairs (self_bounds_row: light rows that fill the grid's tail instead of a
+    // launch of their own in front of it), then - a ball scene without a jobs launch - the next step's safe acceleration ranges, one row per
+    // joint (range_wave)
+    if ((int)blockIdx.y >= S.n_bodies) {
+        const int r = (int)blockIdx.y - S.n_bodies, e0 = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (r < pair_rows) { if (SELF) self_bounds_row(S, st, r, e0); }
+        else range_wave(S, st, r - pair_rows, e0);
+        return;
+    }
     // grid y: the bodies, outer ones (most planet work, the longest blocks) leading.  (The self-collision pairs of a scene with mounted
     // bodies are not rows of this grid: self_bounds_kernel / jobs_kernel.)
     const int l = S.body_order[(int)blockIdx.y];
@@ -387,6 +395,10 @@ template <bool SELF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SMR_KEYS_WAVES, SMR_KEYS_WAVES))) void keys_kernel(const DScene *__restrict__ Sp, DState st) {
     const DScene &S = *Sp;
     constexpr int kBlock = 256;
+    if ((int)blockIdx.y >= S.n_bodies) {                 // rows behind the bodies: the self-collision pairs' bound tests (see collide_kernel)
+        if (SELF) self_bounds_row(S, st, (int)blockIdx.y - S.n_bodies, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+        return;
+    }
     const int l = S.body_order[(int)blockIdx.y];
     const int B = S.B, N = S.checks_per_step, NB = S.n_bodies;
     {
@@ -574,10 +586,13 @@ __device__ __forceinline__ void push_jobs(const DState &st, int env, const int (
 // end of the step (bound table, spheres, capsules: self_pair_cleared); a pair they cannot put beyond the distance range the reward
 // reads (DScene::self_cut) becomes a job of kind kJobSelf: 0.3 per env on uniformly drawn states, where the 14 pairs of the ball
 // machine used to be 14 rows of the collide grid with a GJK run in most lanes of the two rows against iiwa_link_5.
+// (the rows of one pair: a kernel of its own - self_bounds_kernel - or rows behind the bodies of the keys / collide grid, round 4)
+__device__ __forceinline__ void self_bounds_row(const DScene &S, const DState &st, int pair, int e0);
 __global__ __launch_bounds__(256) void self_bounds_kernel(const DScene *__restrict__ Sp, DState st) {
-    const DScene &S = *Sp;
-    const int B = S.B, pair = (int)blockIdx.y;
-    const int e0 = blockIdx.x * blockDim.x + threadIdx.x;
+    self_bounds_row(*Sp, st, (int)blockIdx.y, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+__device__ __forceinline__ void self_bounds_row(const DScene &S, const DState &st, int pair, int e0) {
+    const int B = S.B;
     const bool valid = e0 < B;
     const int e = valid ? e0 : B - 1;
     float q[SMR_NJ];
@@ -2430,6 +2445,7 @@ struct smr_env {
     // the next step's safe acceleration ranges are computed beside the distance kernels (range_kernel; SMR_RANGE_AHEAD=0: by the plan kernel, as before)
     int range_mode = 1;                               // SMR_RANGE_AHEAD=0: the plan kernel computes the ranges itself, as it did until round 4 (A/B switch)
     bool range_host = true;                           // as extra blocks of the jobs kernel where the step has one (SMR_RANGE_HOST=0: always the stream)
+    bool self_rows = false;                           // SMR_SELF_ROWS=1: the self-collision pairs' bound tests as rows of the keys / collide grid instead of self_bounds_kernel (measured: -1.6 .. +2 %, opt-in)
     hipStream_t range_stream = nullptr;
     hipEvent_t ev_planned = nullptr, ev_ranges = nullptr;
     DScene hscene;              // host copy (device pointers inside)
@@ -2830,6 +2846,7 @@ int smr_create(const smr_scene_t *scene, int32_t num_envs, uint32_t env_index_ba
     if (e1 || e2 || e3 || e4 || e5 || e6 || e7 || e8 || e9 || hipMemset(st.range_valid, 0, B * 4)) { env->err = "hipMemset failed"; return fail(SMR_E_HIP); }
     if (const char *v = getenv("SMR_RANGE_AHEAD")) env->range_mode = atoi(v) != 0 ? 1 : 0;
     if (const char *v = getenv("SMR_RANGE_HOST")) env->range_host = atoi(v) != 0;
+    if (const char *v = getenv("SMR_SELF_ROWS")) env->self_rows = atoi(v) != 0;
     if (const char *v = getenv("SMR_BRAKE_BLOCK")) if (atoi(v) == 64 || atoi(v) == 128 || atoi(v) == 192 || atoi(v) == 256) env->brake_block = atoi(v);
     if (env->hscene.jobs_on) {
         const size_t NB = (size_t)scene->n_bodies, N = (size_t)scene->collision_checks_per_step;
@@ -3327,15 +3344,17 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
         const dim3 grid((B + block - 1) / block, env->hscene.n_bodies);
         // the next step's ranges ride along with the step's full jobs launch (range_block); scenes without one get them from range_kernel
         const int range_blocks = range_in_jobs ? (7 * ((B + 63) / 64) + env->job_block_lanes / 64 - 1) / (env->job_block_lanes / 64) : 0;
-        const dim3 cgrid(grid.x, grid.y + (range_in_collide ? SMR_NJ : 0));
+        // the self-collision pairs' bound tests: a kernel of their own in front (SMR_SELF_ROWS=1: rows behind the bodies of the keys / collide grid)
+        const bool ball_jobs = env->hscene.ball_jobs != 0;
+        const bool self_jobs_alone = pairs && !env->hscene.planets_jobs && !ball_jobs;      // no pair / ball jobs to work them behind
+        const int pair_rows = (pairs && !self_jobs_alone && env->self_rows) ? env->hscene.n_self_pairs : 0;
+        const dim3 cgrid(grid.x, grid.y + pair_rows + (range_in_collide ? SMR_NJ : 0));
         const dim3 jgrid(env->job_blocks + range_blocks);
         // the self-collision pairs: bounds per env, the survivors as jobs (worked by the jobs kernel behind the pair jobs of a planet
         // scene, by a launch of its own otherwise)
-        const bool ball_jobs = env->hscene.ball_jobs != 0;
-        const bool self_jobs_alone = pairs && !env->hscene.planets_jobs && !ball_jobs;      // no pair / ball jobs to work them behind
         // (on a stream of their own beside the other distance kernels they finished sooner, but took from the staged refills what they
         // gained: reaching task 94 -> 86 M env-steps/s; ball scene beside the collide kernel: 63.6 -> 51.8 M; both measured)
-        if (pairs) {
+        if (pairs && !pair_rows) {
             hipLaunchKernelGGL(self_bounds_kernel, dim3((B + 255) / 256, env->hscene.n_self_pairs), dim3(256), 0, env->stream, env->dscene, env->st);
             if (self_jobs_alone) hipLaunchKernelGGL((jobs_kernel<true>), dim3(env->self_job_blocks), dim3(512), env->job_lds_bytes, env->stream, env->dscene, env->st, 0, 64, 0);
         }
@@ -3344,7 +3363,7 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
             const dim3 egrid(env_blocks + (env->N > 1 ? env->item_blocks : 0));      // behind the env blocks: a fixed grid striding over the items
             {
                 LaunchTimer tk(env, SMR_K_KEYS);
-                if (self) hipLaunchKernelGGL((keys_kernel<true>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
+                if (self) hipLaunchKernelGGL((keys_kernel<true>), dim3(grid.x, grid.y + pair_rows), dim3(256), 0, env->stream, env->dscene, env->st);
                 else hipLaunchKernelGGL((keys_kernel<false>), grid, dim3(256), 0, env->stream, env->dscene, env->st);
             }
             {
@@ -3352,10 +3371,10 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
                 if (self) hipLaunchKernelGGL((enumerate_kernel<true>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
                 else hipLaunchKernelGGL((enumerate_kernel<false>), egrid, dim3(256), 0, env->stream, env->dscene, env->st, env_blocks);
             }
-        } else if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st);
-        else hipLaunchKernelGGL((collide_kernel<false, false>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st);
+        } else if (self && autop) hipLaunchKernelGGL((collide_kernel<true, true>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st, pair_rows);
+        else if (self) hipLaunchKernelGGL((collide_kernel<true, false>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st, pair_rows);
+        else if (autop) hipLaunchKernelGGL((collide_kernel<false, true>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st, pair_rows);
+        else hipLaunchKernelGGL((collide_kernel<false, false>), cgrid, dim3(block), 0, env->stream, env->dscene, env->st, pair_rows);
         if (env->hscene.jobs_on) {
             if (ball_jobs) {                                  // the self pairs' and the ball's runs: one launch behind the collide kernel
                 LaunchTimer tj(env, SMR_K_JOBS);
