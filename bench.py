@@ -286,7 +286,7 @@ def main():
     # HIP events around the launches of every `period`-th timed step: a pair of events is a pair of barrier packets in the queue, and around
     # every launch of every step they cost the step 12 % (0.485 -> 0.550 ms at 65 536 envs, measured)
     repeats = 1 if args.steps >= 100 else 5              # (see the timed regions below)
-    period = max(1, min(8, args.steps * repeats // 4))
+    period = max(1, min(16, args.steps * repeats // 6))  # at least six sampled steps; 16: the timed launches cost the run under 1 %
     env.set_profiling(period)
     # A short run (the driver's 20 steps after 5 warm-up steps) is timed `repeats` times back to back and the MEDIAN region is reported:
     # a single 10 ms region right after reset() holds the burst in which every surviving env ends its first episode (39 577 of

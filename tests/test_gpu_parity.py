@@ -683,6 +683,45 @@ def test_episode_metrics_on_the_gpu_env(built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["space", "ball", "reach"])
+def test_ranges_prepared_one_step_ahead_equal_the_plan_kernels_own(built, monkeypatch, scene):
+    """The safe acceleration ranges of step t + 1 are computed during step t (extra blocks of the jobs launch / extra rows of the collide
+    grid; restarting envs bring the range of their staged start state) - SMR_RANGE_AHEAD=0 lets the plan kernel compute them as it did
+    before.  Same function of the same state: the two runs agree as two batch compositions do (test_ragged_batches), episodes end in the same
+    steps but for distances on a threshold, and a state injected in between (set_state
+    invalidates the prepared ranges) changes nothing."""
+    import torch
+    import safemotionsrisk_amd as smr
+    cfg = {"space": smr.SPACE_ENV_CONFIG, "ball": smr.BALL_ENV_CONFIG, "reach": smr.REACH_ENV_CONFIG}[scene]
+    B, T = 2048, 30
+    acts = np.random.default_rng(5).uniform(-1, 1, (T, B, 7)).astype(np.float32)
+    runs = []
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("SMR_RANGE_AHEAD", ahead)
+        env = smr.VecSafeMotionsEnv(B, device=0, seed=3, auto_reset=True, **cfg)
+        monkeypatch.delenv("SMR_RANGE_AHEAD")
+        rec = [env.reset().cpu().numpy().copy()]
+        for t in range(T):
+            if t == 12:                                   # an injected state: the same one, so the runs stay comparable
+                st = env.get_state()
+                env.set_state(**{k: st[k] for k in env.STATE_KEYS})
+            obs, rew, done, info = env.step(torch.from_numpy(acts[t]).cuda())
+            rec.append(np.concatenate([obs.cpu().numpy(), rew.cpu().numpy()[:, None], done.cpu().numpy()[:, None].astype(np.float32)], axis=1))
+        runs.append(rec)
+        env.close()
+    assert np.array_equal(runs[0][0], runs[1][0])
+    # (the tolerance of test_ragged_batches: a range end is the largest feasible point the wavefront's shared k-section evaluated, and which
+    # points it evaluates depends on how many lanes of the wavefront have an open bracket - the two runs differ in exactly that)
+    alive = np.ones(B, bool)                              # envs whose episodes ended in the same steps so far
+    close, tight = [], []
+    for a, b in zip(runs[0][1:], runs[1][1:]):
+        alive &= a[:, -1] == b[:, -1]
+        d = np.abs(a[alive, :-2] - b[alive, :-2]).max(axis=1)
+        close.append((d < 1e-4).mean()); tight.append((d < 2e-6).mean())
+    assert alive.mean() > 0.99 and min(close) > 0.97 and np.mean(tight) > 0.8, (alive.mean(), min(close), np.mean(tight))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("auto_reset", [False, True])
 def test_ragged_batches_give_the_same_envs(built, auto_reset):
     """Batch sizes that fill neither a wavefront nor a 256-lane block (1, 63, 257, 1000): env i is the same env in every batch
