@@ -1,4 +1,5 @@
-"""Generates tests/golden/ball_step.npz (ball scene, BASELINE configs[3]) from the float64 oracle; see make_golden.py."""
+"""Generates tests/golden/ball_step.npz (ball scene, BASELINE configs[3]) and ball_bm_step.npz (the same scene on robot_ball_machine.urdf =
+the shipped backup_networks/ball/params.json: self-collision pairs, the runs against the ball as jobs) from the float64 oracle; see make_golden.py."""
 import os
 import sys
 
@@ -11,9 +12,9 @@ from oracle.oracle import OracleEnv                                  # noqa: E40
 from safemotionsrisk_amd.scene import BALL_ENV_CONFIG, build_scene   # noqa: E402
 
 
-def main():
+def main(ball_machine=False):
     B, T = 256, 8
-    scene = build_scene(BALL_ENV_CONFIG, auto_reset=False)
+    scene = build_scene(dict(BALL_ENV_CONFIG, ball_machine_mode=ball_machine), auto_reset=False)
     env = OracleEnv(scene, B, seed=17, num_threads=4)
     env.reset()
     st = env.get_state()
@@ -33,11 +34,11 @@ def main():
         env.set_state(q=f32(st["q"]), v=f32(st["v"]), a=f32(st["a"]), ball=f32(st["ball"]),
                       step_count=np.where(d, 0, st["step_count"]))
     out.update(actions=actions, **{k: np.array(v) for k, v in rec.items()})
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ball_step.npz")
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ball_bm_step.npz" if ball_machine else "ball_step.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes; done", out["done"].mean(), "reasons", np.unique(out["reason"]),
           "spawns", (out["ball_i"][-1][:, 4] - out["ball_i0"][:, 4]).sum())
 
 
 if __name__ == "__main__":
-    main()
+    main("bm" in sys.argv[1:])

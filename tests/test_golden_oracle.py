@@ -52,11 +52,12 @@ def test_oracle_reproduces_golden_components(built, space_scene):
         assert np.allclose(lo, g["comp_lo"][i]) and np.allclose(hi, g["comp_hi"][i]) and np.array_equal(code, g["comp_code"][i])
 
 
-def test_oracle_reproduces_golden_ball_vectors(built):
+@pytest.mark.parametrize("name", ["ball_step.npz", "ball_bm_step.npz"])
+def test_oracle_reproduces_golden_ball_vectors(built, name):
     from safemotionsrisk_amd.scene import BALL_ENV_CONFIG, build_scene
-    g = np.load(os.path.join(os.path.dirname(GOLD), "ball_step.npz"))
+    g = np.load(os.path.join(os.path.dirname(GOLD), name))
     B, T = int(g["B"]), int(g["T"])
-    env = OracleEnv(build_scene(BALL_ENV_CONFIG, auto_reset=False), B, seed=int(g["seed"]), num_threads=4)
+    env = OracleEnv(build_scene(dict(BALL_ENV_CONFIG, ball_machine_mode=name == "ball_bm_step.npz"), auto_reset=False), B, seed=int(g["seed"]), num_threads=4)
     env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], step_count=g["step_count0"], moving_hit=0, ball=g["ball0"], ball_i=g["ball_i0"])
     f32 = lambda x: x.astype(np.float32)
     for t in range(T):

@@ -310,11 +310,14 @@ def test_ball_components_against_oracle(built):
     env.close()
 
 
-def test_ball_step_against_golden(built):
+@pytest.mark.parametrize("name", ["ball_step.npz", "ball_bm_step.npz"])
+def test_ball_step_against_golden(built, name):
+    """ball_bm_step.npz: the same scene on robot_ball_machine.urdf (the shipped backup_networks/ball/params.json) - self-collision pairs,
+    and the runs against the ball as jobs of the jobs kernel"""
     import torch
-    g = np.load(os.path.join(os.path.dirname(GOLD), "ball_step.npz"))
+    g = np.load(os.path.join(os.path.dirname(GOLD), name))
     B, T = int(g["B"]), int(g["T"])
-    env = _ball_env(B, seed=int(g["seed"]))
+    env = _ball_env(B, name == "ball_bm_step.npz", seed=int(g["seed"]))
     env.set_state(q=g["q0"], v=g["v0"], a=g["a0"], step_count=g["step_count0"], moving_hit=0, ball=g["ball0"], ball_i=g["ball_i0"])
     from oracle.oracle import OracleEnv
     ora = OracleEnv(env.scene, 1)
@@ -807,6 +810,39 @@ def test_shards_are_a_partition_of_the_global_batch(built, scene):
         assert all(np.array_equal(st_one[k], st[k]) for k in st_one)
     dones = sum(r[:, one[0].shape[1] + 1].sum() for r in one[1:] if r.shape[1] > one[0].shape[1])
     assert dones > 100                                          # auto-resets happened inside the compared window
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ball_machine", [False, True])
+def test_ragged_batches_in_the_ball_scenes(built, ball_machine):
+    """The same for the ball scenes, whose collide grid has 128-lane blocks and rows behind the bodies (the next step's acceleration ranges
+    on the plain robot; with the ball machine mounted the runs against the ball are jobs and the ranges ride in the jobs launch): batch
+    sizes that fill neither a wavefront nor a block give every env the values it has in a batch of 1000 - bit for bit in complete
+    wavefronts - through auto-resets, ball launches and respawns."""
+    import torch
+    T = 24
+    acts = np.random.default_rng(6).uniform(-1, 1, (T, 1000, 7)).astype(np.float32)
+    outs = {}
+    for B in (1000, 321, 129, 5):
+        env = _ball_env(B, ball_machine, seed=23, auto_reset=True)
+        rec = [env.reset().cpu().numpy().copy()]
+        for t in range(T):
+            obs, rew, done, info = env.step(torch.from_numpy(acts[t, :B]).cuda())
+            rec.append(np.concatenate([obs.cpu().numpy(), rew.cpu().numpy()[:, None], done.cpu().numpy()[:, None].astype(np.float32),
+                                       info["termination_reason"].cpu().numpy()[:, None].astype(np.float32), info["values"].cpu().numpy()], axis=1))
+        st = env.get_state()
+        rec.append(np.concatenate([st["ball"], st["ball_i"].astype(np.float32)], axis=1))
+        outs[B] = rec
+        env.close()
+    for B in (321, 129, 5):
+        full = (B // 64) * 64
+        close = []
+        for t in range(T + 2):
+            assert np.array_equal(outs[B][t][:full], outs[1000][t][:full]), (B, t)
+            if full < B:
+                close.append(np.abs(outs[B][t][full:] - outs[1000][t][full:B]).max(axis=1) < 1e-4)
+        assert np.mean(np.concatenate(close)) > 0.95, (B, np.mean(np.concatenate(close)))
+    assert sum(r[:, -17].sum() for r in outs[1000][1:-1]) > 500            # (done column) episodes ended
 
 
 def _scene_of(auto_reset):
