@@ -276,6 +276,17 @@ def test_profiling_counters(built):
     env.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,switch", [("space_step.npz", "SMR_COLLIDE_LANES"), ("space_bm_step.npz", "SMR_COLLIDE_LANES"),
+                                         ("reach_step.npz", "SMR_SELF_ROWS"), ("space_bm_step.npz", "SMR_SELF_ROWS")])
+def test_step_against_golden_under_the_ab_switches(built, monkeypatch, name, switch):
+    """The A/B switches that keep an older form of the distance stage alive stay correct: SMR_COLLIDE_LANES=1 (planet scenes in the
+    lane-per-(env, body) collide kernel, with the next step's ranges as rows of its grid), SMR_SELF_ROWS=1 (the self-collision pairs' bound
+    tests as rows of the keys grid)."""
+    monkeypatch.setenv(switch, "1")
+    test_step_against_golden(built, name)
+
+
 # ------------------------------------------------------------------ ball scene (A10, BASELINE configs[3])
 def _ball_env(B, ball_machine=False, **kw):
     import torch
