@@ -61,6 +61,11 @@ __global__ __launch_bounds__(256) void plan_kernel(const DScene *__restrict__ Sp
         if (!have) { lo = lo2; hi = hi2; }
     }
     if (!live) return;
+    if (j == 0 && e == 0) {                            // this step's list counters (a memset each on the stream was a 5 us kernel of its own: 2 % of a ball-scene step)
+        if (st.done_count) *st.done_count = 0;
+        if (st.spawn_count) *st.spawn_count = 0;
+        if (st.tp_list_count) *st.tp_list_count = 0;
+    }
     if (j == 0 && S.check_braking) { st.braked[e] = 0; st.bt_min[e] = 0x7F800000u; }   // set by brake_plan_kernel / brake_check_kernel
     if (j == 0 && S.jobs_on) {                         // the accumulators and lists of this step's jobs (self_bounds / keys / enumerate / jobs kernels)
         if (S.planets_jobs) {
@@ -3261,13 +3266,11 @@ int smr_step(smr_env_t *env, const float *actions_dev, float *obs_dev, float *re
     // (0.485 -> 0.550 ms at 65 536 envs, measured) - with a period the timed steps are a sample
     struct ProfilingScope { smr_env *e; ~ProfilingScope() { e->profiling = false; } } profiling_scope{env};      // this call's own flag
     env->profiling = env->profile_every > 0 && (env->step_seq++ % env->profile_every) == 0;
-    if (env->auto_reset && !(env->staged && env->auto_reset)) SMR_HIP(hipMemsetAsync(env->st.done_count, 0, sizeof(int), env->stream));   // staged: unused
     if (env->hscene.use_ball) {
         // this step's spawn list: the side stream may still be re-staging from the other one
         env->st.spawn_list = env->spawn_lists + (size_t)env->rot * B; env->st.spawn_tags = env->spawn_tag_lists + (size_t)env->rot * B; env->st.spawn_count = env->spawn_counts + env->rot;
-        SMR_HIP(hipMemsetAsync(env->st.spawn_count, 0, sizeof(int), env->stream));
     }
-    if (env->hscene.use_target) SMR_HIP(hipMemsetAsync(env->st.tp_list_count, 0, sizeof(int), env->stream));
+    // (done_count / spawn_count / tp_list_count of this step: cleared by the plan kernel)
     // The next step's safe acceleration ranges ahead of time: range_block inside the step's jobs launch, range_kernel on a stream of its own
     // in the scenes without one (65 536 envs: space 133 -> 146 M env-steps/s, ball 141 -> 148, reaching task 109 -> 115, with the risk
     // networks 57 -> 67, ball machine + ball 81.4 -> 81.9)
